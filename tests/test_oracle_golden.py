@@ -1,0 +1,168 @@
+"""Pins the CPU oracle to the golden vectors produced by the reference itself
+(tests/golden/gen_golden.py).  Bit-exact for T-PPR arrays and state; 1e-4 for
+float32 network outputs (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import inputs as I
+from conftest import golden
+
+EMB_TOL = 1e-4
+
+
+def _state_equal(oracle_state, g, m):
+    for kk in ("len", "norm", "eidx", "node", "ts", "w"):
+        a, b = oracle_state[kk], g["state%d_%s" % (m, kk)]
+        assert a.shape == b.shape and np.array_equal(a, b), "state mismatch %s model %d" % (kk, m)
+
+
+@pytest.mark.parametrize("name", list(I.STREAM_CASES))
+def test_streaming_matches_reference(oracle, name):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES[name]
+    g = golden("g1_stream_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = oracle.TpprOracle(N, k, len(al), al, be)
+    nb = (E + bs - 1) // bs
+    full = set(g["full_idx"].tolist())
+    for b in range(nb):
+        s, e = b * bs, min(E, (b + 1) * bs)
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        on, oe, od, ow = f.streaming_topk(nodes, np.concatenate([ts[s:e]] * 3), eidx[s:e])
+        arrs = []
+        for m in range(len(al)):
+            arrs += [on[m], oe[m], od[m], ow[m]]
+        if b in full:
+            assert np.array_equal(np.stack(on), g["b%d_nodes" % b])
+            assert np.array_equal(np.stack(oe), g["b%d_eidx" % b])
+            assert np.array_equal(np.stack(od), g["b%d_dt" % b])
+            assert np.array_equal(np.stack(ow), g["b%d_w" % b])
+        assert I.digest(arrs) == str(g["digests"][b]), "batch %d differs from the reference" % b
+    for m in range(len(al)):
+        _state_equal(f.export(m), g, m)
+
+
+def test_streaming_variants(oracle):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES["tiny_general"]
+    g = golden("g1_variants")
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = oracle.TpprOracle(N, k, len(al), al, be)
+    on, oe, od, ow = f.streaming_topk_no_fake(np.concatenate([src[:40], dst[:40]]), ts[:40], eidx[:40])
+    assert np.array_equal(np.stack(on), g["nf_nodes"]) and np.array_equal(np.stack(oe), g["nf_eidx"])
+    assert np.array_equal(np.stack(od), g["nf_dt"]) and np.array_equal(np.stack(ow), g["nf_w"])
+    sn, se, sd, sw = f.single_streaming_topk(np.concatenate([src[40:80], dst[40:80], neg[40:80]]), ts[40:80],
+                                             eidx[40:80], 1)
+    assert np.array_equal(sn, g["single_nodes"]) and np.array_equal(se, g["single_eidx"])
+    assert np.array_equal(sd, g["single_dt"]) and np.array_equal(sw, g["single_w"])
+    for m in range(len(al)):
+        _state_equal(f.export(m), g, m)
+
+
+def test_fill_matches_compute_val_tppr(oracle):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES["bip_k20"]
+    g = golden("g2_fill")
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = oracle.TpprOracle(N, k, len(al), al, be)
+    f.update_only(src[:1000], dst[:1000], ts[:1000], eidx[:1000])
+    for m in range(len(al)):
+        _state_equal(f.export(m), g, m)
+    # the reference's backup/restore alias the live state
+    assert bool(g["alias"]) and bool(g["restore_is_noop"])
+
+
+def test_hub_case_exercises_unstable_ties(oracle):
+    """The hub fixture must contain sorts where numba's quicksort and a stable
+    sort disagree, otherwise it does not pin the tie semantics."""
+    rng = np.random.RandomState(0)
+    diff = 0
+    for _ in range(200):
+        v = rng.randint(0, 4, 41).astype(np.float64)
+        if not np.array_equal(oracle.numba_argsort(v), np.argsort(v, kind="stable")):
+            diff += 1
+    assert diff > 0
+
+
+@pytest.mark.parametrize("name", list(I.PRUNE_CASES))
+def test_pruning_matches_reference(oracle, name):
+    kind, N, E, seed, nq, width, depth, k, alpha, beta = I.PRUNE_CASES[name]
+    g = golden("g3_prune_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    csr = oracle.CsrOracle(src, dst, eidx, ts)
+    for v in g["probe"]:
+        nb, ei, tt = csr.find_before(int(v), np.inf)
+        assert np.array_equal(nb, g["adj%d_nbr" % v]) and np.array_equal(ei, g["adj%d_eid" % v])
+        assert np.array_equal(tt, g["adj%d_ts" % v])
+    on = np.zeros((nq, k), np.int32)
+    oe = np.zeros((nq, k), np.int32)
+    od = np.zeros((nq, k), np.float32)
+    ow = np.zeros((nq, k), np.float32)
+    csr.get_pruned_topk(g["q_nodes"], g["q_ts"], width, depth, alpha, beta, k, on, oe, od, ow)
+    assert np.array_equal(on, g["nodes"]) and np.array_equal(oe, g["eidx"])
+    assert np.array_equal(od, g["dt"]) and np.array_equal(ow, g["w"])
+
+
+def test_numba_int_pow_matches_python_restatement(oracle):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import numba_semantics as ns
+    for beta in (0.5, 0.95, 0.9, 0.7, 0.999):
+        for n in (0, 1, 2, 3, 7, 20, 63, 64, 1000, 65536, 65537, 200000):
+            assert oracle.numba_int_pow(beta, n) == ns.numba_int_pow(beta, n)
+    rng = np.random.RandomState(3)
+    for n in (1, 2, 15, 16, 17, 41, 81, 155, 420):
+        for _ in range(20):
+            v = np.round(rng.random_sample(n), 1 if _ % 2 else 6)
+            assert np.array_equal(oracle.numba_argsort(v), ns.numba_argsort(v))
+
+
+@pytest.mark.parametrize("name", list(I.EMBED_CASES))
+def test_embedding_and_memory_protocol(oracle, name):
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g45_embed_" + name)
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tw = I.time_encode_weights(T)
+    M = len(al)
+
+    # G4: embedding from a random memory table
+    f = oracle.TpprOracle(N, k, M, al, be)
+    half = E // 2
+    f.update_only(src[:half], dst[:half], ts[:half], eidx[:half])
+    s, e = half, half + bs
+    nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+    on, oe, od, ow = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+    emb = oracle.embed(mem0, efeat, tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow), w)
+    assert np.abs(emb - g["emb"]).max() <= EMB_TOL
+    avg = np.mean(np.sum(ow[0][:2 * bs], axis=1))
+    assert abs(avg - float(g["average_topk"])) < 1e-6
+
+    # G5: eval-mode protocol (model/tgn_model.py:124-174), 4 consecutive batches
+    f = oracle.TpprOracle(N, k, M, al, be)
+    mem = oracle.MemoryOracle(N, D, 2 * D + F + T)
+    gru = {kk: w[kk] for kk in ("w_ih", "w_hh", "b_ih", "b_hh")}
+    aff = dict(fc1_w=w["aff1_w"], fc1_b=w["aff1_b"], fc2_w=w["aff2_w"], fc2_b=w["aff2_b"])
+    mem.gru_update(gru, None)                        # first eval batch flushes pending messages
+    for b in range(nb):
+        s, e = b * bs, (b + 1) * bs
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        on, oe, od, ow = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        emb = oracle.embed(mem.memory, efeat, tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow), w)
+        assert np.abs(emb - g["eval_b%d_emb" % b]).max() <= EMB_TOL, "batch %d" % b
+        B = e - s
+        prob = oracle.affinity(np.concatenate([emb[:B], emb[:B]]), np.concatenate([emb[B:2 * B], emb[2 * B:]]), aff)
+        assert np.abs(prob - g["eval_b%d_prob" % b]).max() <= EMB_TOL
+        mem.store_messages(efeat, tw, src[s:e], dst[s:e], ts[s:e], eidx[s:e])
+        mem.gru_update(gru, np.unique(np.concatenate([src[s:e], dst[s:e]])))
+    pre = "eval_b%d_" % (nb - 1)
+    assert np.abs(mem.memory - g[pre + "memory"]).max() <= EMB_TOL
+    assert np.array_equal(mem.last_update, g[pre + "last_update"])
+    assert np.abs(mem.messages - g[pre + "messages"]).max() <= EMB_TOL
+    assert np.array_equal(mem.timestamps, g[pre + "timestamps"])
+    assert np.array_equal(mem.flags, g[pre + "flags"])
+
+
+def test_time_encode(oracle):
+    g = golden("g6_timeencode")
+    assert np.array_equal(I.time_encode_weights(100), g["time_w"])
+    enc = np.cos(g["dts"][..., None] * g["time_w"][None, None, :]).astype(np.float32)
+    assert np.abs(enc - g["enc"]).max() <= 1e-6

@@ -1,0 +1,79 @@
+"""Synthetic temporal edge streams.
+
+No dataset ships with the build and none can be downloaded, so tests, the
+golden-vector generator and bench.py all draw streams from here.  Shapes follow
+the reference's on-disk format (utils/preprocess_data.py:30-79): node ids and
+edge ids are 1-based, id 0 is padding, bipartite graphs put users in
+1..U and items in U+1..U+I; timestamps are non-decreasing float64 seconds.
+"""
+import numpy as np
+
+
+def _power_law_sampler(n, s, rng, perm_seed=None):
+    """Return draw(m) -> int64[m] ranks in [0, n) with p(r) ~ (r+1)^-s."""
+    p = np.arange(1, n + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+
+    def draw(m):
+        return np.minimum(np.searchsorted(cdf, rng.random_sample(m)), n - 1)
+    return draw
+
+
+def power_law_stream(n_nodes, n_edges, bipartite=None, s=0.9, seed=2020, mean_dt=30.0,
+                     t0=0.0, first_eidx=1):
+    """Bounded power-law temporal stream.
+
+    n_nodes  : number of real nodes (ids 1..n_nodes); ignored when bipartite.
+    bipartite: (U, I) -> sources in 1..U, destinations in U+1..U+I.
+    Returns src int32[E], dst int32[E], ts float64[E] (strictly increasing),
+    eidx int64[E] = first_eidx..first_eidx+E-1.
+    """
+    rng = np.random.RandomState(seed)
+    if bipartite is not None:
+        U, I = bipartite
+        src = 1 + _power_law_sampler(U, s, rng)(n_edges)
+        dst = 1 + U + _power_law_sampler(I, s, rng)(n_edges)
+    else:
+        draw = _power_law_sampler(n_nodes, s, rng)
+        src = 1 + draw(n_edges)
+        dst = 1 + draw(n_edges)
+    ts = t0 + np.cumsum(rng.exponential(mean_dt, n_edges))
+    eidx = np.arange(first_eidx, first_eidx + n_edges, dtype=np.int64)
+    return src.astype(np.int32), dst.astype(np.int32), ts.astype(np.float64), eidx
+
+
+def negatives(dst, n, seed=0):
+    """RandEdgeSampler.sample's destination half (utils/util.py:69-84): uniform
+    over the observed (unique) destinations."""
+    rng = np.random.RandomState(seed)
+    uniq = np.unique(dst)
+    return uniq[rng.randint(0, len(uniq), n)].astype(np.int32)
+
+
+def edge_features(n_edges_plus1, F, seed=1):
+    """[|E|+1, F] float32; row 0 is the padding row (zeros).  F == 1 means the
+    dataset has no edge features and the reference substitutes zeros
+    (train.py:133-136)."""
+    if F == 1:
+        return np.zeros((n_edges_plus1, 1), np.float32)
+    rng = np.random.RandomState(seed)
+    f = rng.standard_normal((n_edges_plus1, F)).astype(np.float32)
+    f[0] = 0
+    return f
+
+
+# Shapes of BASELINE.json's configs (SURVEY.md section 8, table at the top).
+WORKLOADS = {
+    # name: dict(nodes, edges, bipartite, F, bs, k, strategy, alpha, beta)
+    "c1": dict(bipartite=(8227, 1000), n_nodes=9227, n_edges=157474, F=172, bs=200, k=20,
+               strategy="streaming", alpha=[0.1], beta=[0.9]),
+    "c2": dict(bipartite=(8227, 1000), n_nodes=9227, n_edges=157474, F=172, bs=200, k=20,
+               strategy="streaming", alpha=[0.1, 0.1], beta=[0.5, 0.95]),
+    "c3": dict(bipartite=(10000, 984), n_nodes=10984, n_edges=672447, F=172, bs=600, k=20,
+               strategy="streaming", alpha=[0.1, 0.1], beta=[0.5, 0.95]),
+    "c4": dict(bipartite=None, n_nodes=194085, n_edges=1443339, F=1, bs=1000, k=40,
+               strategy="pruning", width=10, depth=2, alpha=[0.1, 0.1], beta=[0.5, 0.95]),
+    "c5": dict(bipartite=None, n_nodes=10_000_000, n_edges=100_000_000, F=1, bs=4096, k=20,
+               strategy="streaming", alpha=[0.1, 0.1], beta=[0.5, 0.95]),
+}
