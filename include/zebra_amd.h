@@ -1,0 +1,213 @@
+/*
+ * zebra_amd.h -- C-ABI of libzebra_amd.so, the MI355X (gfx950) implementation
+ * of Zebra's T-PPR + top-k aggregate + memory-update hot path.
+ *
+ * The reference has no FFI: its boundary is a set of Python attribute calls
+ * (SURVEY.md section 8b).  Each entry point below names the reference method
+ * it replaces (paths relative to the reference checkout).  The Python classes
+ * in zebra_amd/ (tppr_finder, NeighborFinder, GraphDiffusionEmbedding, Memory,
+ * GRUMemoryUpdater, TGN) bind these with ctypes; INTEGRATION.md shows the stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status (ZT_OK == 0) and never throws;
+ *   - "dev" pointers are device (HBM) addresses, "host" pointers host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued on it and is stream-ordered; the library is not
+ *     thread-safe per handle (the reference holds the GIL throughout);
+ *   - node ids and edge ids are validated on the device: an out-of-range id
+ *     rejects the whole call BEFORE any state is modified and latches
+ *     ZT_ERR_RANGE in the handle's status word (zt_tppr_status / the status
+ *     out-parameter), because the reference's Numba code would read out of
+ *     bounds there (SURVEY.md 8b "Errors").
+ */
+#ifndef ZEBRA_AMD_H
+#define ZEBRA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZT_OK 0
+#define ZT_ERR_ARG (-1)         /* bad argument (NULL, non-positive size, k > ZT_MAX_K ...) */
+#define ZT_ERR_RANGE (-2)       /* node / edge id out of range */
+#define ZT_ERR_HIP (-3)         /* a HIP runtime call failed (see zt_last_error) */
+#define ZT_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
+#define ZT_ERR_TIMEOUT (-5)     /* an in-kernel dependency wait hit its spin bound */
+
+#define ZT_MAX_K 63             /* top-k width supported by the wave-level merge */
+
+/* Human-readable description of the last failure on this thread. */
+const char *zt_last_error(void);
+/* Library / build information ("zebra_amd <version> gfx950"). */
+const char *zt_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* Streaming T-PPR  --  utils/util.py:391-873 (class tppr_finder)            */
+/* ------------------------------------------------------------------------ */
+
+typedef struct zt_tppr zt_tppr;
+
+/* tppr_finder.__init__ (utils/util.py:393-400): allocates the device-resident
+ * state [n_tppr][num_nodes][k] (key, timestamp, weight) + length + normaliser,
+ * all zero.  alpha/beta are host arrays of n_tppr doubles. */
+int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32_t n_tppr,
+                   const double *alpha_host, const double *beta_host);
+int zt_tppr_destroy(zt_tppr *h);
+
+/* tppr_finder.reset_tppr (utils/util.py:419-434). */
+int zt_tppr_reset(zt_tppr *h, void *stream);
+
+/* Deep snapshot: dst <- src (same shape).  Replaces backup_tppr /
+ * restore_tppr / restore_val_tppr (utils/util.py:436-444), which alias the
+ * live state in the reference; the Python shim chooses
+ * between deep and alias semantics. */
+int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream);
+
+/* tppr_finder.streaming_topk (utils/util.py:473-576), streaming_topk_no_fake
+ * (:682-782), single_streaming_topk (:581-679) and the update loop of
+ * compute_val_tppr (:787-870).
+ *   nodes_dev : int32 [n_roles*B] = [src | dst | (neg)]
+ *   ts_dev    : float64 [B]   (the reference reads only timestamps[:B], :499)
+ *   eidx_dev  : int64 [B]
+ *   n_roles   : 3 (with negatives) or 2
+ *   emit      : 1 = fill the four output arrays, 0 = update only
+ *   model     : -1 = all models, else only that one
+ *   out_*_dev : [n_emitted_models][n_roles*B][k] int32/int32/float32/float32;
+ *               every row is written (zeros when the dictionary is empty).
+ * Edges are applied in batch order, each seeing the state left by the edges
+ * before it, exactly as the reference's sequential loop. */
+int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev,
+                   const int64_t *eidx_dev, int64_t B, int32_t n_roles,
+                   int32_t emit, int32_t model, int32_t *out_nodes_dev,
+                   int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
+                   void *stream);
+
+/* Synchronises `stream` and returns the latched device status (ZT_OK,
+ * ZT_ERR_RANGE or ZT_ERR_TIMEOUT), clearing it. */
+int zt_tppr_status(zt_tppr *h, void *stream);
+
+/* State of model m to / from host arrays, dictionary items in iteration
+ * order (attrs PPR_list / norm_list of the reference, utils/util.py:383-386):
+ *   len int32[N], norm float64[N], eidx int64[N*k], node int64[N*k],
+ *   ts float64[N*k], w float64[N*k]; slots >= len are zero.  Synchronous. */
+int zt_tppr_export(zt_tppr *h, int32_t m, int32_t *len_host, double *norm_host,
+                   int64_t *eidx_host, int64_t *node_host, double *ts_host,
+                   double *w_host);
+int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host,
+                   const double *norm_host, const int64_t *eidx_host,
+                   const int64_t *node_host, const double *ts_host,
+                   const double *w_host);
+
+/* ------------------------------------------------------------------------ */
+/* Static adjacency + pruning T-PPR -- utils/util.py:90-276                  */
+/* ------------------------------------------------------------------------ */
+
+typedef struct zt_csr zt_csr;
+
+/* get_neighbor_finder (utils/util.py:90-107): host edge arrays -> device CSR
+ * (indptr int64[N+1], nbr int32[2E], eid int32[2E], ts float64[2E]); each
+ * node's entries stably sorted by timestamp. */
+int zt_csr_build(zt_csr **out, const int32_t *src_host, const int32_t *dst_host,
+                 const int64_t *eidx_host, const double *ts_host, int64_t E,
+                 int64_t num_nodes);
+/* NeighborFinder(node_to_neighbors, node_to_edge_idxs, node_to_edge_timestamps)
+ * (utils/util.py:146-149): adopt an adjacency that is already grouped by node
+ * and time-sorted (host CSR arrays). */
+int zt_csr_from_sorted(zt_csr **out, const int64_t *indptr_host, const int32_t *nbr_host,
+                       const int32_t *eid_host, const double *ts_host, int64_t num_nodes);
+int zt_csr_destroy(zt_csr *c);
+/* Sizes and a host copy of the adjacency (attrs node_to_neighbors, ... of the
+ * reference object). */
+int zt_csr_size(const zt_csr *c, int64_t *num_nodes, int64_t *num_entries);
+int zt_csr_export(const zt_csr *c, int64_t *indptr_host, int32_t *nbr_host, int32_t *eid_host,
+                  double *ts_host);
+/* NeighborFinder.find_before (utils/util.py:152-154) for one node: number of
+ * entries strictly before t, and copies of that prefix (host, optional). */
+int zt_csr_find_before(const zt_csr *c, int32_t v, double t, int64_t *count,
+                       int32_t *nbr_host, int32_t *eid_host, double *ts_host,
+                       int64_t cap);
+
+/* NeighborFinder.get_pruned_topk (utils/util.py:185-276): rows whose
+ * dictionary is empty are left untouched, all others fully written (the
+ * reference mutates caller-owned arrays in place). */
+int zt_pruned_topk(const zt_csr *c, const int32_t *q_nodes_dev,
+                   const double *q_ts_dev, int64_t nq, int32_t width,
+                   int32_t depth, double alpha, double beta, int32_t k,
+                   int32_t *out_nodes_dev, int32_t *out_eidx_dev,
+                   float *out_dt_dev, float *out_w_dev, int32_t *status_dev,
+                   void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Gather + TimeEncode + transform + weighted sum                            */
+/*   GraphDiffusionEmbedding.compute_embedding_tppr_ensemble, eval forward   */
+/*   (modules/embedding_module.py:243-276, 320-328; model/time_encoding.py)  */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    const float *fc1_w, *fc1_b;   /* [D][D+F+T], [D]   torch Linear layout */
+    const float *fc2_w, *fc2_b;   /* [D][D], [D] */
+    const float *fc1s_w, *fc1s_b; /* transform_source */
+    const float *fc2s_w, *fc2s_b;
+    const float *time_w;          /* TimeEncode frequencies [T] */
+} zt_embed_weights;               /* all device pointers */
+
+/*   memory_dev [num_nodes][D], efeat_dev [num_edges][F]
+ *   nodes_dev int32[N]; nbr/eix int32 [M][N][k]; dt/w float32 [M][N][k]
+ *   out_dev [N][D*(M+1)] = [transform_source(memory[nodes]) | model 0 | ...]
+ *   workspace_dev: at least zt_embed_workspace_bytes(N, D, M) bytes. */
+int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t M);
+int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes,
+             int64_t num_edges, int32_t D, int32_t F, int32_t T,
+             const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
+             const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev,
+             const float *w_dev, const zt_embed_weights *weights, float *out_dev,
+             void *workspace_dev, int32_t *status_dev, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* Memory: last-message store + GRU update                                   */
+/* ------------------------------------------------------------------------ */
+
+/* TGN.get_raw_messages + Memory.store_raw_messages (model/tgn_model.py:204-226,
+ * modules/memory.py:27-30).  "Last message wins" over the 2B sequence
+ * [src|dst]; overwrites messages[node], msg_ts[node], sets flags[node] = 1.
+ *   scratch_dev: int32[num_nodes], all -1 on entry and restored to -1 on exit.
+ *   uniq_ids_dev (optional): receives the unique endpoint ids, *n_uniq_dev
+ *   their count (order unspecified). */
+int zt_store_messages(const float *memory_dev, const float *last_update_dev,
+                      const float *efeat_dev, const float *time_w_dev,
+                      int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F,
+                      int32_t T, const int32_t *src_dev, const int32_t *dst_dev,
+                      const double *ts_dev, const int64_t *eidx_dev, int64_t B,
+                      float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev,
+                      int32_t *scratch_dev, int32_t *uniq_ids_dev,
+                      int32_t *n_uniq_dev, int32_t *status_dev, void *stream);
+
+typedef struct {
+    const float *w_ih, *w_hh; /* [3D][msg], [3D][D]  (torch GRUCell, gates r,z,n) */
+    const float *b_ih, *b_hh; /* [3D] */
+} zt_gru_weights;             /* device pointers */
+
+/* SequenceMemoryUpdater.update_memory / update_memory_in_test with
+ * nn.GRUCell (modules/memory_updater.py:29-57,95-98), followed by
+ * Memory.clear_messages (modules/memory.py:59-60) for the same ids.
+ *   ids_dev == NULL : every node (update_memory_in_test);
+ *   ids_dev != NULL : ids_dev[0 .. *n_ids_dev) if n_ids_dev != NULL, else
+ *                     ids_dev[0 .. n_ids); ids must be unique.
+ *   Flagged ids get last_update = msg_ts and memory = GRU(messages, memory);
+ *   flags of all ids are cleared.
+ *   workspace_dev: zt_gru_workspace_bytes(max_rows, D) bytes. */
+int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D);
+int zt_gru_update(float *memory_dev, float *last_update_dev,
+                  const float *messages_dev, const float *msg_ts_dev,
+                  uint8_t *flags_dev, int64_t num_nodes, int32_t D,
+                  int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
+                  const int32_t *n_ids_dev, const zt_gru_weights *weights,
+                  void *workspace_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEBRA_AMD_H */

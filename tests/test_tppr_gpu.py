@@ -1,0 +1,197 @@
+"""GPU parity of the HIP T-PPR kernels: bit-exact against the golden vectors
+(produced by the reference) and against the CPU oracle on larger seeded
+streams.  All calls go through the C-ABI (zebra_amd._capi -> libzebra_amd.so)."""
+import types
+
+import numpy as np
+import pytest
+
+import inputs as I
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def zt():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from zebra_amd import tppr
+    return tppr
+
+
+def _cmp_state(a, b, what=""):
+    for kk in ("len", "norm", "eidx", "node", "ts", "w"):
+        assert np.array_equal(a[kk], b[kk]), "state %s differs %s" % (kk, what)
+
+
+@pytest.mark.parametrize("name", list(I.STREAM_CASES))
+def test_streaming_golden(zt, name):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES[name]
+    g = golden("g1_stream_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    nb = (E + bs - 1) // bs
+    full = set(g["full_idx"].tolist())
+    for b in range(nb):
+        s, e = b * bs, min(E, (b + 1) * bs)
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        on, oe, od, ow = f.streaming_topk(nodes, np.concatenate([ts[s:e]] * 3), eidx[s:e])
+        if b in full:
+            assert np.array_equal(np.stack(on), g["b%d_nodes" % b])
+            assert np.array_equal(np.stack(oe), g["b%d_eidx" % b])
+            assert np.array_equal(np.stack(od), g["b%d_dt" % b])
+            assert np.array_equal(np.stack(ow), g["b%d_w" % b])
+        arrs = []
+        for m in range(len(al)):
+            arrs += [on[m], oe[m], od[m], ow[m]]
+        assert I.digest(arrs) == str(g["digests"][b]), "batch %d differs from the reference" % b
+    for m in range(len(al)):
+        st = f.export_state(m)
+        gs = {kk: g["state%d_%s" % (m, kk)] for kk in st}
+        _cmp_state(st, gs, "model %d" % m)
+
+
+def test_streaming_variants_golden(zt):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES["tiny_general"]
+    g = golden("g1_variants")
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    on, oe, od, ow = f.streaming_topk_no_fake(np.concatenate([src[:40], dst[:40]]), np.concatenate([ts[:40]] * 2),
+                                              eidx[:40])
+    assert np.array_equal(np.stack(on), g["nf_nodes"]) and np.array_equal(np.stack(oe), g["nf_eidx"])
+    assert np.array_equal(np.stack(od), g["nf_dt"]) and np.array_equal(np.stack(ow), g["nf_w"])
+    sn, se, sd, sw = f.single_streaming_topk(np.concatenate([src[40:80], dst[40:80], neg[40:80]]),
+                                             np.concatenate([ts[40:80]] * 3), eidx[40:80], 1)
+    assert np.array_equal(sn, g["single_nodes"]) and np.array_equal(se, g["single_eidx"])
+    assert np.array_equal(sd, g["single_dt"]) and np.array_equal(sw, g["single_w"])
+    for m in range(len(al)):
+        st = f.export_state(m)
+        _cmp_state(st, {kk: g["state%d_%s" % (m, kk)] for kk in st})
+
+
+def test_fill_and_snapshots(zt):
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES["bip_k20"]
+    g = golden("g2_fill")
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    f.compute_val_tppr(src[:1000], dst[:1000], ts[:1000], eidx[:1000], chunk=300)
+    for m in range(len(al)):
+        st = f.export_state(m)
+        _cmp_state(st, {kk: g["state%d_%s" % (m, kk)] for kk in st})
+    # deep snapshot semantics (default): backup -> stream -> restore really restores
+    before = f.export_state(0)
+    bk = f.backup_tppr()
+    nodes = np.concatenate([src[1000:1200], dst[1000:1200], neg[1000:1200]])
+    f.streaming_topk(nodes, ts[1000:1200], eidx[1000:1200])
+    assert not np.array_equal(f.export_state(0)["w"], before["w"])
+    f.restore_tppr(bk)
+    _cmp_state(f.export_state(0), before)
+    f.reset_tppr()
+    assert f.export_state(0)["len"].sum() == 0
+    f.restore_val_tppr()
+    _cmp_state(f.export_state(0), before)
+    # reference-compatible aliasing: restore is a no-op, like the reference (g2 records it)
+    f2 = zt.tppr_finder(N, k, len(al), al, be, reference_compat_aliasing=True)
+    f2.compute_val_tppr(src[:1000], dst[:1000], ts[:1000], eidx[:1000])
+    bk = f2.backup_tppr()
+    f2.streaming_topk(nodes, ts[1000:1200], eidx[1000:1200])
+    after = f2.export_state(0)
+    f2.restore_tppr(bk)
+    _cmp_state(f2.export_state(0), after)
+    assert bool(g["restore_is_noop"])
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2000, E=20000, bs=600, k=20, al=[0.1, 0.1], be=[0.5, 0.95], kind="bipartite", seed=101),
+    dict(N=500, E=12000, bs=4096, k=20, al=[0.1, 0.1], be=[0.5, 0.95], kind="hub", seed=102),
+    dict(N=3000, E=9000, bs=1000, k=40, al=[0.2], be=[0.8], kind="general", seed=103),
+    dict(N=300, E=3000, bs=200, k=63, al=[0.0], be=[0.6], kind="general", seed=104),
+])
+def test_streaming_vs_oracle(zt, oracle, cfg):
+    """Seeded streams at sizes the oracle finishes in seconds: every batch's
+    four output arrays and the final state must be bit-identical."""
+    src, dst, neg, ts, eidx = I.make_stream(cfg["kind"], cfg["N"], cfg["E"], cfg["seed"])
+    al, be, k, N, bs, E = cfg["al"], cfg["be"], cfg["k"], cfg["N"], cfg["bs"], cfg["E"]
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    o = oracle.TpprOracle(N, k, len(al), al, be)
+    for s in range(0, E, bs):
+        e = min(E, s + bs)
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        a = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        b = o.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        for x, y, nm in zip(a, b, ("nodes", "eidx", "dt", "w")):
+            assert np.array_equal(np.stack(x), np.stack(y)), "%s differs in batch at %d" % (nm, s)
+    for m in range(len(al)):
+        _cmp_state(f.export_state(m), o.export(m), "model %d" % m)
+
+
+def test_streaming_edge_cases(zt, oracle):
+    f = zt.tppr_finder(20, 5, 1, [0.1], [0.9])
+    # empty batch
+    on, oe, od, ow = f.streaming_topk(np.zeros(0, np.int32), np.zeros(0), np.zeros(0, np.int64))
+    assert on[0].shape == (0, 5)
+    # out-of-range node id: rejected, state untouched
+    with pytest.raises(IndexError):
+        f.streaming_topk(np.array([1, 2, 25], np.int32), np.array([1.0]), np.array([1], np.int64))
+    assert f.export_state(0)["len"].sum() == 0
+    with pytest.raises(IndexError):
+        f.streaming_topk(np.array([1, 2, 3], np.int32), np.array([1.0]), np.array([-4], np.int64))
+    # a valid call afterwards works and matches the oracle
+    o = oracle.TpprOracle(20, 5, 1, [0.1], [0.9])
+    nodes = np.array([1, 1, 2, 2, 1, 3, 4, 5, 6], np.int32)        # self-loop, repeated pair
+    t = np.array([1.0, 1.0, 2.0])
+    e = np.array([1, 2, 3], np.int64)
+    a, b = f.streaming_topk(nodes, t, e), o.streaming_topk(nodes, t, e)
+    for x, y in zip(a, b):
+        assert np.array_equal(np.stack(x), np.stack(y))
+    with pytest.raises(ValueError):
+        zt.tppr_finder(20, 64, 1, [0.1], [0.9])                    # k > ZT_MAX_K
+
+
+@pytest.mark.parametrize("name", list(I.PRUNE_CASES))
+def test_pruning_golden(zt, name):
+    kind, N, E, seed, nq, width, depth, k, alpha, beta = I.PRUNE_CASES[name]
+    g = golden("g3_prune_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    nf = zt.get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+    for v in g["probe"]:
+        nb, ei, tt = nf.find_before(int(v), np.inf)
+        assert np.array_equal(nb, g["adj%d_nbr" % v]) and np.array_equal(ei, g["adj%d_eid" % v])
+        assert np.array_equal(tt, g["adj%d_ts" % v])
+    on = np.zeros((nq, k), np.int32)
+    oe = np.zeros((nq, k), np.int32)
+    od = np.zeros((nq, k), np.float32)
+    ow = np.zeros((nq, k), np.float32)
+    assert nf.get_pruned_topk(g["q_nodes"], g["q_ts"], width, depth, alpha, beta, k, on, oe, od, ow) is None
+    assert np.array_equal(on, g["nodes"]) and np.array_equal(oe, g["eidx"])
+    assert np.array_equal(od, g["dt"]) and np.array_equal(ow, g["w"])
+    # the list-of-arrays constructor gives the same object
+    nf2 = zt.NeighborFinder(nf.node_to_neighbors, nf.node_to_edge_idxs, nf.node_to_edge_timestamps)
+    on2 = np.full((nq, k), 7, np.int32)
+    oe2, od2, ow2 = np.zeros_like(oe), np.zeros_like(od), np.zeros_like(ow)
+    nf2.get_pruned_topk(g["q_nodes"], g["q_ts"], width, depth, alpha, beta, k, on2, oe2, od2, ow2)
+    empty = (g["w"] == 0).all(axis=1) & (g["nodes"] == 0).all(axis=1) & (g["dt"] == 0).all(axis=1)
+    assert np.array_equal(on2[~empty], g["nodes"][~empty])
+    assert (on2[empty] == 7).all()                    # rows with an empty dictionary are left untouched
+
+
+def test_pruning_vs_oracle_superuser_shape(zt, oracle):
+    """C4-shaped (k=40, width 10, depth 2) at a size the oracle runs in seconds."""
+    N, E = 20000, 150000
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, 105)
+    nf = zt.get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+    csr = oracle.CsrOracle(src, dst, eidx, ts, nf.num_nodes)
+    s = E - 1000
+    q = np.concatenate([src[s:], dst[s:], neg[s:]])
+    qt = np.concatenate([ts[s:]] * 3)
+    for alpha, beta in ((0.1, 0.5), (0.1, 0.95)):
+        outs_a = [np.zeros((3000, 40), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+        outs_b = [np.zeros((3000, 40), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+        nf.get_pruned_topk(q, qt, 10, 2, alpha, beta, 40, *outs_a)
+        csr.get_pruned_topk(q, qt, 10, 2, alpha, beta, 40, *outs_b)
+        for x, y in zip(outs_a, outs_b):
+            assert np.array_equal(x, y)
+    with pytest.raises(ValueError):
+        nf.get_pruned_topk(q[:4], qt[:4], 20, 3, 0.1, 0.5, 20, *[np.zeros((4, 20), dt) for dt in
+                                                                 (np.int32, np.int32, np.float32, np.float32)])

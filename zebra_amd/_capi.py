@@ -1,0 +1,82 @@
+"""ctypes binding of libzebra_amd.so (the C-ABI declared in include/zebra_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load the
+import raises, and every op raises on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzebra_amd.so")
+
+ZT_OK = 0
+ZT_ERR_ARG, ZT_ERR_RANGE, ZT_ERR_HIP, ZT_ERR_UNSUPPORTED, ZT_ERR_TIMEOUT = -1, -2, -3, -4, -5
+
+# every symbol include/zebra_amd.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "zt_last_error", "zt_version",
+    "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_status",
+    "zt_tppr_export", "zt_tppr_import",
+    "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
+    "zt_embed_workspace_bytes", "zt_embed",
+    "zt_store_messages", "zt_gru_workspace_bytes", "zt_gru_update",
+]
+
+
+class EmbedWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "fc1s_w", "fc1s_b", "fc2s_w",
+                                          "fc2s_b", "time_w")]
+
+
+class GruWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (in-tree build).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "zebra_amd: %s not found. Build it with `python -m zebra_amd.build` "
+                "(hipcc, --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.zt_last_error.restype = C.c_char_p
+        _lib.zt_version.restype = C.c_char_p
+        for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes"):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_int64
+    return _lib
+
+
+class ZebraError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc == ZT_OK:
+        return
+    msg = lib().zt_last_error().decode()
+    text = "%s: %s (status %d)" % (what or "zebra_amd", msg, rc)
+    if rc == ZT_ERR_RANGE:
+        raise IndexError(text)
+    if rc in (ZT_ERR_ARG, ZT_ERR_UNSUPPORTED):
+        raise ValueError(text)
+    raise ZebraError(text)
+
+
+def ptr(t):
+    """Device/host address of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return t.ctypes.data_as(C.c_void_p)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,60 @@
+"""Builds zebra_amd/lib/libzebra_amd.so (HIP, gfx950) in-tree with hipcc.
+
+    python -m zebra_amd.build [--force]
+
+The T-PPR translation units are compiled with -ffp-contract=off: the reference
+rounds every float64 multiply and add separately and the results must be
+bit-exact.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libzebra_amd.so")
+
+# file -> extra flags
+SOURCES = {
+    "tppr_stream.hip": ["-ffp-contract=off"],
+    "tppr_prune.hip": ["-ffp-contract=off"],
+    "aggregate.hip": [],
+    "memory_update.hip": [],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(LIBDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "zebra_amd.h"))
+    objs = []
+    rebuilt = False
+    for src, extra in SOURCES.items():
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _newer(sp, op) or any(_newer(h, op) for h in headers):
+            cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+            rebuilt = True
+        objs.append(op)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

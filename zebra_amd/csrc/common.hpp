@@ -1,0 +1,92 @@
+// Shared host/device helpers for libzebra_amd (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/zebra_amd.h"
+
+namespace zt {
+
+void set_error(const char *fmt, ...);
+
+#define ZT_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            zt::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__,   \
+                          __LINE__);                                                          \
+            return ZT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+#define ZT_LAUNCH_CHECK()                                                                     \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) {                                                              \
+            zt::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),         \
+                          __FILE__, __LINE__);                                                \
+            return ZT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+typedef unsigned long long u64;
+
+constexpr int WAVE = 64;
+
+// ---- device helpers ---------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// Make this wave's LDS writes visible to its own later cross-lane LDS reads
+// (orders the compiler and drains lgkmcnt; no workgroup barrier involved).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Agent-scope relaxed accesses: lower to global_load/store ... sc1 (L1 bypass /
+// write-through), the form cross-CU hand-offs inside one launch need
+// (cdna_hip_programming.md Guideline 16, recipe R1).
+__device__ __forceinline__ u64 ld_agent(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(u64 *p, u64 v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+    return __longlong_as_double((long long)ld_agent(reinterpret_cast<const u64 *>(p)));
+}
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+    st_agent(reinterpret_cast<u64 *>(p), (u64)__double_as_longlong(v));
+}
+__device__ __forceinline__ int ld_agent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int *p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace zt

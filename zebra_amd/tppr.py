@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference's T-PPR classes over the HIP library.
+
+Same names, argument order and return conventions as the reference
+(utils/util.py): ``tppr_finder`` (:391-873), ``NeighborFinder`` (:144-276) and
+``get_neighbor_finder`` (:90-107).  The arithmetic runs in
+libzebra_amd.so on the GPU; torch is only used for device buffers and the
+current HIP stream.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import check, lib, ptr, stream_ptr
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError("zebra_amd needs a ROCm GPU (MI355X / gfx950); no CPU fallback exists")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class _TpprState:
+    """Owns one device-resident T-PPR state (a zt_tppr handle)."""
+
+    def __init__(self, num_nodes, k, n_tppr, alpha, beta):
+        self.shape = (int(num_nodes), int(k), int(n_tppr))
+        self._alpha = np.ascontiguousarray(alpha, np.float64)
+        self._beta = np.ascontiguousarray(beta, np.float64)
+        h = C.c_void_p()
+        check(lib().zt_tppr_create(C.byref(h), C.c_int64(num_nodes), C.c_int32(k), C.c_int32(n_tppr),
+                                   ptr(self._alpha), ptr(self._beta)), "zt_tppr_create")
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                lib().zt_tppr_destroy(h)
+            except Exception:
+                pass
+
+    def clone(self):
+        o = _TpprState(*self.shape, self._alpha, self._beta)
+        check(lib().zt_tppr_copy(o.h, self.h, stream_ptr()), "zt_tppr_copy")
+        return o
+
+    def export(self, m):
+        N, k, _ = self.shape
+        ln = np.empty(N, np.int32)
+        norm = np.empty(N, np.float64)
+        e = np.empty((N, k), np.int64)
+        nd = np.empty((N, k), np.int64)
+        ts = np.empty((N, k), np.float64)
+        w = np.empty((N, k), np.float64)
+        check(lib().zt_tppr_export(self.h, C.c_int32(m), ptr(ln), ptr(norm), ptr(e), ptr(nd), ptr(ts), ptr(w)),
+              "zt_tppr_export")
+        return dict(len=ln, norm=norm, eidx=e, node=nd, ts=ts, w=w)
+
+    def import_(self, m, st):
+        check(lib().zt_tppr_import(self.h, C.c_int32(m), ptr(np.ascontiguousarray(st["len"], np.int32)),
+                                   ptr(np.ascontiguousarray(st["norm"], np.float64)),
+                                   ptr(np.ascontiguousarray(st["eidx"], np.int64)),
+                                   ptr(np.ascontiguousarray(st["node"], np.int64)),
+                                   ptr(np.ascontiguousarray(st["ts"], np.float64)),
+                                   ptr(np.ascontiguousarray(st["w"], np.float64))), "zt_tppr_import")
+
+
+class tppr_finder:
+    """Drop-in for the reference's ``tppr_finder`` jitclass (utils/util.py:391).
+
+    ``reference_compat_aliasing=True`` reproduces the reference's shallow
+    backup / restore / val snapshots (they alias the live state);
+    the default takes true device-side snapshots.
+    """
+
+    def __init__(self, num_nodes, k, n_tppr, alpha_list, beta_list, reference_compat_aliasing=False):
+        if len(alpha_list) != n_tppr or len(beta_list) != n_tppr:
+            raise ValueError("alpha_list / beta_list must have n_tppr entries")
+        self.num_nodes = int(num_nodes)
+        self.k = int(k)
+        self.n_tppr = int(n_tppr)
+        self.alpha_list = [float(a) for a in alpha_list]
+        self.beta_list = [float(b) for b in beta_list]
+        self.reference_compat_aliasing = bool(reference_compat_aliasing)
+        self._dev = _dev()
+        self._val = self._new_state()        # reset_val_tppr (:399)
+        self._live = self._new_state()       # reset_tppr (:400)
+
+    # ------------------------------------------------------------ state mgmt
+    def _new_state(self):
+        return _TpprState(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list)
+
+    def reset_val_tppr(self):                # utils/util.py:402-417
+        self._val = self._new_state()
+
+    def reset_tppr(self):                    # utils/util.py:419-434
+        if self.reference_compat_aliasing:
+            self._live = self._new_state()   # new objects; old ones may live on in val/backups
+        else:
+            check(lib().zt_tppr_reset(self._live.h, stream_ptr()), "zt_tppr_reset")
+
+    def backup_tppr(self):                   # utils/util.py:436-437
+        return self._live if self.reference_compat_aliasing else self._live.clone()
+
+    def restore_tppr(self, backup):          # utils/util.py:439-440
+        self._live = backup if self.reference_compat_aliasing else backup.clone()
+
+    def restore_val_tppr(self):              # utils/util.py:442-444
+        self._live = self._val if self.reference_compat_aliasing else self._val.clone()
+
+    # reference attributes, materialised on demand from the device state
+    @property
+    def norm_list(self):
+        return [self._live.export(m)["norm"] for m in range(self.n_tppr)]
+
+    @property
+    def PPR_list(self):
+        return [self._dicts(self._live, m) for m in range(self.n_tppr)]
+
+    @property
+    def val_norm_list(self):
+        return [self._val.export(m)["norm"] for m in range(self.n_tppr)]
+
+    @property
+    def val_PPR_list(self):
+        return [self._dicts(self._val, m) for m in range(self.n_tppr)]
+
+    @staticmethod
+    def _dicts(state, m):
+        st = state.export(m)
+        out = []
+        for v in range(len(st["len"])):
+            n = st["len"][v]
+            out.append({(int(st["eidx"][v, j]), int(st["node"][v, j]), float(st["ts"][v, j])): float(st["w"][v, j])
+                        for j in range(n)})
+        return out
+
+    def export_state(self, m):
+        """Dense view of model m's dictionaries (iteration order)."""
+        return self._live.export(m)
+
+    # ------------------------------------------------------------- streaming
+    def _upload(self, source_nodes, timestamps, edge_idxs, n_roles):
+        nodes = np.ascontiguousarray(source_nodes, np.int32)
+        if nodes.ndim != 1 or len(nodes) % n_roles:
+            raise ValueError("source_nodes must be 1-D with a multiple of %d entries" % n_roles)
+        B = len(nodes) // n_roles
+        ts = np.ascontiguousarray(np.asarray(timestamps, np.float64)[:B])
+        eidx = np.ascontiguousarray(edge_idxs, np.int64)
+        if len(ts) < B or len(eidx) != B:
+            raise ValueError("timestamps / edge_idxs shorter than the batch")
+        d = self._dev
+        return (torch.from_numpy(nodes).to(d), torch.from_numpy(ts).to(d), torch.from_numpy(eidx).to(d), B)
+
+    def stream_device(self, nodes_d, ts_d, eidx_d, n_roles=3, emit=True, model=-1, check_status=True):
+        """Device-resident form: int32[n_roles*B], float64[B], int64[B] CUDA
+        tensors in, four [n_models][n_roles*B][k] CUDA tensors out."""
+        B = nodes_d.numel() // n_roles
+        nm = self.n_tppr if model < 0 else 1
+        d = nodes_d.device
+        if emit:
+            on = torch.empty((nm, n_roles * B, self.k), dtype=torch.int32, device=d)
+            oe = torch.empty_like(on)
+            od = torch.empty((nm, n_roles * B, self.k), dtype=torch.float32, device=d)
+            ow = torch.empty_like(od)
+        else:
+            on = oe = od = ow = None
+        check(lib().zt_tppr_stream(self._live.h, ptr(nodes_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B),
+                                   C.c_int32(n_roles), C.c_int32(1 if emit else 0), C.c_int32(model), ptr(on),
+                                   ptr(oe), ptr(od), ptr(ow), stream_ptr()), "zt_tppr_stream")
+        if check_status:
+            check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
+        return on, oe, od, ow
+
+    def check_status(self):
+        check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
+
+    @staticmethod
+    def _lists(on, oe, od, ow):
+        return ([a for a in on.cpu().numpy()], [a for a in oe.cpu().numpy()], [a for a in od.cpu().numpy()],
+                [a for a in ow.cpu().numpy()])
+
+    def streaming_topk(self, source_nodes, timestamps, edge_idxs):            # utils/util.py:473-576
+        n, t, e, _ = self._upload(source_nodes, timestamps, edge_idxs, 3)
+        return self._lists(*self.stream_device(n, t, e, 3, True, -1))
+
+    def streaming_topk_no_fake(self, source_nodes, timestamps, edge_idxs):    # utils/util.py:682-782
+        n, t, e, _ = self._upload(source_nodes, timestamps, edge_idxs, 2)
+        return self._lists(*self.stream_device(n, t, e, 2, True, -1))
+
+    def single_streaming_topk(self, source_nodes, timestamps, edge_idxs, tppr_id):   # utils/util.py:581-679
+        n, t, e, _ = self._upload(source_nodes, timestamps, edge_idxs, 3)
+        on, oe, od, ow = self.stream_device(n, t, e, 3, True, int(tppr_id))
+        return on[0].cpu().numpy(), oe[0].cpu().numpy(), od[0].cpu().numpy(), ow[0].cpu().numpy()
+
+    def compute_val_tppr(self, sources, targets, timestamps, edge_idxs, chunk=1 << 16):   # utils/util.py:787-873
+        """One pass over a whole stream without emitting rows, then snapshot
+        the result as the ``val`` state."""
+        src = np.ascontiguousarray(sources, np.int32)
+        dst = np.ascontiguousarray(targets, np.int32)
+        ts = np.ascontiguousarray(timestamps, np.float64)
+        eidx = np.ascontiguousarray(edge_idxs, np.int64)
+        for s in range(0, len(src), chunk):
+            e = min(len(src), s + chunk)
+            nodes = np.concatenate([src[s:e], dst[s:e]])
+            n, t, ei, _ = self._upload(nodes, ts[s:e], eidx[s:e], 2)
+            self.stream_device(n, t, ei, 2, False, -1, check_status=False)
+        self.check_status()
+        self._val = self._live if self.reference_compat_aliasing else self._live.clone()
+
+
+class NeighborFinder:
+    """Drop-in for the reference's ``NeighborFinder`` jitclass (utils/util.py:144)."""
+
+    def __init__(self, node_to_neighbors, node_to_edge_idxs, node_to_edge_timestamps, _handle=None):
+        self._dev = _dev()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            n = len(node_to_neighbors)
+            indptr = np.zeros(n + 1, np.int64)
+            indptr[1:] = np.cumsum([len(a) for a in node_to_neighbors])
+            cat = (lambda xs, dt: np.ascontiguousarray(np.concatenate([np.asarray(x, dt) for x in xs]) if n else
+                                                       np.zeros(0, dt), dt))
+            nbr, eid, ts = cat(node_to_neighbors, np.int32), cat(node_to_edge_idxs, np.int32), \
+                cat(node_to_edge_timestamps, np.float64)
+            h = C.c_void_p()
+            check(lib().zt_csr_from_sorted(C.byref(h), ptr(indptr), ptr(nbr), ptr(eid), ptr(ts), C.c_int64(n)),
+                  "zt_csr_from_sorted")
+            self._h = h
+        n, e2 = C.c_int64(), C.c_int64()
+        check(lib().zt_csr_size(self._h, C.byref(n), C.byref(e2)))
+        self.num_nodes, self._e2 = n.value, e2.value
+        self._indptr = np.empty(self.num_nodes + 1, np.int64)
+        self._nbr = np.empty(self._e2, np.int32)
+        self._eid = np.empty(self._e2, np.int32)
+        self._ts = np.empty(self._e2, np.float64)
+        check(lib().zt_csr_export(self._h, ptr(self._indptr), ptr(self._nbr), ptr(self._eid), ptr(self._ts)))
+        self._status = torch.zeros(1, dtype=torch.int32, device=self._dev)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().zt_csr_destroy(h)
+            except Exception:
+                pass
+
+    # reference attributes (lists of per-node arrays, utils/util.py:147-149)
+    def _split(self, a):
+        return [a[self._indptr[v]:self._indptr[v + 1]] for v in range(self.num_nodes)]
+
+    @property
+    def node_to_neighbors(self):
+        return self._split(self._nbr)
+
+    @property
+    def node_to_edge_idxs(self):
+        return self._split(self._eid)
+
+    @property
+    def node_to_edge_timestamps(self):
+        return self._split(self._ts)
+
+    def find_before(self, src_idx, cut_time):                                 # utils/util.py:152-154
+        if src_idx < 0 or src_idx >= self.num_nodes:
+            raise IndexError("node id %d out of range" % src_idx)
+        lo, hi = self._indptr[src_idx], self._indptr[src_idx + 1]
+        i = int(np.searchsorted(self._ts[lo:hi], cut_time))
+        return self._nbr[lo:lo + i], self._eid[lo:lo + i], self._ts[lo:lo + i]
+
+    def pruned_topk_device(self, nodes_d, ts_d, width, depth, alpha, beta, k, on, oe, od, ow, check_status=True):
+        check(lib().zt_pruned_topk(self._h, ptr(nodes_d), ptr(ts_d), C.c_int64(nodes_d.numel()), C.c_int32(width),
+                                   C.c_int32(depth), C.c_double(alpha), C.c_double(beta), C.c_int32(k), ptr(on),
+                                   ptr(oe), ptr(od), ptr(ow), ptr(self._status), stream_ptr()), "zt_pruned_topk")
+        if check_status:
+            st = int(self._status.item())
+            if st != 0:
+                self._status.zero_()
+                raise IndexError("get_pruned_topk: node id out of range (status %d)" % st)
+
+    def get_pruned_topk(self, source_nodes, timestamps, width, depth, alpha, beta, k, node_list, edge_idxs_list,
+                        delta_time_list, weight_list):                        # utils/util.py:185-276
+        """Writes into the four caller-owned [N, k] arrays in place, returns None."""
+        q = torch.from_numpy(np.ascontiguousarray(source_nodes, np.int32)).to(self._dev)
+        t = torch.from_numpy(np.ascontiguousarray(timestamps, np.float64)).to(self._dev)
+        outs = []
+        for a, dt in ((node_list, np.int32), (edge_idxs_list, np.int32), (delta_time_list, np.float32),
+                      (weight_list, np.float32)):
+            if a.dtype != dt or a.shape != (len(q), k):
+                raise ValueError("output arrays must be [N, k] int32/int32/float32/float32")
+            outs.append(torch.from_numpy(np.ascontiguousarray(a)).to(self._dev))
+        self.pruned_topk_device(q, t, width, depth, float(alpha), float(beta), k, *outs)
+        for a, o in zip((node_list, edge_idxs_list, delta_time_list, weight_list), outs):
+            a[...] = o.cpu().numpy()
+
+
+def get_neighbor_finder(data):
+    """utils/util.py:90-107: undirected, time-sorted adjacency of a ``Data``
+    object (attributes sources, destinations, edge_idxs, timestamps)."""
+    _dev()
+    src = np.ascontiguousarray(data.sources, np.int32)
+    dst = np.ascontiguousarray(data.destinations, np.int32)
+    eidx = np.ascontiguousarray(data.edge_idxs, np.int64)
+    ts = np.ascontiguousarray(data.timestamps, np.float64)
+    n = int(max(src.max(), dst.max())) + 1 if len(src) else 1
+    h = C.c_void_p()
+    check(lib().zt_csr_build(C.byref(h), ptr(src), ptr(dst), ptr(eidx), ptr(ts), C.c_int64(len(src)), C.c_int64(n)),
+          "zt_csr_build")
+    return NeighborFinder(None, None, None, _handle=h)
