@@ -157,8 +157,10 @@ typedef struct {
 /*   memory_dev [num_nodes][D], efeat_dev [num_edges][F]
  *   nodes_dev int32[N]; nbr/eix int32 [M][N][k]; dt/w float32 [M][N][k]
  *   out_dev [N][D*(M+1)] = [transform_source(memory[nodes]) | model 0 | ...]
- *   workspace_dev: at least zt_embed_workspace_bytes(N, D, M) bytes. */
-int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t M);
+ *   workspace_dev: at least zt_embed_workspace_bytes(N, D, F, T, M, k) bytes
+ *   (-1 = shape unsupported). */
+int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T,
+                                 int32_t M, int32_t k);
 int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes,
              int64_t num_edges, int32_t D, int32_t F, int32_t T,
              const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
@@ -198,8 +200,11 @@ typedef struct {
  *                     ids_dev[0 .. n_ids); ids must be unique.
  *   Flagged ids get last_update = msg_ts and memory = GRU(messages, memory);
  *   flags of all ids are cleared.
- *   workspace_dev: zt_gru_workspace_bytes(max_rows, D) bytes. */
-int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D);
+ *   flags_dev must be 4-byte aligned and padded to a multiple of 4 bytes (flag
+ *   bytes are cleared with 32-bit atomics).
+ *   workspace_dev: zt_gru_workspace_bytes(max_rows, D, msg_dim) bytes, where
+ *   max_rows = n_ids (or num_nodes when ids_dev == NULL). */
+int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t msg_dim);
 int zt_gru_update(float *memory_dev, float *last_update_dev,
                   const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D,

@@ -1,0 +1,126 @@
+"""GPU parity of the aggregation (P2) and memory-update (P3) kernels and of the
+whole per-batch protocol, through the reference-shaped Python surface:
+golden vectors (1e-4, BASELINE.json north_star tolerance) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as I
+from conftest import golden
+from helpers import build_tgn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", list(I.EMBED_CASES))
+def test_embedding_golden(name):
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g45_embed_" + name)
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    assert np.array_equal(tgn.time_encoder.w.weight.detach().cpu().numpy().ravel(), I.time_encode_weights(T))
+    em = tgn.embedding_module
+    half = E // 2
+    em.tppr_finder.compute_val_tppr(src[:half], dst[:half], ts[:half], eidx[:half])
+    em.tppr_finder.restore_val_tppr()
+    s, e = half, half + bs
+    nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+    emb = em.compute_embedding_tppr_ensemble(memory=torch.from_numpy(mem0).cuda(), source_nodes=nodes,
+                                             timestamps=np.concatenate([ts[s:e]] * 3), edge_idxs=eidx[s:e],
+                                             memory_updater=tgn.memory_updater, train=False)
+    assert emb.shape == g["emb"].shape
+    assert np.abs(emb.cpu().numpy() - g["emb"]).max() <= TOL
+    assert abs(em.average_topk - float(g["average_topk"])) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("name", list(I.EMBED_CASES))
+def test_protocol_golden(name, mode):
+    """Consecutive batches of TGN.compute_temporal_embeddings (tgn_model.py:124-174)."""
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g45_embed_" + name)
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+    train = mode == "train"
+    tgn.train(train)
+    for b in range(nb):
+        s, e = b * bs, (b + 1) * bs
+        ctx = torch.enable_grad() if train else torch.no_grad()
+        with ctx:
+            pos, negp = tgn.compute_edge_probabilities(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, train)
+        prob = torch.cat([pos, negp]).detach().cpu().numpy().ravel()
+        assert np.abs(prob - g["%s_b%d_prob" % (mode, b)]).max() <= TOL, "batch %d" % b
+        if train:
+            tgn.memory.detach_memory()
+    m = tgn.memory
+    pre = "%s_b%d_" % (mode, nb - 1)
+    assert np.abs(m.memory.cpu().numpy() - g[pre + "memory"]).max() <= TOL
+    assert np.array_equal(m.last_update.cpu().numpy(), g[pre + "last_update"])
+    assert np.abs(m.messages.cpu().numpy() - g[pre + "messages"]).max() <= TOL
+    assert np.array_equal(m.timestamps.cpu().numpy(), g[pre + "timestamps"])
+    assert np.array_equal(m.nodes.astype(np.uint8), g[pre + "flags"])
+
+
+def test_embeddings_golden_all_batches():
+    """Embeddings of every eval batch (not only the probabilities)."""
+    name = "d100_f172"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g45_embed_" + name)
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    for b in range(nb):
+        s, e = b * bs, (b + 1) * bs
+        with torch.no_grad():
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, False)
+        emb = torch.cat([se, de, ne]).cpu().numpy()
+        assert np.abs(emb - g["eval_b%d_emb" % b]).max() <= TOL, "batch %d" % b
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=3000, E=6000, F=172, bs=200, k=20, al=[0.1, 0.1], be=[0.5, 0.95], warm=4000, nb=6, seed=201),
+    dict(N=5000, E=9000, F=1, bs=512, k=20, al=[0.1, 0.1], be=[0.5, 0.95], warm=5000, nb=5, seed=202),
+    dict(N=800, E=4000, F=4, bs=100, k=40, al=[0.2], be=[0.8], warm=3000, nb=5, seed=203),
+])
+def test_protocol_vs_oracle(oracle, cfg):
+    """Larger seeded runs: T-PPR state bit-exact, embeddings / memory within 1e-4
+    of the CPU oracle after several dependent batches."""
+    D = T = 100
+    N, E, F, bs, k, al, be = cfg["N"], cfg["E"], cfg["F"], cfg["bs"], cfg["k"], cfg["al"], cfg["be"]
+    M = len(al)
+    src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, cfg["seed"])
+    w = I.model_weights(D, F, T, M, cfg["seed"])
+    _, efeat = I.random_tables(N, E + 1, D, F, cfg["seed"])
+    tw = I.time_encode_weights(T)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    f = oracle.TpprOracle(N, k, M, al, be)
+    mem = oracle.MemoryOracle(N, D, 2 * D + F + T)
+    gru = {kk: w[kk] for kk in ("w_ih", "w_hh", "b_ih", "b_hh")}
+    s = 0
+    while s < cfg["warm"] + cfg["nb"] * bs:
+        e = s + bs
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        with torch.no_grad():
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, False)
+        on, oe, od, ow = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        emb = oracle.embed(mem.memory, efeat, tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow), w,
+                           n_threads=8)
+        got = torch.cat([se, de, ne]).cpu().numpy()
+        assert np.abs(got - emb).max() <= TOL, "embeddings differ at edge %d" % s
+        mem.store_messages(efeat, tw, src[s:e], dst[s:e], ts[s:e], eidx[s:e])
+        mem.gru_update(gru, np.unique(np.concatenate([src[s:e], dst[s:e]])), n_threads=8)
+        s = e
+    for m in range(M):
+        a, b = tgn.embedding_module.tppr_finder.export_state(m), f.export(m)
+        for kk in a:
+            assert np.array_equal(a[kk], b[kk])
+    assert np.abs(tgn.memory.memory.cpu().numpy() - mem.memory).max() <= TOL
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), mem.last_update)
+    assert np.abs(tgn.memory.messages.cpu().numpy() - mem.messages).max() <= TOL
+    assert np.array_equal(tgn.memory.nodes.astype(np.uint8), mem.flags)

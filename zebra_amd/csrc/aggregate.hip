@@ -1,0 +1,377 @@
+// Top-k neighbour gather + TimeEncode + transform + T-PPR-weighted sum (P2).
+//
+// Replaces the device half of GraphDiffusionEmbedding.compute_embedding_tppr_ensemble
+// (reference modules/embedding_module.py:243-276, transform/transform_source
+// :320-328, TimeEncode model/time_encoding.py:23-28), eval forward.
+//
+// The reference materialises cat[memory[nbr] | edge_feat[eidx] | cos(dt*w)] as
+// an [N,k,2D+F] tensor, runs two Linear layers over all N*k rows and then
+// reduces over k.  Here:
+//   k_fc1_agg   one workgroup per (tile of RQ query rows, model): gathers the
+//               RQ*k neighbour rows straight into an LDS tile (the cat is never
+//               written to HBM), evaluates the time encoding in-register,
+//               runs fc1 on exact-f32 MFMA (v_mfma_f32_16x16x4_f32; weights
+//               streamed from L2 as pre-padded fragments), applies bias+ReLU
+//               and the normalised T-PPR weight, and reduces over k in LDS.
+//               fc2 is linear, so sum_k w_k*fc2(h_k) = fc2(sum_k w_k*h_k) +
+//               b2*sum_k w_k: only the [N,D] reduced rows go through fc2.
+//   k_embed_out fc2 on the reduced rows, transform_source on memory[nodes],
+//               and the concat into out[N, D*(M+1)].
+// Arithmetic is float32 throughout (parity tolerance for embeddings: 1e-4).
+#include "common.hpp"
+
+using namespace zt;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AGG_THREADS = 256;
+constexpr int AGG_WAVES = 4;
+constexpr int MAX_MT = 5;          // M-tiles (16 gathered rows each) per workgroup
+constexpr int NTW = 2;             // N-tiles per wave -> D <= 128
+constexpr int LDS_BUDGET = 150 * 1024;
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Zero-padded copy W[rows][cols] -> Wp[rows_p][cols_p].
+__global__ void k_pad_matrix(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wp, int rows_p,
+                             int cols_p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_p * cols_p) return;
+    const int r = i / cols_p, c = i % cols_p;
+    Wp[i] = (r < rows && c < cols) ? W[(size_t)r * cols + c] : 0.f;
+}
+
+// Transposed copy W[rows][cols] -> Wt[cols][rows].
+__global__ void k_transpose(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i / cols, c = i % cols;
+    Wt[(size_t)c * rows + r] = W[i];
+}
+
+// ---------------------------------------------------------------------------
+// fc1 + ReLU + weighted k-reduction.
+//   A tile in LDS: [mt*16][lda] floats, row g = q*k + j holds
+//   [memory[nbr] (D) | efeat[eidx] (F) | cos(dt*w_t) (T) | 0-pad].
+//   W1p: [Dp][K1p] zero padded (Dp = NT*16, K1p = round_up(K1,16)).
+//   H:   [M][N][D] reduced hidden rows;  S: [M][N] = 1 if sum(w) != 0 else 0.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
+    const float *__restrict__ memory, const float *__restrict__ efeat, const float *__restrict__ time_w,
+    long long num_nodes, long long num_edges, int D, int F, int T, long long N, int k, int rq, int mt_count, int lda,
+    const int *__restrict__ nbr, const int *__restrict__ eix, const float *__restrict__ dt,
+    const float *__restrict__ w, const float *__restrict__ W1p, int K1p, const float *__restrict__ b1,
+    float *__restrict__ H, float *__restrict__ S, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *A = reinterpret_cast<float *>(smem);                       // [mt*16][lda]
+    float *wn = A + (size_t)mt_count * 16 * lda;                      // [mt*16] normalised weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = blockIdx.y;
+    const long long q0 = (long long)blockIdx.x * rq;
+    const int nq = (int)((N - q0) < rq ? (N - q0) : rq);
+    const int rows = nq * k, rows_p = mt_count * 16;
+    const int K1 = D + F + T;
+    const size_t mb = ((size_t)m * N + q0) * k;                       // first entry of this tile in [M][N][k]
+
+    // ---- normalised weights: w / sum(w), 0 where the sum is 0 (:267-270) ----
+    for (int q = tid; q < nq; q += AGG_THREADS) {
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) s += w[mb + (size_t)q * k + j];
+        for (int j = 0; j < k; ++j) wn[q * k + j] = (s == 0.f) ? 0.f : w[mb + (size_t)q * k + j] / s;
+        S[(size_t)m * N + q0 + q] = (s == 0.f) ? 0.f : 1.f;
+    }
+    for (int g = rows + tid; g < rows_p; g += AGG_THREADS) wn[g] = 0.f;
+
+    // ---- gather: one wave per row, lanes sweep the columns (coalesced) ----
+    for (int g = wave; g < rows_p; g += AGG_WAVES) {
+        float *row = A + (size_t)g * lda;
+        if (g >= rows) {
+            for (int c = lane; c < K1p; c += WAVE) row[c] = 0.f;
+            continue;
+        }
+        int nb = nbr[mb + g], ei = eix[mb + g];
+        const float d = dt[mb + g];
+        if (nb < 0 || nb >= num_nodes || ei < 0 || ei >= num_edges) {
+            if (lane == 0) atomicExch(status, ZT_ERR_RANGE);
+            nb = 0; ei = 0;
+        }
+        const float *mr = memory + (size_t)nb * D;
+        const float *er = efeat + (size_t)ei * F;
+        for (int c = lane; c < D; c += WAVE) row[c] = mr[c];
+        for (int c = lane; c < F; c += WAVE) row[D + c] = er[c];
+        for (int c = lane; c < T; c += WAVE) row[D + F + c] = cosf(d * time_w[c]);   // cos(t*w + 0)
+        for (int c = K1 + lane; c < K1p; c += WAVE) row[c] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- fc1 on f32 MFMA: wave handles N-tiles {wave, wave+4}, all M-tiles ----
+    const int NT = (D + 15) / 16;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    f32x4 acc[MAX_MT][NTW];
+#pragma unroll
+    for (int a = 0; a < MAX_MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *bp[NTW];
+    bool live[NTW];
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        const int nt = wave + b * AGG_WAVES;
+        live[b] = nt < NT;
+        bp[b] = W1p + (size_t)((live[b] ? nt : 0) * 16 + r16) * K1p + 4 * g4;
+    }
+    const int nchunk = K1p / 16;
+    f32x4 bcur[NTW], bnext[NTW];
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) bcur[b] = *reinterpret_cast<const f32x4 *>(bp[b]);
+    for (int kc = 0; kc < nchunk; ++kc) {
+        if (kc + 1 < nchunk) {
+#pragma unroll
+            for (int b = 0; b < NTW; ++b) bnext[b] = *reinterpret_cast<const f32x4 *>(bp[b] + 16 * (kc + 1));
+        }
+#pragma unroll
+        for (int a = 0; a < MAX_MT; ++a) {
+            if (a < mt_count) {
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4);
+#pragma unroll
+                for (int b = 0; b < NTW; ++b) {
+                    if (live[b]) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bcur[b][0], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bcur[b][1], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bcur[b][2], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bcur[b][3], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) bcur[b] = bnext[b];
+    }
+    __syncthreads();   // every wave is done reading the A tile: reuse it for the hidden rows
+
+    // ---- bias + ReLU + weight, staged as Hs[g][col] in the A region ----
+    float *Hs = A;                               // [rows_p][ldh]
+    const int ldh = NT * 16 + 1;
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        if (!live[b]) continue;
+        const int col = (wave + b * AGG_WAVES) * 16 + r16;
+        const float bias = col < D ? b1[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < MAX_MT; ++a) {
+            if (a >= mt_count) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = a * 16 + g4 * 4 + j;
+                float v = acc[a][b][j] + bias;
+                v = v > 0.f ? v : 0.f;
+                Hs[(size_t)g * ldh + col] = v * wn[g];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- reduce over the k neighbours of each query row ----
+    for (int idx = tid; idx < nq * D; idx += AGG_THREADS) {
+        const int q = idx / D, c = idx % D;
+        float s = 0.f;
+        for (int j = 0; j < k; ++j) s += Hs[(size_t)(q * k + j) * ldh + c];
+        H[((size_t)m * N + q0 + q) * D + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// out[n] = [ fc2s(relu(fc1s(memory[nodes[n]]))) | fc2(H_0[n]) + b2*S_0[n] | ... ]
+// Weights arrive transposed (Wt[in][out]) so that lanes read them coalesced.
+// One workgroup per 16 rows; thread = (output column, row half).
+// ---------------------------------------------------------------------------
+constexpr int OUT_ROWS = 16;
+
+__global__ __launch_bounds__(256) void k_embed_out(const float *__restrict__ memory, long long num_nodes,
+                                                   const int *__restrict__ nodes, long long N, int D, int M,
+                                                   const float *__restrict__ H, const float *__restrict__ S,
+                                                   const float *__restrict__ fc2_t, const float *__restrict__ fc2_b,
+                                                   const float *__restrict__ fc1s_t, const float *__restrict__ fc1s_b,
+                                                   const float *__restrict__ fc2s_t, const float *__restrict__ fc2s_b,
+                                                   float *__restrict__ out, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *X = reinterpret_cast<float *>(smem);          // [OUT_ROWS][D] input rows
+    float *Y = X + OUT_ROWS * D;                         // [OUT_ROWS][D] hidden rows (source path)
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * OUT_ROWS;
+    const int nr = (int)((N - r0) < OUT_ROWS ? (N - r0) : OUT_ROWS);
+    const int OW = D * (M + 1);
+    const int col = tid % 128, half = tid / 128;          // rows [half*8, half*8+8)
+
+    // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
+    for (int idx = tid; idx < OUT_ROWS * D; idx += 256) {
+        const int r = idx / D, c = idx % D;
+        float v = 0.f;
+        if (r < nr) {
+            int nd = nodes[r0 + r];
+            if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
+            v = memory[(size_t)nd * D + c];
+        }
+        X[idx] = v;
+    }
+    __syncthreads();
+    if (col < D) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = fc1s_b[col];
+        for (int i = 0; i < D; ++i) {
+            const float wv = fc1s_t[(size_t)i * D + col];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += X[(half * 8 + r) * D + i] * wv;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) Y[(half * 8 + r) * D + col] = acc[r] > 0.f ? acc[r] : 0.f;
+    }
+    __syncthreads();
+    if (col < D) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = fc2s_b[col];
+        for (int i = 0; i < D; ++i) {
+            const float wv = fc2s_t[(size_t)i * D + col];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += Y[(half * 8 + r) * D + i] * wv;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (half * 8 + r < nr) out[(size_t)(r0 + half * 8 + r) * OW + col] = acc[r];
+    }
+    // ---- neighbour paths: fc2 on the reduced rows of each model ----
+    for (int m = 0; m < M; ++m) {
+        __syncthreads();
+        for (int idx = tid; idx < OUT_ROWS * D; idx += 256) {
+            const int r = idx / D, c = idx % D;
+            X[idx] = r < nr ? H[((size_t)m * N + r0 + r) * D + c] : 0.f;
+        }
+        __syncthreads();
+        if (col < D) {
+            float acc[8];
+            const float bias = fc2_b[col];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = half * 8 + r;
+                acc[r] = rr < nr ? bias * S[(size_t)m * N + r0 + rr] : 0.f;
+            }
+            for (int i = 0; i < D; ++i) {
+                const float wv = fc2_t[(size_t)i * D + col];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] += X[(half * 8 + r) * D + i] * wv;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (half * 8 + r < nr) out[(size_t)(r0 + half * 8 + r) * OW + (size_t)D * (m + 1) + col] = acc[r];
+        }
+    }
+}
+
+struct EmbedPlan {
+    int Dp, K1p, lda, mt, rq;
+    size_t lds;
+    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, total;
+};
+
+bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
+{
+    const int K1 = D + F + T;
+    p.Dp = round_up(D, 16);
+    p.K1p = round_up(K1, 16);
+    p.lda = p.K1p + 4;
+    // M-tiles per workgroup: as many whole query rows as fit in 5 tiles / the LDS budget
+    int mt = MAX_MT;
+    while (mt > 1 && ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4) > (size_t)LDS_BUDGET) --mt;
+    int rq = (mt * 16) / k;
+    if (rq < 1) {
+        // one query row must fit: grow to ceil(k/16) tiles if the budget allows
+        mt = (k + 15) / 16;
+        rq = 1;
+        if (mt > MAX_MT || ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4) > (size_t)LDS_BUDGET) return false;
+    }
+    mt = (rq * k + 15) / 16;
+    p.mt = mt;
+    p.rq = rq;
+    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4;
+    // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
+    if ((size_t)mt * 16 * (p.Dp + 1) * 4 > (size_t)mt * 16 * p.lda * 4) return false;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    p.off_w1p = take((size_t)p.Dp * p.K1p * 4);
+    p.off_H = take((size_t)M * N * D * 4);
+    p.off_S = take((size_t)M * N * 4);
+    p.off_fc2t = take((size_t)D * D * 4);
+    p.off_fc1st = take((size_t)D * D * 4);
+    p.off_fc2st = take((size_t)D * D * 4);
+    p.total = o;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
+{
+    EmbedPlan p;
+    if (N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) return -1;
+    if (!make_plan(N > 0 ? N : 1, D, F, T, M, k, p)) return -1;
+    return (int64_t)p.total;
+}
+
+extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
+                        int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
+                        const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                        const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
+                        void *stream)
+{
+    if (!memory_dev || !efeat_dev || !wt || !status_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) {
+        set_error("zt_embed: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (N == 0) return ZT_OK;
+    if (!nodes_dev || !nbr_dev || !eix_dev || !dt_dev || !w_dev || !out_dev || !workspace_dev) {
+        set_error("zt_embed: NULL buffer");
+        return ZT_ERR_ARG;
+    }
+    EmbedPlan p;
+    if (D > 16 * NTW * AGG_WAVES || D > 128 || !make_plan(N, D, F, T, M, k, p)) {
+        set_error("zt_embed: D=%d F=%d T=%d k=%d outside the supported shapes (D<=128, one query row of k "
+                  "neighbours must fit the %d KB LDS tile)", D, F, T, k, LDS_BUDGET / 1024);
+        return ZT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    float *W1p = reinterpret_cast<float *>(ws + p.off_w1p);
+    float *H = reinterpret_cast<float *>(ws + p.off_H);
+    float *S = reinterpret_cast<float *>(ws + p.off_S);
+    float *fc2t = reinterpret_cast<float *>(ws + p.off_fc2t);
+    float *fc1st = reinterpret_cast<float *>(ws + p.off_fc1st);
+    float *fc2st = reinterpret_cast<float *>(ws + p.off_fc2st);
+    const int K1 = D + F + T;
+    k_pad_matrix<<<(p.Dp * p.K1p + 255) / 256, 256, 0, s>>>(wt->fc1_w, D, K1, W1p, p.Dp, p.K1p);
+    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2_w, D, D, fc2t);
+    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc1s_w, D, D, fc1st);
+    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2s_w, D, D, fc2st);
+    static size_t attr_lds = 0;
+    if (p.lds > 48 * 1024 && p.lds > attr_lds) {
+        ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc1_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.lds));
+        attr_lds = p.lds;
+    }
+    dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
+    k_fc1_agg<<<grid, AGG_THREADS, p.lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N, k,
+                                               p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
+                                               wt->fc1_b, H, S, status_dev);
+    const size_t lds2 = (size_t)2 * OUT_ROWS * D * 4;
+    k_embed_out<<<(unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), 256, lds2, s>>>(
+        memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
+        out_dev, status_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}

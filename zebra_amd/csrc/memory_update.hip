@@ -1,0 +1,320 @@
+// TGN node-memory maintenance (P3): "last message wins" raw-message store and
+// the GRU memory update.
+//
+// Replaces TGN.get_raw_messages + Memory.store_raw_messages
+// (reference model/tgn_model.py:204-226, modules/memory.py:27-30) and
+// SequenceMemoryUpdater.update_memory / update_memory_in_test with nn.GRUCell
+// (modules/memory_updater.py:29-57,95-98) + Memory.clear_messages (:59-60).
+//
+// The reference resolves "last occurrence per node" on the host (np.unique on
+// the flipped batch) and keeps the pending-message flags in a host numpy
+// array; here both stay on the device: an atomicMax over batch positions picks
+// the winner, flags are a device u8 array.  The GRU runs on exact-f32 MFMA
+// with the gathered [message | memory] rows staged in LDS.
+#include "common.hpp"
+
+using namespace zt;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------ last message ----
+__global__ void k_last_pos(const int *__restrict__ src, const int *__restrict__ dst,
+                           const long long *__restrict__ eidx, long long B, long long num_nodes, long long num_edges,
+                           int *scratch, int *status)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 2 * B) return;
+    const int v = p < B ? src[p] : dst[p - B];
+    const long long e = eidx[p < B ? p : p - B];
+    if (v < 0 || v >= num_nodes || e < 0 || e >= num_edges) { atomicExch(status, ZT_ERR_RANGE); return; }
+    atomicMax(&scratch[v], (int)p);
+}
+
+// one wavefront per batch position; only the last occurrence of a node writes
+__global__ __launch_bounds__(256) void k_build_messages(
+    const float *__restrict__ memory, const float *__restrict__ last_update, const float *__restrict__ efeat,
+    const float *__restrict__ time_w, long long num_nodes, long long num_edges, int D, int F, int T,
+    const int *__restrict__ src, const int *__restrict__ dst, const double *__restrict__ ts,
+    const long long *__restrict__ eidx, long long B, float *messages, float *msg_ts, unsigned char *flags,
+    int *scratch, int *uniq_ids, int *n_uniq, const int *status)
+{
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= 2 * B) return;
+    const bool rejected = *status == ZT_ERR_RANGE;          // whole call rejected: only restore scratch
+    const long long i = p < B ? p : p - B;
+    const int v = p < B ? src[i] : dst[i];
+    if (v < 0 || v >= num_nodes) return;
+    if (scratch[v] != (int)p) return;                        // not the last occurrence (or already reset)
+    if (!rejected) {
+        const int partner = p < B ? dst[i] : src[i];
+        const float tf = (float)ts[i];                       // edge_times .float() (tgn_model.py:213)
+        const float delta = tf - last_update[v];             // :221
+        const int msg = 2 * D + F + T;
+        float *row = messages + (size_t)v * msg;
+        const float *m1 = memory + (size_t)v * D, *m2 = memory + (size_t)partner * D;
+        const float *er = efeat + (size_t)eidx[i] * F;
+        for (int c = lane; c < D; c += WAVE) row[c] = m1[c];
+        for (int c = lane; c < D; c += WAVE) row[D + c] = m2[c];
+        for (int c = lane; c < F; c += WAVE) row[2 * D + c] = er[c];
+        for (int c = lane; c < T; c += WAVE) row[2 * D + F + c] = cosf(delta * time_w[c]);
+        if (lane == 0) {
+            msg_ts[v] = tf;
+            flags[v] = 1;
+            if (uniq_ids) uniq_ids[atomicAdd(n_uniq, 1)] = v;
+            else if (n_uniq) atomicAdd(n_uniq, 1);
+        }
+    }
+    if (lane == 0) scratch[v] = -1;
+}
+
+// ------------------------------------------------------------------- GRU ----
+// Compact the flagged subset of ids (or of all nodes) into rows[]; clear the
+// flags of every id considered (Memory.clear_messages).
+__global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, const int *__restrict__ n_ids_dev,
+                                 long long num_nodes, unsigned char *flags, int *rows, int *n_rows)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long n = ids ? (n_ids_dev ? (long long)*n_ids_dev : n_ids) : num_nodes;
+    if (ids && n > n_ids && n_ids_dev == nullptr) n = n_ids;
+    if (t >= n) return;
+    const int v = ids ? ids[t] : (int)t;
+    if (v < 0 || v >= num_nodes) return;
+    // clear the flag byte atomically (32-bit word) so that a duplicated id is
+    // selected once
+    unsigned *wp = reinterpret_cast<unsigned *>(flags + (v & ~3));
+    const unsigned mask = 0xffu << (8 * (v & 3));
+    const unsigned old = atomicAnd(wp, ~mask);
+    if (old & mask) rows[atomicAdd(n_rows, 1)] = v;
+}
+
+constexpr int GRU_MT = 2;      // 32 rows per workgroup
+constexpr int GRU_NTW = 2;     // hidden N-tiles per wave -> D <= 128
+
+// Zero-padded gate-major copy: W[3D][K] -> Wp[3][Dp][Kp]
+__global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *__restrict__ Wp, int Dp, int Kp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * Dp * Kp) return;
+    const int g = i / (Dp * Kp), r = (i / Kp) % Dp, c = i % Kp;
+    Wp[i] = (r < D && c < K) ? W[((size_t)g * D + r) * K + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, const float *__restrict__ messages,
+                                             const float *__restrict__ msg_ts, const int *__restrict__ rows,
+                                             const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
+                                             int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
+                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = *n_rows;
+    const int r0 = blockIdx.x * (GRU_MT * 16);
+    if (r0 >= total) return;
+    const int nr = (total - r0) < GRU_MT * 16 ? (total - r0) : GRU_MT * 16;
+    const int Dp = Hp;
+
+    for (int g = wave; g < GRU_MT * 16; g += 4) {
+        float *row = A + (size_t)g * lda;
+        if (g >= nr) {
+            for (int c = lane; c < Xp + Hp; c += WAVE) row[c] = 0.f;
+            continue;
+        }
+        const int v = rows[r0 + g];
+        const float *x = messages + (size_t)v * msg_dim, *h = memory + (size_t)v * D;
+        for (int c = lane; c < Xp; c += WAVE) row[c] = c < msg_dim ? x[c] : 0.f;
+        for (int c = lane; c < Hp; c += WAVE) row[Xp + c] = c < D ? h[c] : 0.f;
+    }
+    __syncthreads();
+
+    const int NT = (D + 15) / 16;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    // per (m-tile, n-tile): r, z (message + memory), n_i (message), n_h (memory)
+    f32x4 ar[GRU_MT][GRU_NTW], az[GRU_MT][GRU_NTW], ani[GRU_MT][GRU_NTW], anh[GRU_MT][GRU_NTW];
+#pragma unroll
+    for (int a = 0; a < GRU_MT; ++a)
+#pragma unroll
+        for (int b = 0; b < GRU_NTW; ++b) {
+            ar[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; az[a][b] = ar[a][b]; ani[a][b] = ar[a][b]; anh[a][b] = ar[a][b];
+        }
+    bool live[GRU_NTW];
+    int colrow[GRU_NTW];
+#pragma unroll
+    for (int b = 0; b < GRU_NTW; ++b) {
+        const int nt = wave + b * 4;
+        live[b] = nt < NT;
+        colrow[b] = (live[b] ? nt : 0) * 16 + r16;
+    }
+    // message part: gi = W_ih x
+    for (int kc = 0; kc < Xp / 16; ++kc) {
+        f32x4 av[GRU_MT];
+#pragma unroll
+        for (int a = 0; a < GRU_MT; ++a)
+            av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4);
+#pragma unroll
+        for (int b = 0; b < GRU_NTW; ++b) {
+            if (!live[b]) continue;
+            const size_t o = (size_t)colrow[b] * Xp + 16 * kc + 4 * g4;
+            const f32x4 wr = *reinterpret_cast<const f32x4 *>(Wih_p + o);
+            const f32x4 wz = *reinterpret_cast<const f32x4 *>(Wih_p + (size_t)Dp * Xp + o);
+            const f32x4 wn = *reinterpret_cast<const f32x4 *>(Wih_p + (size_t)2 * Dp * Xp + o);
+#pragma unroll
+            for (int a = 0; a < GRU_MT; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[j], ar[a][b], 0, 0, 0);
+                    az[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wz[j], az[a][b], 0, 0, 0);
+                    ani[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[j], ani[a][b], 0, 0, 0);
+                }
+        }
+    }
+    // memory part: gh = W_hh h
+    for (int kc = 0; kc < Hp / 16; ++kc) {
+        f32x4 av[GRU_MT];
+#pragma unroll
+        for (int a = 0; a < GRU_MT; ++a)
+            av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + Xp + 16 * kc + 4 * g4);
+#pragma unroll
+        for (int b = 0; b < GRU_NTW; ++b) {
+            if (!live[b]) continue;
+            const size_t o = (size_t)colrow[b] * Hp + 16 * kc + 4 * g4;
+            const f32x4 wr = *reinterpret_cast<const f32x4 *>(Whh_p + o);
+            const f32x4 wz = *reinterpret_cast<const f32x4 *>(Whh_p + (size_t)Dp * Hp + o);
+            const f32x4 wn = *reinterpret_cast<const f32x4 *>(Whh_p + (size_t)2 * Dp * Hp + o);
+#pragma unroll
+            for (int a = 0; a < GRU_MT; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[j], ar[a][b], 0, 0, 0);
+                    az[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wz[j], az[a][b], 0, 0, 0);
+                    anh[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[j], anh[a][b], 0, 0, 0);
+                }
+        }
+    }
+    // gates (torch.nn.GRUCell): r,z = sigmoid(gi+gh); n = tanh(gi_n + r*gh_n); h' = (1-z)*n + z*h
+#pragma unroll
+    for (int b = 0; b < GRU_NTW; ++b) {
+        if (!live[b]) continue;
+        const int col = (wave + b * 4) * 16 + r16;
+        if (col >= D) continue;
+        const float bir = b_ih[col], biz = b_ih[D + col], bin = b_ih[2 * D + col];
+        const float bhr = b_hh[col], bhz = b_hh[D + col], bhn = b_hh[2 * D + col];
+#pragma unroll
+        for (int a = 0; a < GRU_MT; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = a * 16 + g4 * 4 + j;
+                if (g >= nr) continue;
+                const float r = 1.f / (1.f + expf(-(ar[a][b][j] + bir + bhr)));
+                const float z = 1.f / (1.f + expf(-(az[a][b][j] + biz + bhz)));
+                const float n = tanhf(ani[a][b][j] + bin + r * (anh[a][b][j] + bhn));
+                const float hold = A[(size_t)g * lda + Xp + col];
+                memory[(size_t)rows[r0 + g] * D + col] = (1.f - z) * n + z * hold;
+            }
+    }
+    for (int g = tid; g < nr; g += 256) {
+        const int v = rows[r0 + g];
+        last_update[v] = msg_ts[v];                   // memory_updater.py:40
+    }
+}
+
+struct GruPlan {
+    int Xp, Hp, lda;
+    size_t lds, off_rows, off_cnt, off_wih, off_whh, total;
+};
+
+void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
+{
+    p.Xp = round_up(msg_dim, 16);
+    p.Hp = round_up(D, 16);
+    p.lda = p.Xp + p.Hp + 4;
+    p.lds = (size_t)GRU_MT * 16 * p.lda * 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    p.off_cnt = take(256);
+    p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
+    p.off_wih = take((size_t)3 * p.Hp * p.Xp * 4);
+    p.off_whh = take((size_t)3 * p.Hp * p.Hp * 4);
+    p.total = o;
+}
+
+}  // namespace
+
+extern "C" int zt_store_messages(const float *memory_dev, const float *last_update_dev, const float *efeat_dev,
+                                 const float *time_w_dev, int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F,
+                                 int32_t T, const int32_t *src_dev, const int32_t *dst_dev, const double *ts_dev,
+                                 const int64_t *eidx_dev, int64_t B, float *messages_dev, float *msg_ts_dev,
+                                 uint8_t *flags_dev, int32_t *scratch_dev, int32_t *uniq_ids_dev, int32_t *n_uniq_dev,
+                                 int32_t *status_dev, void *stream)
+{
+    if (B < 0 || D <= 0 || F < 0 || T < 0 || !status_dev) { set_error("zt_store_messages: bad argument"); return ZT_ERR_ARG; }
+    if (B == 0) return ZT_OK;
+    if (!memory_dev || !last_update_dev || !efeat_dev || !time_w_dev || !src_dev || !dst_dev || !ts_dev || !eidx_dev ||
+        !messages_dev || !msg_ts_dev || !flags_dev || !scratch_dev) {
+        set_error("zt_store_messages: NULL buffer");
+        return ZT_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (n_uniq_dev) ZT_HIP(hipMemsetAsync(n_uniq_dev, 0, sizeof(int), s));
+    const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
+    k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
+                                                               scratch_dev, status_dev);
+    k_build_messages<<<(unsigned)((2 * B + 3) / 4), 256, 0, s>>>(
+        memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
+        B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t msg_dim)
+{
+    if (max_rows < 0 || D <= 0 || msg_dim <= 0) return -1;
+    GruPlan p;
+    gru_plan(max_rows, D, msg_dim, p);
+    return (int64_t)p.total;
+}
+
+extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const float *messages_dev,
+                             const float *msg_ts_dev, uint8_t *flags_dev, int64_t num_nodes, int32_t D,
+                             int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids, const int32_t *n_ids_dev,
+                             const zt_gru_weights *wt, void *workspace_dev, void *stream)
+{
+    if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
+        D <= 0 || msg_dim <= 0 || n_ids < 0) {
+        set_error("zt_gru_update: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (D > 128) { set_error("zt_gru_update: D=%d > 128 unsupported", D); return ZT_ERR_UNSUPPORTED; }
+    const int64_t max_rows = ids_dev ? n_ids : num_nodes;
+    if (max_rows == 0) return ZT_OK;
+    GruPlan p;
+    gru_plan(max_rows, D, msg_dim, p);
+    if (p.lds > 150 * 1024) { set_error("zt_gru_update: message width %d too large", msg_dim); return ZT_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    int *cnt = reinterpret_cast<int *>(ws + p.off_cnt);
+    int *rows = reinterpret_cast<int *>(ws + p.off_rows);
+    float *wih = reinterpret_cast<float *>(ws + p.off_wih);
+    float *whh = reinterpret_cast<float *>(ws + p.off_whh);
+    ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
+                                                                      rows, cnt);
+    k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
+    k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
+    static size_t attr_lds = 0;
+    if (p.lds > 48 * 1024 && p.lds > attr_lds) {
+        ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.lds));
+        attr_lds = p.lds;
+    }
+    const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
+    k_gru<<<grid, 256, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
+                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}

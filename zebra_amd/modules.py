@@ -1,0 +1,392 @@
+"""Host-side mirror of the reference's hot-path modules over the HIP library.
+
+Class, method, parameter and attribute names follow the reference so that a
+driver written against it (and its ``state_dict``) keeps working:
+
+  TimeEncode                model/time_encoding.py:6-28
+  MergeLayer                utils/util.py:14-26
+  Memory                    modules/memory.py:7-60
+  GRUMemoryUpdater          modules/memory_updater.py:19-98
+  GraphDiffusionEmbedding   modules/embedding_module.py:76-336
+
+Eval-mode forward (the path the metric is defined on) runs entirely in
+libzebra_amd.so.  ``train=True`` needs autograd through the aggregation and
+the GRU; that path is composed from torch device ops on the same device-side
+T-PPR outputs ("next") -- never from the CPU oracle.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _capi
+from ._capi import check, lib, ptr, stream_ptr
+from .tppr import tppr_finder
+
+
+class TimeEncode(nn.Module):
+    """cos(t * w + 0), w_i = 10^(-9i/(dim-1)) evaluated in float32 by numpy
+    exactly as the reference does (model/time_encoding.py:18)."""
+
+    def __init__(self, dimension):
+        super().__init__()
+        self.dimension = dimension
+        self.w = nn.Linear(1, dimension)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.w.weight = nn.Parameter(
+            torch.from_numpy(1 / 10 ** np.linspace(0, 9, self.dimension, dtype=np.float32)).reshape(self.dimension, -1))
+        self.w.bias = nn.Parameter(torch.zeros(self.dimension))
+        self.w.weight.requires_grad = False
+        self.w.bias.requires_grad = False
+
+    @torch.no_grad()
+    def forward(self, t):
+        return torch.cos(self.w(t.unsqueeze(dim=2)))
+
+
+class MergeLayer(nn.Module):
+    def __init__(self, dim1, dim2, dim3, dim4):
+        super().__init__()
+        self.fc1 = nn.Linear(dim1 + dim2, dim3)
+        self.fc2 = nn.Linear(dim3, dim4)
+        self.act = nn.ReLU()
+        nn.init.xavier_normal_(self.fc1.weight)
+        nn.init.xavier_normal_(self.fc2.weight)
+
+    def forward(self, x1, x2):
+        return self.fc2(self.act(self.fc1(torch.cat([x1, x2], dim=1))))
+
+
+class Memory(nn.Module):
+    """Dense per-node state.  Unlike the reference, the pending-message flags
+    live on the device (``flags``, uint8); ``nodes`` returns a host bool copy
+    for code that inspects them."""
+
+    def __init__(self, n_nodes, memory_dimension, input_dimension, message_dimension=None, device="cuda",
+                 combination_method="sum"):
+        super().__init__()
+        self.n_nodes = n_nodes
+        self.memory_dimension = memory_dimension
+        self.input_dimension = input_dimension
+        self.message_dimension = message_dimension
+        self.device = torch.device(device)
+        self.combination_method = combination_method
+        self.__init_memory__()
+
+    def __init_memory__(self):
+        d = self.device
+        self.memory = torch.zeros((self.n_nodes, self.memory_dimension), device=d)
+        self.last_update = torch.zeros(self.n_nodes, device=d)
+        self._flag_buf = torch.zeros((self.n_nodes + 3) // 4 * 4, dtype=torch.uint8, device=d)
+        self.messages = torch.zeros((self.n_nodes, self.message_dimension), device=d)
+        self.timestamps = torch.zeros(self.n_nodes, device=d)
+
+    @property
+    def flags(self):
+        return self._flag_buf[: self.n_nodes]
+
+    @property
+    def nodes(self):
+        return self.flags.cpu().numpy().astype(bool)
+
+    def _ids(self, idx):
+        if torch.is_tensor(idx):
+            return idx.to(self.device).long()
+        return torch.as_tensor(np.asarray(idx), device=self.device).long()
+
+    def store_raw_messages(self, nodes, messages, timestamps):
+        ids = self._ids(nodes)
+        self.flags[ids] = 1
+        self.messages[ids] = messages
+        self.timestamps[ids] = timestamps
+
+    def get_memory(self, node_idxs):
+        return self.memory[self._ids(node_idxs), :]
+
+    def set_memory(self, node_idxs, values):
+        self.memory[self._ids(node_idxs), :] = values
+
+    def get_last_update(self, node_idxs):
+        return self.last_update[self._ids(node_idxs)]
+
+    def backup_memory(self):
+        return (self.memory.clone(), self.last_update.clone(), self.messages.clone(), self._flag_buf.clone(),
+                self.timestamps.clone())
+
+    def restore_memory(self, memory_backup):
+        self.memory, self.last_update, self.messages = (memory_backup[0].clone(), memory_backup[1].clone(),
+                                                        memory_backup[2].clone())
+        self._flag_buf = memory_backup[3].clone()
+        self.timestamps = memory_backup[4].clone()
+
+    def detach_memory(self):
+        self.memory.detach_()
+        self.messages.detach_()
+
+    def clear_messages(self, positives):
+        self.flags[self._ids(positives)] = 0
+
+
+class GRUMemoryUpdater(nn.Module):
+    """SequenceMemoryUpdater + nn.GRUCell (modules/memory_updater.py:19-98)."""
+
+    def __init__(self, message_dimension, memory_dimension, device):
+        super().__init__()
+        self.layer_norm = nn.LayerNorm(memory_dimension)       # dead parameter in the reference; kept for state_dict
+        self.message_dimension = message_dimension
+        self.device = torch.device(device)
+        self.memory_updater = nn.GRUCell(input_size=message_dimension, hidden_size=memory_dimension)
+        self.t_index = self.t_real_update = self.t_others = 0
+        self._ws = None
+
+    def _weights(self):
+        g = self.memory_updater
+        self._gw = _capi.GruWeights(ptr(g.weight_ih.detach()), ptr(g.weight_hh.detach()), ptr(g.bias_ih.detach()),
+                                    ptr(g.bias_hh.detach()))
+        return self._gw
+
+    def _workspace(self, max_rows, D):
+        need = lib().zt_gru_workspace_bytes(C.c_int64(max_rows), C.c_int32(D), C.c_int32(self.message_dimension))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def update_device(self, memory, ids_d=None, n_ids=0, n_ids_d=None):
+        """GRU-update the flagged subset of ``ids_d`` (None = all nodes) in place
+        and clear their flags; everything stays on the device."""
+        D = memory.memory_dimension
+        max_rows = memory.n_nodes if ids_d is None else int(n_ids)
+        if max_rows == 0:
+            return
+        ws = self._workspace(max_rows, D)
+        check(lib().zt_gru_update(ptr(memory.memory), ptr(memory.last_update), ptr(memory.messages),
+                                  ptr(memory.timestamps), ptr(memory._flag_buf), C.c_int64(memory.n_nodes),
+                                  C.c_int32(D), C.c_int32(self.message_dimension), ptr(ids_d), C.c_int64(n_ids),
+                                  ptr(n_ids_d), C.byref(self._weights()), ptr(ws), stream_ptr()), "zt_gru_update")
+
+    @torch.no_grad()
+    def update_memory(self, memory, positives):                 # modules/memory_updater.py:29-43
+        ids = torch.as_tensor(np.ascontiguousarray(positives, np.int32), device=self.device)
+        self.update_device(memory, ids, ids.numel())
+
+    @torch.no_grad()
+    def update_memory_in_test(self, memory):                    # modules/memory_updater.py:46-57
+        self.update_device(memory, None)
+
+    def get_updated_memory(self, memory, index=None):           # modules/memory_updater.py:61-90
+        """Train-mode lazily-updated copy (autograd flows through the GRU).
+        Device torch ops; the reference clones the whole memory here too."""
+        flags = memory.flags
+        if index is None:
+            ids = torch.nonzero(flags, as_tuple=False).view(-1)
+        else:
+            idx = torch.as_tensor(np.asarray(index), device=self.device).long()
+            ids = idx[flags[idx] != 0]
+        if ids.numel() == 0:
+            return memory.memory.clone(), memory.last_update.clone()
+        updated_memory = memory.memory.clone()
+        updated_memory[ids] = self.memory_updater(memory.messages[ids], updated_memory[ids])
+        updated_last_update = memory.last_update.clone()
+        updated_last_update[ids] = memory.timestamps[ids]
+        return updated_memory, updated_last_update
+
+
+def get_memory_updater(module_type, message_dimension, memory_dimension, device):
+    if module_type != "gru":
+        raise ValueError("only the GRU memory updater is on the accelerated path (got %r)" % module_type)
+    return GRUMemoryUpdater(message_dimension, memory_dimension, device)
+
+
+class GraphDiffusionEmbedding(nn.Module):
+    """modules/embedding_module.py:76-336 (GraphEmbedding -> GraphDiffusionEmbedding)."""
+
+    def __init__(self, node_features, edge_features, memory, neighbor_finder, time_encoder, n_layers,
+                 n_node_features, n_edge_features, n_time_features, embedding_dimension, device, n_heads=2,
+                 dropout=0.1, use_memory=True, args=None, num_nodes=-1):
+        super().__init__()
+        self.node_features = node_features
+        self.edge_features = edge_features
+        self.neighbor_finder = neighbor_finder
+        self.time_encoder = time_encoder
+        self.n_layers = n_layers
+        self.n_node_features = n_node_features
+        self.n_edge_features = n_edge_features
+        self.n_time_features = n_time_features
+        self.dropout = dropout
+        self.embedding_dimension = embedding_dimension
+        self.device = torch.device(device)
+        self.use_memory = use_memory
+        self.args = args
+        self.num_nodes = num_nodes
+        self.t_tppr = 0
+        self.sync_timers = False
+
+        self.fc1 = nn.Linear(embedding_dimension + n_time_features + n_edge_features, embedding_dimension)
+        self.fc2 = nn.Linear(embedding_dimension, embedding_dimension)
+        self.act = nn.ReLU()
+        self.drop = nn.Dropout(0.1)
+        nn.init.xavier_normal_(self.fc1.weight)
+        nn.init.xavier_normal_(self.fc2.weight)
+        self.fc1_source = nn.Linear(embedding_dimension, embedding_dimension)
+        self.fc2_source = nn.Linear(embedding_dimension, embedding_dimension)
+        nn.init.xavier_normal_(self.fc1_source.weight)
+        nn.init.xavier_normal_(self.fc2_source.weight)
+        self.combiner = nn.Linear(embedding_dimension + embedding_dimension, embedding_dimension)   # dead, as in the reference
+
+        self.n_tppr = len(args.alpha_list)
+        self.alpha_list = list(args.alpha_list)
+        self.beta_list = list(args.beta_list)
+        self.k = args.topk
+        self.tppr_strategy = args.tppr_strategy
+        self.width = args.n_degree
+        self.depth = args.n_layer
+        assert self.k != 0
+        if self.tppr_strategy == "streaming":
+            self.tppr_finder = tppr_finder(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list,
+                                           reference_compat_aliasing=getattr(args, "reference_compat_aliasing", False))
+        self._ws = None
+        self._status = None
+        self._avg_topk_t = None
+
+    # ---- T-PPR state management (modules/embedding_module.py:114-136) ----
+    def reset_tppr(self):
+        self.tppr_finder.reset_tppr()
+
+    def backup_tppr(self):
+        return self.tppr_finder.backup_tppr()
+
+    def restore_tppr(self, backup):
+        self.tppr_finder.restore_tppr(backup)
+
+    def streaming_topk(self, source_nodes, timestamps, edge_idxs):
+        return self.tppr_finder.streaming_topk(source_nodes, timestamps, edge_idxs)
+
+    def streaming_topk_no_fake(self, source_nodes, timestamps, edge_idxs):
+        return self.tppr_finder.streaming_topk_no_fake(source_nodes, timestamps, edge_idxs)
+
+    def fill_tppr(self, sources, targets, timestamps, edge_idxs, tppr_filled):
+        if tppr_filled:
+            self.tppr_finder.restore_val_tppr()
+        else:
+            self.tppr_finder.compute_val_tppr(sources, targets, timestamps, edge_idxs)
+
+    def pruning_topk(self, source_nodes, timestamps):           # modules/embedding_module.py:280-297
+        on, oe, od, ow = self.pruning_topk_device(
+            torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=self.device),
+            torch.as_tensor(np.ascontiguousarray(timestamps, np.float64), device=self.device))
+        return ([a for a in on.cpu().numpy()], [a for a in oe.cpu().numpy()], [a for a in od.cpu().numpy()],
+                [a for a in ow.cpu().numpy()])
+
+    def pruning_topk_device(self, nodes_d, ts_d, check_status=True):
+        n = nodes_d.numel()
+        on = torch.zeros((self.n_tppr, n, self.k), dtype=torch.int32, device=self.device)
+        oe = torch.zeros_like(on)
+        od = torch.zeros((self.n_tppr, n, self.k), dtype=torch.float32, device=self.device)
+        ow = torch.zeros_like(od)
+        for i, alpha in enumerate(self.alpha_list):
+            self.neighbor_finder.pruned_topk_device(nodes_d, ts_d, self.width, self.depth, float(alpha),
+                                                    float(self.beta_list[i]), self.k, on[i], oe[i], od[i], ow[i],
+                                                    check_status=check_status)
+        return on, oe, od, ow
+
+    @property
+    def average_topk(self):
+        return float(self._avg_topk_t.item()) if self._avg_topk_t is not None else 0.0
+
+    # ---- the hot path ----
+    def _embed_weights(self):
+        p = lambda t: ptr(t.detach())
+        self._ew = _capi.EmbedWeights(p(self.fc1.weight), p(self.fc1.bias), p(self.fc2.weight), p(self.fc2.bias),
+                                      p(self.fc1_source.weight), p(self.fc1_source.bias), p(self.fc2_source.weight),
+                                      p(self.fc2_source.bias), p(self.time_encoder.w.weight))
+        return self._ew
+
+    def topk_device(self, nodes_d, ts_d, eidx_d, check_status=True):
+        """T-PPR query for one batch, device tensors in and out."""
+        if self.tppr_strategy == "streaming":
+            B = eidx_d.numel()
+            return self.tppr_finder.stream_device(nodes_d, ts_d[:B].contiguous(), eidx_d, 3 if nodes_d.numel() == 3 * B
+                                                  else 2, True, -1, check_status=check_status)
+        if self.tppr_strategy == "pruning":
+            return self.pruning_topk_device(nodes_d, ts_d, check_status=check_status)
+        raise ValueError("tppr_strategy must be 'streaming' or 'pruning'")
+
+    def embed_device(self, memory_t, nodes_d, on, oe, od, ow, check_status=True):
+        """Eval forward of :243-276 on the HIP kernels: [N, D*(n_tppr+1)]."""
+        N, D = nodes_d.numel(), self.embedding_dimension
+        F, T = self.n_edge_features, self.n_time_features
+        need = lib().zt_embed_workspace_bytes(C.c_int64(N), C.c_int32(D), C.c_int32(F), C.c_int32(T),
+                                              C.c_int32(self.n_tppr), C.c_int32(self.k))
+        if need < 0:
+            raise ValueError("zt_embed: unsupported shape D=%d F=%d T=%d k=%d" % (D, F, T, self.k))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        out = torch.empty((N, D * (self.n_tppr + 1)), dtype=torch.float32, device=self.device)
+        check(lib().zt_embed(ptr(memory_t), ptr(self.edge_features), C.c_int64(memory_t.shape[0]),
+                             C.c_int64(self.edge_features.shape[0]), C.c_int32(D), C.c_int32(F), C.c_int32(T),
+                             ptr(nodes_d), C.c_int64(N), C.c_int32(self.n_tppr), C.c_int32(self.k), ptr(on), ptr(oe),
+                             ptr(od), ptr(ow), C.byref(self._embed_weights()), ptr(out), ptr(self._ws),
+                             ptr(self._status), stream_ptr()), "zt_embed")
+        if check_status:
+            st = int(self._status.item())
+            if st != 0:
+                self._status.zero_()
+                raise IndexError("zt_embed: node / edge id out of range (status %d)" % st)
+        return out
+
+    def compute_embedding_tppr_ensemble(self, memory, source_nodes, timestamps, edge_idxs, memory_updater, train):
+        """modules/embedding_module.py:217-278.  ``memory`` is the Memory object
+        in train mode and the raw memory tensor in eval mode, as in the reference."""
+        d = self.device
+        nodes_d = torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=d)
+        ts_d = torch.as_tensor(np.ascontiguousarray(timestamps, np.float64), device=d)
+        eidx_d = torch.as_tensor(np.ascontiguousarray(edge_idxs, np.int64), device=d)
+        t = time.time()
+        on, oe, od, ow = self.topk_device(nodes_d, ts_d, eidx_d)
+        if self.sync_timers:
+            torch.cuda.synchronize()
+        self.t_tppr += time.time() - t
+        n_edge = ow.shape[1] // 3
+        self._avg_topk_t = ow[0, : 2 * n_edge].sum(dim=1).mean()
+        if not train:
+            with torch.no_grad():
+                return self.embed_device(memory, nodes_d, on, oe, od, ow)
+        return self._train_forward(memory, nodes_d, on, oe, od, ow, memory_updater)
+
+    def _train_forward(self, memory, nodes_d, on, oe, od, ow, memory_updater):
+        """Autograd path (:227-276) composed from torch device ops."""
+        index = torch.unique(on.reshape(-1).long()).cpu().numpy()
+        mem, _ = memory_updater.get_updated_memory(memory, index)
+        embeddings = self.transform_source(mem[nodes_d.long()])
+        for m in range(self.n_tppr):
+            x = torch.cat([mem[on[m].long()], self.edge_features[oe[m].long(), :], self.time_encoder(od[m])], dim=-1)
+            x = self.transform(x)
+            w = ow[m]
+            ws = torch.sum(w, dim=1)
+            w = w / ws.unsqueeze(1)
+            w[ws == 0] = 0
+            embeddings = torch.cat((embeddings, torch.sum(x * w[:, :, None], dim=1)), dim=1)
+        return embeddings
+
+    def transform_source(self, x):
+        return self.fc2_source(self.drop(self.act(self.fc1_source(x))))
+
+    def transform(self, x):
+        return self.fc2(self.drop(self.act(self.fc1(x))))
+
+    def combine(self, x):
+        return self.combiner(x)
+
+
+def get_embedding_module(module_type, **kw):
+    if module_type != "diffusion":
+        raise ValueError("only the 'diffusion' embedding module is reachable from the reference's train.py "
+                         "(SURVEY.md 0.1); got %r" % module_type)
+    kw.pop("n_neighbors", None)
+    return GraphDiffusionEmbedding(**kw)

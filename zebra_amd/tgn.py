@@ -1,0 +1,176 @@
+"""TGN orchestration over the HIP hot path (mirror of model/tgn_model.py:14-232).
+
+``compute_temporal_embeddings`` / ``compute_edge_probabilities`` keep the
+reference's signatures (numpy batches in, tensors out) and its exact ordering
+of embedding, message store and memory update.  ``step_device`` is the same
+eval-mode protocol with device-resident inputs and no host synchronisation:
+it is what bench.py times.
+"""
+import ctypes as C
+import logging
+
+import numpy as np
+import torch
+
+from ._capi import check, lib, ptr, stream_ptr
+from .modules import Memory, MergeLayer, TimeEncode, get_embedding_module, get_memory_updater
+
+
+class TGN(torch.nn.Module):
+    def __init__(self, neighbor_finder, node_features, edge_features, device, n_layers=2, n_heads=2, dropout=0.1,
+                 use_memory=False, node_dimension=100, time_dimension=100, memory_dimension=100,
+                 embedding_module_type="diffusion", message_function="identity", n_neighbors=None,
+                 aggregator_type="last", memory_updater_type="gru", use_destination_embedding_in_message=False,
+                 use_source_embedding_in_message=False, args=None):
+        super().__init__()
+        if message_function != "identity":
+            raise ValueError("the reference only runs with the identity message function (tgn_model.py:64)")
+        if use_destination_embedding_in_message or use_source_embedding_in_message:
+            raise ValueError("embedding-in-message variants are not on the accelerated path")
+        self.batch_counter = 0
+        self.n_layers = n_layers
+        self.neighbor_finder = neighbor_finder
+        self.device = torch.device(device)
+        self.logger = logging.getLogger(__name__)
+        self.args = args
+        self.test_mode = False
+
+        if torch.is_tensor(edge_features):
+            self.edge_raw_features = edge_features.to(self.device, torch.float32).contiguous()
+        else:
+            self.edge_raw_features = torch.from_numpy(np.asarray(edge_features).astype(np.float32)).to(self.device)
+        self.n_edge_features = self.edge_raw_features.shape[1]
+        self.n_nodes = args.n_nodes
+        self.time_dimension = time_dimension
+        self.memory_dimension = memory_dimension
+        self.embedding_dimension = node_dimension
+        self.n_node_features = self.embedding_dimension
+        self.n_neighbors = n_neighbors
+        self.embedding_module_type = embedding_module_type
+        self.use_destination_embedding_in_message = use_destination_embedding_in_message
+        self.use_source_embedding_in_message = use_source_embedding_in_message
+
+        self.time_encoder = TimeEncode(dimension=self.time_dimension)
+        self.use_memory = use_memory
+        raw_message_dimension = 2 * self.memory_dimension + self.n_edge_features + self.time_dimension
+        message_dimension = raw_message_dimension
+        self.memory = Memory(n_nodes=self.n_nodes, memory_dimension=self.memory_dimension,
+                             input_dimension=message_dimension, message_dimension=message_dimension,
+                             device=self.device)
+        self.memory_updater = get_memory_updater(module_type=memory_updater_type, message_dimension=message_dimension,
+                                                 memory_dimension=self.memory_dimension, device=self.device)
+        self.embedding_module = get_embedding_module(
+            module_type=embedding_module_type, node_features=None, edge_features=self.edge_raw_features,
+            memory=self.memory, neighbor_finder=self.neighbor_finder, time_encoder=self.time_encoder,
+            n_layers=self.n_layers, n_node_features=self.n_node_features, n_edge_features=self.n_edge_features,
+            n_time_features=self.time_dimension, embedding_dimension=self.embedding_dimension, device=self.device,
+            n_heads=n_heads, dropout=dropout, use_memory=use_memory, n_neighbors=self.n_neighbors, args=args,
+            num_nodes=self.n_nodes)
+        hidden_dim = self.n_node_features * (len(args.alpha_list) + 1)
+        self.affinity_score = MergeLayer(hidden_dim, hidden_dim, hidden_dim, 1)
+        # device scratch of the message-store kernel: last occurrence per node (all -1 between calls)
+        self._scratch = torch.full((self.n_nodes,), -1, dtype=torch.int32, device=self.device)
+        self._uniq = None
+        self._n_uniq = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.reset_timer()
+
+    def reset_timer(self):
+        self.t_get_message = self.t_store_message = self.t_clear_message = self.t_message = 0
+        self.t_embedding = self.t_get_memory = self.t_update_memory = self.t_temporal = self.t_score = 0
+        self.n_update_memory = 0
+        self.embedding_module.t_tppr = 0
+
+    # ------------------------------------------------------------------ device protocol
+    def store_messages_device(self, src_d, dst_d, ts_d, eidx_d):
+        """get_raw_messages + store_raw_messages (tgn_model.py:204-226) on the device.
+        Leaves the unique endpoint ids in self._uniq[: self._n_uniq]."""
+        B = src_d.numel()
+        if self._uniq is None or self._uniq.numel() < 2 * B:
+            self._uniq = torch.empty(2 * B, dtype=torch.int32, device=self.device)
+        m = self.memory
+        check(lib().zt_store_messages(ptr(m.memory), ptr(m.last_update), ptr(self.edge_raw_features),
+                                      ptr(self.time_encoder.w.weight), C.c_int64(m.n_nodes),
+                                      C.c_int64(self.edge_raw_features.shape[0]), C.c_int32(self.memory_dimension),
+                                      C.c_int32(self.n_edge_features), C.c_int32(self.time_dimension), ptr(src_d),
+                                      ptr(dst_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B), ptr(m.messages),
+                                      ptr(m.timestamps), ptr(m._flag_buf), ptr(self._scratch), ptr(self._uniq),
+                                      ptr(self._n_uniq), ptr(self._status), stream_ptr()), "zt_store_messages")
+        return B
+
+    @torch.no_grad()
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False):
+        """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
+        int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
+        ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings."""
+        if not self.test_mode:
+            self.update_memory_in_test(self.memory)
+            self.test_mode = True
+        em = self.embedding_module
+        nodes_d = torch.cat([src_d, dst_d, neg_d])
+        ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
+        on, oe, od, ow = em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status)
+        emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
+        B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
+        self.memory_updater.update_device(self.memory, self._uniq, 2 * B, self._n_uniq)
+        if check_status:
+            st = int(self._status.item())
+            if st != 0:
+                self._status.zero_()
+                raise IndexError("node / edge id out of range (status %d)" % st)
+        return emb
+
+    # ------------------------------------------------------------------ reference surface
+    def compute_temporal_embeddings(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
+                                    n_neighbors, train):
+        self.batch_counter += 1
+        n_samples = len(source_nodes)
+        positives = np.concatenate([source_nodes, destination_nodes])
+        unique_positives = np.unique(positives)
+        self.n_update_memory += len(positives)
+        d = self.device
+        src_d = torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=d)
+        dst_d = torch.as_tensor(np.ascontiguousarray(destination_nodes, np.int32), device=d)
+        ts_d = torch.as_tensor(np.ascontiguousarray(edge_times, np.float64), device=d)
+        eidx_d = torch.as_tensor(np.ascontiguousarray(edge_idxs, np.int64), device=d)
+
+        if not train:
+            if negative_nodes is None:
+                raise ValueError("the accelerated eval path expects negatives (tgn_model.py:132)")
+            neg_d = torch.as_tensor(np.ascontiguousarray(negative_nodes, np.int32), device=d)
+            node_embedding = self.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=True)
+        else:
+            self.test_mode = False
+            nodes = np.concatenate([source_nodes, destination_nodes, negative_nodes])
+            timestamps = np.concatenate([edge_times, edge_times, edge_times])
+            node_embedding = self.embedding_module.compute_embedding_tppr_ensemble(
+                memory=self.memory, source_nodes=nodes, timestamps=timestamps, edge_idxs=edge_idxs,
+                memory_updater=self.memory_updater, train=True)
+            # update memory without gradients, THEN collect raw messages (:155-168)
+            self.update_memory(self.memory, unique_positives)
+            with torch.no_grad():
+                self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
+        return (node_embedding[:n_samples], node_embedding[n_samples:2 * n_samples], node_embedding[2 * n_samples:])
+
+    def compute_edge_probabilities(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
+                                   n_neighbors, train):
+        n_samples = len(source_nodes)
+        s, dd, n = self.compute_temporal_embeddings(source_nodes, destination_nodes, negative_nodes, edge_times,
+                                                    edge_idxs, n_neighbors, train)
+        score = self.affinity_score(torch.cat([s, s], dim=0), torch.cat([dd, n])).squeeze(dim=0)
+        return score[:n_samples].sigmoid(), score[n_samples:].sigmoid()
+
+    def update_memory(self, memory, positives):
+        with torch.no_grad():
+            self.memory_updater.update_memory(memory, positives)
+
+    def update_memory_in_test(self, memory):
+        with torch.no_grad():
+            self.memory_updater.update_memory_in_test(memory)
+
+    def get_updated_memory(self, memory):
+        return self.memory_updater.get_updated_memory(memory)
+
+    def set_neighbor_finder(self, neighbor_finder):
+        self.neighbor_finder = neighbor_finder
+        self.embedding_module.neighbor_finder = neighbor_finder
