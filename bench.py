@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py -- temporal edges/sec embedded by the T-PPR + top-k aggregate +
+memory-update path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5|c2|c3|c4]
+
+One "step" = one pass of the hot path over one batch of the synthetic stream
+(eval-mode protocol of reference model/tgn_model.py:124-174): streaming (or
+pruning) T-PPR update + row emission, gather/TimeEncode/transform/weighted
+sum for the 3B rows x n_tppr models, last-message store and GRU memory update.
+All inputs are resident in HBM when the timed region starts.
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): T-PPR
+state and memory are replicated, every rank applies the whole batch's T-PPR
+update (bit-identical replicas, no communication), the 3B embedding rows and
+the touched-endpoint memory updates are sharded, and the touched memory rows
+are exchanged with one all-gather per batch.  Total work per
+step is fixed ("strong" scaling).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with the
+`roofline` of the dominant kernel and the `cpu_baseline` (oracle timed on the
+host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # dense f32 MFMA
+
+
+def algorithmic_bytes(k, F, M, D=100, T=100):
+    """logical bytes per edge, no cache credit."""
+    msg = 2 * D + F + T
+    p1 = 5 * (24 * k + 8) + 48 * k                    # per model
+    p2 = 3 * k * (4 * D + 4 * F) + 3 * k * 16         # per model
+    p2_once = 3 * 4 * D + 3 * 4 * D * (M + 1)
+    p3 = 2 * (4 * msg + 4 * D + 4 * D + 4) + 2 * (4 * msg + 4)
+    return dict(p1=p1, p2=p2, p2_once=p2_once, p3=p3, total=M * (p1 + p2) + p2_once + p3)
+
+
+def algorithmic_flops(k, F, M, D=100, T=100):
+    msg = 2 * D + F + T
+    p2 = 3 * k * (2 * (D + F + T) * D + 2 * D * D)    # per model (reference formulation)
+    return dict(p2=p2, src=3 * 4 * D * D, gru=2 * 2 * 3 * D * (msg + D), total=M * p2 + 3 * 4 * D * D + 2 * 2 * 3 * D * (msg + D))
+
+
+def make_stream(wl, n_edges, seed=2020):
+    from zebra_amd import synth
+    src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], n_edges, bipartite=wl["bipartite"], seed=seed)
+    neg = synth.negatives(dst, n_edges, seed=seed + 1)
+    return src, dst, neg, ts, eidx
+
+
+def build_model(wl, device, n_edge_rows):
+    import types
+
+    import torch
+    from zebra_amd.tgn import TGN
+    from zebra_amd.tppr import get_neighbor_finder
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(alpha_list=list(wl["alpha"]), beta_list=list(wl["beta"]), topk=wl["k"],
+                                 tppr_strategy=wl["strategy"], n_degree=wl.get("width", 10),
+                                 n_layer=wl.get("depth", 2), n_nodes=wl["n_nodes"] + 1, n_edges=n_edge_rows)
+    F = wl["F"]
+    if F == 1:
+        efeat = torch.zeros((n_edge_rows, 1), dtype=torch.float32, device=device)
+    else:
+        g = torch.Generator(device="cpu").manual_seed(1)
+        efeat = torch.randn((n_edge_rows, F), generator=g, dtype=torch.float32)
+        efeat[0] = 0
+        efeat = efeat.to(device)
+    tgn = TGN(neighbor_finder=None, node_features=None, edge_features=efeat, device=device, n_layers=args.n_layer,
+              use_memory=True, embedding_module_type="diffusion", message_function="identity",
+              memory_updater_type="gru", n_neighbors=args.n_degree, args=args).to(device).eval()
+    return tgn
+
+
+def cpu_baseline(wl, n_edges, n_threads):
+    """Oracle ("port") on the host cores: same protocol, same stream shape,
+    a bounded prefix of the stream; the second half is timed."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    import torch
+    from zebra_amd.modules import TimeEncode
+    if wl["strategy"] != "streaming":
+        return None
+    bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
+    D = T = 100
+    n_edges = max(2 * bs, n_edges // bs * bs)
+    src, dst, neg, ts, eidx = make_stream(wl, n_edges)
+    N = wl["n_nodes"] + 1
+    torch.manual_seed(0)
+    rng = np.random.RandomState(0)
+
+    def lin(o, i):
+        return (rng.standard_normal((o, i)) * np.sqrt(2.0 / (o + i))).astype(np.float32), np.zeros(o, np.float32)
+    w = {}
+    w["fc1_w"], w["fc1_b"] = lin(D, D + F + T)
+    w["fc2_w"], w["fc2_b"] = lin(D, D)
+    w["fc1s_w"], w["fc1s_b"] = lin(D, D)
+    w["fc2s_w"], w["fc2s_b"] = lin(D, D)
+    gru = dict(w_ih=lin(3 * D, 2 * D + F + T)[0], w_hh=lin(3 * D, D)[0], b_ih=np.zeros(3 * D, np.float32),
+               b_hh=np.zeros(3 * D, np.float32))
+    tw = TimeEncode(T).w.weight.detach().numpy().ravel().copy()
+    efeat = np.zeros((n_edges + 1, F), np.float32) if F == 1 else \
+        np.random.RandomState(1).standard_normal((n_edges + 1, F)).astype(np.float32)
+    f = pyoracle.TpprOracle(N, k, M, wl["alpha"], wl["beta"])
+    mem = pyoracle.MemoryOracle(N, D, 2 * D + F + T)
+    nb = n_edges // bs
+    t0 = None
+    timed = 0
+    for b in range(nb):
+        if b == nb // 2:
+            t0 = time.perf_counter()
+        s, e = b * bs, (b + 1) * bs
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        on, oe, od, ow = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        pyoracle.embed(mem.memory, efeat, tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow), w,
+                       n_threads=n_threads)
+        mem.store_messages(efeat, tw, src[s:e], dst[s:e], ts[s:e], eidx[s:e])
+        mem.gru_update(gru, np.unique(np.concatenate([src[s:e], dst[s:e]])), n_threads=n_threads)
+        if t0 is not None:
+            timed += e - s
+    dt = time.perf_counter() - t0
+    return dict(value=timed / dt, unit="edges/s", cores=n_threads, kind="port",
+                sample="first %d edges of the same synthetic stream from an empty state, second half (%d edges) "
+                       "timed; T-PPR loop single-threaded as in the reference, aggregation/GRU on %d OpenMP "
+                       "threads" % (n_edges, timed, n_threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--prefill-steps", type=int, default=-1,
+                    help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
+    ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from zebra_amd import _capi, synth
+    import ctypes as C
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    wl = dict(synth.WORKLOADS[a.workload])
+    bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
+    prefill = a.prefill_steps if a.prefill_steps >= 0 else {"c5": 480, "c3": 300, "c2": 250, "c4": 0}[a.workload]
+    n_steps_total = prefill + a.warmup + a.steps
+    n_edges = n_steps_total * bs
+    stream_edges = min(wl["n_edges"], max(n_edges, 1))
+    if n_edges > wl["n_edges"]:
+        raise SystemExit("stream of %d edges is shorter than prefill+warmup+steps" % wl["n_edges"])
+
+    src, dst, neg, ts, eidx = make_stream(wl, n_edges)
+    n_edge_rows = (wl["n_edges"] if F == 1 else n_edges) + 1      # F=1: the full |E|+1 zero table is cheap
+    tgn = build_model(wl, device, n_edge_rows)
+    if wl["strategy"] == "pruning":
+        import types
+        from zebra_amd.tppr import get_neighbor_finder
+        tgn.set_neighbor_finder(get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst,
+                                                                          edge_idxs=eidx, timestamps=ts)))
+    src_d = torch.from_numpy(src).to(device)
+    dst_d = torch.from_numpy(dst).to(device)
+    neg_d = torch.from_numpy(neg).to(device)
+    ts_d = torch.from_numpy(ts).to(device)
+    eidx_d = torch.from_numpy(eidx).to(device)
+
+    if world > 1:
+        from zebra_amd.distributed import ShardedTGN
+        runner = ShardedTGN(tgn, rank, world)
+        step = runner.step_device
+    else:
+        step = tgn.step_device
+
+    def run(b0, nb):
+        for b in range(b0, b0 + nb):
+            s, e = b * bs, (b + 1) * bs
+            step(src_d[s:e], dst_d[s:e], neg_d[s:e], ts_d[s:e], eidx_d[s:e])
+
+    lib = _capi.lib()
+    run(0, prefill)
+    run(prefill, a.warmup)
+    tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
+    torch.cuda.synchronize()
+    if not a.no_profile:
+        lib.zt_profile_reset()
+        lib.zt_profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(prefill + a.warmup, a.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.zt_profile_enable(0)
+    if wl["strategy"] == "streaming":
+        tgn.embedding_module.tppr_finder.check_status()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-kernel HIP-event times over the timed region ----
+    kern = {}
+    if not a.no_profile:
+        for name in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg",
+                     "embed_out", "store_messages", "gru_update"):
+            n, ms = C.c_int64(), C.c_double()
+            lib.zt_profile_read(name.encode(), C.byref(n), C.byref(ms))
+            if n.value:
+                kern[name] = dict(launches=n.value, avg_us=1e3 * ms.value / n.value)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    edges = a.steps * bs
+    ab = algorithmic_bytes(k, F, M)
+    af = algorithmic_flops(k, F, M)
+    # dominant kernel = the one with the largest total time in the timed region
+    roof = None
+    if kern:
+        dom = max(kern, key=lambda n: kern[n]["avg_us"] * kern[n]["launches"])
+        per_launch_edges = bs / (world if dom in ("fc1_agg", "embed_out") and world > 1 else 1)
+        if dom in ("tppr_stream", "pruned_topk"):
+            per_model = dom == "pruned_topk"
+            byts = (ab["p1"] * (1 if per_model else M)) * bs      # one k_stream launch covers all M models
+            if a.workload == "c4":
+                byts = (3 * 110 * 16 + 48 * k) * bs
+            ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=ach / HBM_PEAK_GBS, traffic=None,
+                        note="dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in "
+                             "order along per-node chains")
+        elif dom == "fc1_agg":
+            fl = af["p2"] * per_launch_edges               # one launch covers all M models via grid.y
+            fl = fl * M
+            ach = fl / (kern[dom]["avg_us"] * 1e-6) / 1e12
+            roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=None)
+        else:
+            byts = ab["p3"] * bs
+            ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=ach / HBM_PEAK_GBS, traffic=None)
+
+    cpu = None
+    if world == 1 and a.cpu_edges != 0:
+        n_threads = min(16, os.cpu_count() or 1)
+        ce = a.cpu_edges if a.cpu_edges > 0 else {"c5": 16 * bs, "c3": 40 * bs, "c2": 60 * bs, "c4": 0}[a.workload]
+        if ce:
+            cpu = cpu_baseline(wl, ce, n_threads)
+
+    value = edges / dt
+    out = {
+        "metric": "temporal edges/sec embedded (k=%d, %d T-PPR models)" % (k, M),
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64 (T-PPR) / f32 (aggregate, GRU)", "data": "synthetic",
+        "config": {"workload": "%s: synthetic %s stream, %d nodes, bs=%d, k=%d, alpha=%s beta=%s, %s T-PPR, F=%d, "
+                               "prefill %d + warmup %d batches" % (a.workload, "bipartite" if wl["bipartite"] else
+                                                                   "power-law", wl["n_nodes"], bs, k, wl["alpha"],
+                                                                   wl["beta"], wl["strategy"], F, prefill, a.warmup),
+                   "global_batch": bs, "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
+                        "hbm_gbs_at_value": ab["total"] * value / 1e9,
+                        "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
+                        "mfma_tflops_at_value": af["total"] * value / 1e12,
+                        "mfma_frac_at_value": af["total"] * value / 1e12 / MFMA_F32_PEAK_TF},
+        "kernels": kern,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,15 @@ const char *zt_last_error(void);
 /* Library / build information ("zebra_amd <version> gfx950"). */
 const char *zt_version(void);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (replaces
+ * the reference's unsynchronised wall-clock accumulators t_tppr etc.,
+ * modules/embedding_module.py:73,220-225).  Names: tppr_prepass, tppr_stream,
+ * tppr_cleanup, pruned_topk, embed_prep, fc1_agg, embed_out, store_messages,
+ * gru_update.  zt_profile_read synchronises the device. */
+int zt_profile_enable(int on);
+int zt_profile_reset(void);
+int zt_profile_read(const char *name, int64_t *count, double *total_ms);
+
 /* ------------------------------------------------------------------------ */
 /* Streaming T-PPR  --  utils/util.py:391-873 (class tppr_finder)            */
 /* ------------------------------------------------------------------------ */
@@ -186,6 +195,21 @@ int zt_store_messages(const float *memory_dev, const float *last_update_dev,
                       float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev,
                       int32_t *scratch_dev, int32_t *uniq_ids_dev,
                       int32_t *n_uniq_dev, int32_t *status_dev, void *stream);
+
+/* Same, but only the winners whose batch position lies in [pos_lo, pos_hi)
+ * (positions 0..2B over [src|dst]) are built and stored; "last occurrence" is
+ * still resolved over the whole batch.  Used when the endpoints of a batch
+ * are sharded across GPUs: every position has at most one winner, so a shard
+ * touches at most pos_hi - pos_lo rows. */
+int zt_store_messages_range(const float *memory_dev, const float *last_update_dev,
+                            const float *efeat_dev, const float *time_w_dev,
+                            int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F,
+                            int32_t T, const int32_t *src_dev, const int32_t *dst_dev,
+                            const double *ts_dev, const int64_t *eidx_dev, int64_t B,
+                            int64_t pos_lo, int64_t pos_hi, float *messages_dev,
+                            float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
+                            int32_t *uniq_ids_dev, int32_t *n_uniq_dev,
+                            int32_t *status_dev, void *stream);
 
 typedef struct {
     const float *w_ih, *w_hh; /* [3D][msg], [3D][D]  (torch GRUCell, gates r,z,n) */

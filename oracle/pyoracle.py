@@ -211,6 +211,7 @@ class MemoryOracle:
         self.messages = np.zeros((n_nodes, msg_dim), np.float32)
         self.timestamps = np.zeros(n_nodes, np.float32)
         self.flags = np.zeros(n_nodes, np.uint8)
+        self._scratch = np.full(n_nodes, -1, np.int32)
 
     def store_messages(self, efeat, time_w, src, dst, ts, eidx):
         efeat = _c(efeat, np.float32)
@@ -224,7 +225,8 @@ class MemoryOracle:
         rc = lib().zo_store_messages(_p(self.memory), _p(self.last_update), _p(efeat), _p(time_w),
                                      C.c_int64(self.n_nodes), C.c_int64(efeat.shape[0]), C.c_int32(self.D),
                                      C.c_int32(F), C.c_int32(T), _p(src), _p(dst), _p(ts), _p(eidx),
-                                     C.c_int64(len(src)), _p(self.messages), _p(self.timestamps), _p(self.flags))
+                                     C.c_int64(len(src)), _p(self.messages), _p(self.timestamps), _p(self.flags),
+                                     _p(self._scratch))
         if rc < 0:
             raise IndexError("zo_store_messages: id out of range")
         return rc

@@ -119,6 +119,8 @@ int zo_embed(const float *memory, const float *efeat, const float *time_w,
  * [src|dst] keep the LAST occurrence of each node; message =
  * [mem[node] | mem[partner] | efeat[eidx] | cos((f32(t) - last_update[node])*w)].
  * Overwrites messages[node], msg_ts[node]; sets flags[node]=1.
+ * scratch: int32[num_nodes], all -1 on entry and on exit (last-occurrence
+ * table; persistent so that a call costs O(B), not O(num_nodes)).
  * returns the number of unique nodes, or -1 on bad id. */
 int64_t zo_store_messages(const float *memory, const float *last_update,
                           const float *efeat, const float *time_w,
@@ -126,7 +128,7 @@ int64_t zo_store_messages(const float *memory, const float *last_update,
                           int32_t F, int32_t T, const int32_t *src,
                           const int32_t *dst, const double *ts,
                           const int64_t *eidx, int64_t B, float *messages,
-                          float *msg_ts, uint8_t *flags);
+                          float *msg_ts, uint8_t *flags, int32_t *scratch);
 
 /* SequenceMemoryUpdater.update_memory / update_memory_in_test with
  * nn.GRUCell (modules/memory_updater.py:29-57,95-98).

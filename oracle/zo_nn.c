@@ -104,7 +104,7 @@ int64_t zo_store_messages(const float *memory, const float *last_update,
                           int32_t F, int32_t T, const int32_t *src,
                           const int32_t *dst, const double *ts,
                           const int64_t *eidx, int64_t B, float *messages,
-                          float *msg_ts, uint8_t *flags)
+                          float *msg_ts, uint8_t *flags, int32_t *last)
 {
     const int msg = 2 * D + F + T;
     for (int64_t i = 0; i < B; ++i) {
@@ -115,11 +115,9 @@ int64_t zo_store_messages(const float *memory, const float *last_update,
      * messages are built from the memory as it is on entry; a node's message
      * row only depends on memory/last_update, which this function does not
      * write, so building in place is safe. */
-    int64_t *last = (int64_t *)malloc(sizeof(int64_t) * (size_t)num_nodes);
-    for (int64_t v = 0; v < num_nodes; ++v) last[v] = -1;
     for (int64_t p = 0; p < 2 * B; ++p) {
         int32_t v = p < B ? src[p] : dst[p - B];
-        last[v] = p;
+        last[v] = (int32_t)p;
     }
     int64_t uniq = 0;
     for (int64_t p = 0; p < 2 * B; ++p) {
@@ -138,7 +136,7 @@ int64_t zo_store_messages(const float *memory, const float *last_update,
         msg_ts[v] = tf;
         flags[v] = 1;
     }
-    free(last);
+    for (int64_t p = 0; p < 2 * B; ++p) last[p < B ? src[p] : dst[p - B]] = -1;
     return uniq;
 }
 

@@ -1,0 +1,100 @@
+"""world_size-2 gloo tests of the multi-GPU exchange logic (zebra_amd.distributed)
+on CPU tensors: sharding arithmetic and the fixed-size all-gather of touched
+rows.  The GPU kernels are not involved (no GPU in the build container)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from zebra_amd.distributed import exchange_touched_rows, pack_rows, shard_capacity, shard_range, unpack_rows
+
+
+def test_shard_ranges_partition_everything():
+    for n in (0, 1, 7, 600, 8192, 12288):
+        for world in (1, 2, 3, 4, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+            assert shard_capacity(n, world) >= (n + world - 1) // world - 0
+
+
+def test_pack_unpack_roundtrip_single_process():
+    N, D, W = 50, 6, 9
+    rng = np.random.RandomState(0)
+    mem = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32))
+    lu = torch.from_numpy(rng.standard_normal(N).astype(np.float32))
+    msg = torch.from_numpy(rng.standard_normal((N, W)).astype(np.float32))
+    ids = torch.tensor([7, 3, 41, 0, 0, 0], dtype=torch.int32)
+    buf = pack_rows([mem, lu, msg], ids, torch.tensor([3], dtype=torch.int32), cap=6)
+    assert buf.shape == (6, 1 + D + 1 + W)
+    got = buf[:, 0].contiguous().view(torch.int32).tolist()
+    assert got == [7, 3, 41, -1, -1, -1]
+    mem2, lu2, msg2 = torch.zeros_like(mem), torch.zeros_like(lu), torch.zeros_like(msg)
+    assert unpack_rows([mem2, lu2, msg2], buf) == 3
+    for v in (7, 3, 41):
+        assert torch.equal(mem2[v], mem[v]) and lu2[v] == lu[v] and torch.equal(msg2[v], msg[v])
+    assert mem2[0].abs().sum() == 0      # padding entries were not written
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, D, W, B = 200, 8, 11, 32
+        rng = np.random.RandomState(5)                       # same on every rank: replicated tables
+        mem = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32))
+        lu = torch.zeros(N)
+        msg = torch.zeros((N, W))
+        # "batch": 2B endpoint positions; winner of a node = its last position
+        ends = torch.from_numpy(rng.randint(1, N, 2 * B).astype(np.int64))
+        last = {int(v): p for p, v in enumerate(ends.tolist())}
+        lo, hi = shard_range(2 * B, rank, world)
+        mine = sorted(v for v, p in last.items() if lo <= p < hi)
+        cap = shard_capacity(2 * B, world)
+        assert len(mine) <= cap
+        # local "update" of my winners (a deterministic function of the id)
+        for v in mine:
+            mem[v] = torch.full((D,), float(v))
+            lu[v] = v + 0.5
+            msg[v] = torch.arange(W, dtype=torch.float32) + v
+        ids = torch.zeros(cap, dtype=torch.int32)
+        ids[: len(mine)] = torch.tensor(mine, dtype=torch.int32)
+        n = exchange_touched_rows([mem, lu, msg], ids, torch.tensor([len(mine)], dtype=torch.int32), cap)
+        assert n == len(last)
+        # every replica must now hold every winner's row
+        for v in last:
+            assert torch.equal(mem[v], torch.full((D,), float(v)))
+            assert lu[v] == v + 0.5
+            assert torch.equal(msg[v], torch.arange(W, dtype=torch.float32) + v)
+        # replicas are identical
+        digest = torch.cat([mem.reshape(-1), lu, msg.reshape(-1)])
+        gathered = [torch.empty_like(digest) for _ in range(world)]
+        dist.all_gather(gathered, digest)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_exchange_touched_rows_gloo(world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert sorted(out.keys()) == list(range(world))

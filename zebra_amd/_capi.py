@@ -6,6 +6,13 @@ import raises, and every op raises on a non-zero status.
 import ctypes as C
 import os
 
+# torch first: it bundles its own ROCm runtime (libamdhip64); loading
+# libzebra_amd.so afterwards makes both share that one HIP runtime instance, so
+# torch device pointers and streams are valid inside the library.  Loaded the
+# other way round the process ends up with two runtimes and hipMalloc fails
+# with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libzebra_amd.so")
 
@@ -14,12 +21,12 @@ ZT_ERR_ARG, ZT_ERR_RANGE, ZT_ERR_HIP, ZT_ERR_UNSUPPORTED, ZT_ERR_TIMEOUT = -1, -
 
 # every symbol include/zebra_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "zt_last_error", "zt_version",
+    "zt_last_error", "zt_version", "zt_profile_enable", "zt_profile_reset", "zt_profile_read",
     "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_status",
     "zt_tppr_export", "zt_tppr_import",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
     "zt_embed_workspace_bytes", "zt_embed",
-    "zt_store_messages", "zt_gru_workspace_bytes", "zt_gru_update",
+    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update",
 ]
 
 

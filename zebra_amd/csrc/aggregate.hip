@@ -354,10 +354,12 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     float *fc1st = reinterpret_cast<float *>(ws + p.off_fc1st);
     float *fc2st = reinterpret_cast<float *>(ws + p.off_fc2st);
     const int K1 = D + F + T;
+    ZT_PROF_BEGIN(s, P_EMBED_PREP);
     k_pad_matrix<<<(p.Dp * p.K1p + 255) / 256, 256, 0, s>>>(wt->fc1_w, D, K1, W1p, p.Dp, p.K1p);
     k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2_w, D, D, fc2t);
     k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc1s_w, D, D, fc1st);
     k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2s_w, D, D, fc2st);
+    ZT_PROF_END(s, P_EMBED_PREP);
     static size_t attr_lds = 0;
     if (p.lds > 48 * 1024 && p.lds > attr_lds) {
         ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc1_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -365,13 +367,17 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         attr_lds = p.lds;
     }
     dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
+    ZT_PROF_BEGIN(s, P_FC1_AGG);
     k_fc1_agg<<<grid, AGG_THREADS, p.lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N, k,
                                                p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
                                                wt->fc1_b, H, S, status_dev);
+    ZT_PROF_END(s, P_FC1_AGG);
+    ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const size_t lds2 = (size_t)2 * OUT_ROWS * D * 4;
     k_embed_out<<<(unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), 256, lds2, s>>>(
         memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
         out_dev, status_dev);
+    ZT_PROF_END(s, P_EMBED_OUT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -12,6 +12,17 @@ namespace zt {
 
 void set_error(const char *fmt, ...);
 
+// Optional HIP-event timing of individual kernels (zt_profile_* in the ABI):
+// an event pair is recorded on the launch stream around the kernel; elapsed
+// times are summed per kernel name when the profile is read.
+enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_AGG, P_EMBED_OUT, P_STORE_MSG, P_GRU,
+              P_COUNT };
+extern bool g_prof_on;
+void prof_begin(hipStream_t s, int id);
+void prof_end(hipStream_t s, int id);
+#define ZT_PROF_BEGIN(s, id) do { if (zt::g_prof_on) zt::prof_begin((s), (id)); } while (0)
+#define ZT_PROF_END(s, id) do { if (zt::g_prof_on) zt::prof_end((s), (id)); } while (0)
+
 #define ZT_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t e__ = (expr);                                                              \

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_build_messages(
     const float *__restrict__ time_w, long long num_nodes, long long num_edges, int D, int F, int T,
     const int *__restrict__ src, const int *__restrict__ dst, const double *__restrict__ ts,
     const long long *__restrict__ eidx, long long B, float *messages, float *msg_ts, unsigned char *flags,
-    int *scratch, int *uniq_ids, int *n_uniq, const int *status)
+    int *scratch, int *uniq_ids, int *n_uniq, const int *status, long long pos_lo, long long pos_hi)
 {
     const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_build_messages(
     const int v = p < B ? src[i] : dst[i];
     if (v < 0 || v >= num_nodes) return;
     if (scratch[v] != (int)p) return;                        // not the last occurrence (or already reset)
-    if (!rejected) {
+    if (!rejected && p >= pos_lo && p < pos_hi) {
         const int partner = p < B ? dst[i] : src[i];
         const float tf = (float)ts[i];                       // edge_times .float() (tgn_model.py:213)
         const float delta = tf - last_update[v];             // :221
@@ -245,12 +245,30 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
 
 }  // namespace
 
+extern "C" int zt_store_messages_range(const float *, const float *, const float *, const float *, int64_t, int64_t, int32_t,
+                                       int32_t, int32_t, const int32_t *, const int32_t *, const double *,
+                                       const int64_t *, int64_t, int64_t, int64_t, float *, float *, uint8_t *,
+                                       int32_t *, int32_t *, int32_t *, int32_t *, void *);
+
 extern "C" int zt_store_messages(const float *memory_dev, const float *last_update_dev, const float *efeat_dev,
                                  const float *time_w_dev, int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F,
                                  int32_t T, const int32_t *src_dev, const int32_t *dst_dev, const double *ts_dev,
                                  const int64_t *eidx_dev, int64_t B, float *messages_dev, float *msg_ts_dev,
                                  uint8_t *flags_dev, int32_t *scratch_dev, int32_t *uniq_ids_dev, int32_t *n_uniq_dev,
                                  int32_t *status_dev, void *stream)
+{
+    return zt_store_messages_range(memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T,
+                                   src_dev, dst_dev, ts_dev, eidx_dev, B, 0, 2 * B, messages_dev, msg_ts_dev, flags_dev,
+                                   scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, stream);
+}
+
+extern "C" int zt_store_messages_range(const float *memory_dev, const float *last_update_dev, const float *efeat_dev,
+                                       const float *time_w_dev, int64_t num_nodes, int64_t num_edges, int32_t D,
+                                       int32_t F, int32_t T, const int32_t *src_dev, const int32_t *dst_dev,
+                                       const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
+                                       int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev,
+                                       int32_t *scratch_dev, int32_t *uniq_ids_dev, int32_t *n_uniq_dev,
+                                       int32_t *status_dev, void *stream)
 {
     if (B < 0 || D <= 0 || F < 0 || T < 0 || !status_dev) { set_error("zt_store_messages: bad argument"); return ZT_ERR_ARG; }
     if (B == 0) return ZT_OK;
@@ -262,11 +280,13 @@ extern "C" int zt_store_messages(const float *memory_dev, const float *last_upda
     hipStream_t s = (hipStream_t)stream;
     if (n_uniq_dev) ZT_HIP(hipMemsetAsync(n_uniq_dev, 0, sizeof(int), s));
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
+    ZT_PROF_BEGIN(s, P_STORE_MSG);
     k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
                                                                scratch_dev, status_dev);
     k_build_messages<<<(unsigned)((2 * B + 3) / 4), 256, 0, s>>>(
         memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
-        B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev);
+        B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi);
+    ZT_PROF_END(s, P_STORE_MSG);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }
@@ -302,6 +322,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     float *wih = reinterpret_cast<float *>(ws + p.off_wih);
     float *whh = reinterpret_cast<float *>(ws + p.off_whh);
     ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    ZT_PROF_BEGIN(s, P_GRU);
     k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
                                                                       rows, cnt);
     k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
@@ -315,6 +336,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
     k_gru<<<grid, 256, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh);
+    ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -392,9 +392,11 @@ extern "C" int zt_pruned_topk(const zt_csr *c, const int32_t *q_nodes_dev, const
         attr_lds = lds;
     }
     const int grid = (int)((nq + PR_WAVES - 1) / PR_WAVES);
+    ZT_PROF_BEGIN((hipStream_t)stream, P_PRUNE);
     k_pruned_topk<<<grid, WAVE * PR_WAVES, lds, (hipStream_t)stream>>>(
         c->indptr, c->nbr, c->eid, c->ts, c->N, q_nodes_dev, q_ts_dev, nq, width, depth, alpha, beta, k,
         out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, status_dev, cap_c, cap_f);
+    ZT_PROF_END((hipStream_t)stream, P_PRUNE);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -36,9 +36,82 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ---- kernel timing with HIP events ----------------------------------------------
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int id; bool open; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+double g_prof_ms[P_COUNT];
+long long g_prof_n[P_COUNT];
+const char *const g_prof_names[P_COUNT] = {"tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk",
+                                           "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update"};
+hipEvent_t prof_event()
+{
+    hipEvent_t e;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+void prof_begin(hipStream_t s, int id)
+{
+    ProfRec r{prof_event(), prof_event(), id, true};
+    if (!r.a || !r.b) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof_recs.push_back(r);
+}
+void prof_end(hipStream_t s, int id)
+{
+    for (size_t i = g_prof_recs.size(); i-- > 0;)
+        if (g_prof_recs[i].id == id && g_prof_recs[i].open) {
+            (void)hipEventRecord(g_prof_recs[i].b, s);
+            g_prof_recs[i].open = false;
+            return;
+        }
+}
+
 }  // namespace zt
 
 using namespace zt;
+
+extern "C" int zt_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    return ZT_OK;
+}
+
+extern "C" int zt_profile_reset(void)
+{
+    (void)hipDeviceSynchronize();
+    for (auto &r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+    g_prof_recs.clear();
+    for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
+    return ZT_OK;
+}
+
+extern "C" int zt_profile_read(const char *name, int64_t *count, double *total_ms)
+{
+    if (!name) return ZT_ERR_ARG;
+    ZT_HIP(hipDeviceSynchronize());
+    for (auto &r : g_prof_recs) {
+        if (!r.open) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { g_prof_ms[r.id] += ms; g_prof_n[r.id] += 1; }
+        }
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    for (int i = 0; i < P_COUNT; ++i)
+        if (strcmp(name, g_prof_names[i]) == 0) {
+            if (count) *count = g_prof_n[i];
+            if (total_ms) *total_ms = g_prof_ms[i];
+            return ZT_OK;
+        }
+    set_error("zt_profile_read: unknown kernel name %s", name);
+    return ZT_ERR_ARG;
+}
 
 extern "C" const char *zt_last_error(void) { return g_err; }
 extern "C" const char *zt_version(void) { return "zebra_amd 0.1 gfx950"; }
@@ -507,6 +580,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
             fflush(stderr);                                                                  \
         }                                                                                    \
     } while (0)
+    ZT_PROF_BEGIN(s, P_PREPASS);
     k_count<<<gb, tb, 0, s>>>(nodes_dev, e64, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
     ZT_DBG("k_count");
     k_reserve<<<gb, tb, 0, s>>>(nodes_dev, A, h->cnt, h->off, h->slot, h->ctl);
@@ -515,6 +589,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
     ZT_DBG("k_fill");
     k_prev<<<gb, tb, 0, s>>>(nodes_dev, A, B, h->cnt, h->off, h->slot, h->list, h->prev);
     ZT_DBG("k_prev");
+    ZT_PROF_END(s, P_PREPASS);
     const int m_lo = model < 0 ? 0 : model;
     const int n_models = model < 0 ? h->M : 1;
     const long long total = B * n_models;
@@ -522,10 +597,14 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
     const long long max_waves = (long long)h->n_cu * WAVES_PER_WG * 2;
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    ZT_PROF_BEGIN(s, P_STREAM);
     k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, nodes_dev, ts_dev, e64, B, n_roles, emit, m_lo, n_models,
                                                   out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, h->epoch);
+    ZT_PROF_END(s, P_STREAM);
     ZT_DBG("k_stream");
+    ZT_PROF_BEGIN(s, P_CLEANUP);
     k_cleanup<<<gb, tb, 0, s>>>(nodes_dev, A, h->slot, h->cnt, h->ctl);
+    ZT_PROF_END(s, P_CLEANUP);
     ZT_DBG("k_cleanup");
     ZT_LAUNCH_CHECK();
     return ZT_OK;

@@ -1,0 +1,107 @@
+"""One-node multi-GPU execution of the eval-mode step.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+The reference has no distributed code at all; this is new work:
+
+  * T-PPR state, node memory, pending messages and the edge-feature table are
+    replicated (C5: ~26 GB of 288 GB per GPU);
+  * P1 (T-PPR update + row emission) is applied to the WHOLE batch on every
+    rank: the stream is sequential by construction, so replicas stay
+    bit-identical with zero communication;
+  * P2 (gather + aggregate) is sharded over contiguous slices of the 3B rows;
+  * P3 (last-message store + GRU update) is sharded by batch POSITION: the
+    last occurrence of every endpoint is resolved over the whole batch, rank r
+    owns the winners at positions [2B*r/W, 2B*(r+1)/W) -- at most one winner
+    per position, so a rank touches at most ceil(2B/W) rows -- and the touched
+    rows [id | memory | last_update | message | msg timestamp] are exchanged
+    with ONE fixed-size all-gather per batch; every replica scatters them.
+
+``exchange_touched_rows`` is pure torch (works on CPU tensors with gloo), so
+the exchange logic is covered by world_size-2 CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) slice of n items owned by ``rank``."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def shard_capacity(n, world):
+    return max(shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world))
+
+
+def pack_rows(tables, ids, n_valid, cap):
+    """[cap, 1 + sum(widths)] float32 send buffer: id (int32 bits) then each
+    table's row.  ids: int32[>=cap]; entries at and beyond n_valid are padding
+    and are sent with id = -1."""
+    dev = ids.device
+    ids = ids[:cap].to(torch.int64)
+    valid = torch.arange(cap, device=dev) < n_valid.to(dev).reshape(())
+    safe = torch.where(valid, ids, torch.zeros_like(ids))
+    cols = [torch.where(valid, ids, torch.full_like(ids, -1)).to(torch.int32).view(torch.float32).reshape(cap, 1)]
+    for t in tables:
+        rows = t.index_select(0, safe)
+        cols.append(rows.reshape(cap, -1).to(torch.float32))
+    return torch.cat(cols, dim=1).contiguous()
+
+
+def unpack_rows(tables, recv):
+    """Scatter every valid received row (id >= 0) into the local tables."""
+    ids = recv[:, 0].contiguous().view(torch.int32).to(torch.int64)
+    sel = torch.nonzero(ids >= 0, as_tuple=False).reshape(-1)      # one host sync
+    if sel.numel() == 0:
+        return 0
+    idx = ids.index_select(0, sel)
+    col = 1
+    for t in tables:
+        w = t[0].numel() if t.dim() > 1 else 1
+        rows = recv[:, col:col + w].index_select(0, sel)
+        if t.dim() == 1:
+            t.index_copy_(0, idx, rows.reshape(-1).to(t.dtype))
+        else:
+            t.index_copy_(0, idx, rows.reshape(-1, *t.shape[1:]).to(t.dtype))
+        col += w
+    return int(sel.numel())
+
+
+def exchange_touched_rows(tables, ids, n_valid, cap, group=None):
+    """All-gather the rows ``ids[:n_valid]`` of every table in ``tables`` from
+    all ranks and write them into the local copies.  Fixed-size payload
+    (cap rows per rank), one collective."""
+    world = dist.get_world_size(group)
+    send = pack_rows(tables, ids, n_valid, cap)
+    recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return unpack_rows(tables, recv)
+
+
+class ShardedTGN:
+    """Eval-mode step of a replicated TGN with sharded aggregation / memory update."""
+
+    def __init__(self, tgn, rank, world, group=None):
+        self.tgn, self.rank, self.world, self.group = tgn, rank, world, group
+
+    @torch.no_grad()
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False):
+        tgn = self.tgn
+        em = tgn.embedding_module
+        if not tgn.test_mode:
+            tgn.update_memory_in_test(tgn.memory)
+            tgn.test_mode = True
+        B = src_d.numel()
+        nodes_d = torch.cat([src_d, dst_d, neg_d])
+        ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
+        on, oe, od, ow = em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status)     # replicated
+        r0, r1 = shard_range(3 * B, self.rank, self.world)
+        emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
+                              oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),
+                              check_status=check_status)
+        p0, p1 = shard_range(2 * B, self.rank, self.world)
+        tgn.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=(p0, p1))
+        tgn.memory_updater.update_device(tgn.memory, tgn._uniq, p1 - p0, tgn._n_uniq)
+        m = tgn.memory
+        exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], tgn._uniq, tgn._n_uniq,
+                              shard_capacity(2 * B, self.world), self.group)
+        return emb

@@ -82,18 +82,21 @@ class TGN(torch.nn.Module):
         self.embedding_module.t_tppr = 0
 
     # ------------------------------------------------------------------ device protocol
-    def store_messages_device(self, src_d, dst_d, ts_d, eidx_d):
+    def store_messages_device(self, src_d, dst_d, ts_d, eidx_d, pos_range=None):
         """get_raw_messages + store_raw_messages (tgn_model.py:204-226) on the device.
-        Leaves the unique endpoint ids in self._uniq[: self._n_uniq]."""
+        Leaves the unique endpoint ids in self._uniq[: self._n_uniq].  ``pos_range``
+        = (lo, hi) restricts the work to winners at batch positions lo..hi-1."""
         B = src_d.numel()
+        lo, hi = pos_range if pos_range is not None else (0, 2 * B)
         if self._uniq is None or self._uniq.numel() < 2 * B:
             self._uniq = torch.empty(2 * B, dtype=torch.int32, device=self.device)
         m = self.memory
-        check(lib().zt_store_messages(ptr(m.memory), ptr(m.last_update), ptr(self.edge_raw_features),
+        check(lib().zt_store_messages_range(ptr(m.memory), ptr(m.last_update), ptr(self.edge_raw_features),
                                       ptr(self.time_encoder.w.weight), C.c_int64(m.n_nodes),
                                       C.c_int64(self.edge_raw_features.shape[0]), C.c_int32(self.memory_dimension),
                                       C.c_int32(self.n_edge_features), C.c_int32(self.time_dimension), ptr(src_d),
-                                      ptr(dst_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B), ptr(m.messages),
+                                      ptr(dst_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B), C.c_int64(lo), C.c_int64(hi),
+                                      ptr(m.messages),
                                       ptr(m.timestamps), ptr(m._flag_buf), ptr(self._scratch), ptr(self._uniq),
                                       ptr(self._n_uniq), ptr(self._status), stream_ptr()), "zt_store_messages")
         return B

@@ -85,7 +85,7 @@ class tppr_finder:
         self.beta_list = [float(b) for b in beta_list]
         self.reference_compat_aliasing = bool(reference_compat_aliasing)
         self._dev = _dev()
-        self._val = self._new_state()        # reset_val_tppr (:399)
+        self._val = None                     # reset_val_tppr (:399): empty; allocated on first use
         self._live = self._new_state()       # reset_tppr (:400)
 
     # ------------------------------------------------------------ state mgmt
@@ -93,7 +93,12 @@ class tppr_finder:
         return _TpprState(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list)
 
     def reset_val_tppr(self):                # utils/util.py:402-417
-        self._val = self._new_state()
+        self._val = None
+
+    def _val_state(self):
+        if self._val is None:
+            self._val = self._new_state()
+        return self._val
 
     def reset_tppr(self):                    # utils/util.py:419-434
         if self.reference_compat_aliasing:
@@ -108,7 +113,7 @@ class tppr_finder:
         self._live = backup if self.reference_compat_aliasing else backup.clone()
 
     def restore_val_tppr(self):              # utils/util.py:442-444
-        self._live = self._val if self.reference_compat_aliasing else self._val.clone()
+        self._live = self._val_state() if self.reference_compat_aliasing else self._val_state().clone()
 
     # reference attributes, materialised on demand from the device state
     @property
@@ -121,11 +126,11 @@ class tppr_finder:
 
     @property
     def val_norm_list(self):
-        return [self._val.export(m)["norm"] for m in range(self.n_tppr)]
+        return [self._val_state().export(m)["norm"] for m in range(self.n_tppr)]
 
     @property
     def val_PPR_list(self):
-        return [self._dicts(self._val, m) for m in range(self.n_tppr)]
+        return [self._dicts(self._val_state(), m) for m in range(self.n_tppr)]
 
     @staticmethod
     def _dicts(state, m):
