@@ -236,6 +236,17 @@ int zt_gru_update(float *memory_dev, float *last_update_dev,
                   const int32_t *n_ids_dev, const zt_gru_weights *weights,
                   void *workspace_dev, void *stream);
 
+/* ------------------------------------------------------------------------ */
+/* Test hook (not product API): the exact top-k selection primitive on its    */
+/* own.  vals [cases][n] float64; writes np.argsort(vals[c])[-k:] under       */
+/* numba's quicksort semantics into sel_out [cases][k] and the path taken     */
+/* (0 fast rank, 1 wave-parallel exact, 2 sequential exact) into path_out.    */
+/* mode: 0 = production dispatch, 1 = force wave-parallel, 2 = force sequential */
+/* ------------------------------------------------------------------------ */
+int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases,
+                 int32_t mode, int32_t *sel_out_dev, int32_t *path_out_dev,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,3 +195,47 @@ def test_pruning_vs_oracle_superuser_shape(zt, oracle):
     with pytest.raises(ValueError):
         nf.get_pruned_topk(q[:4], qt[:4], 20, 3, 0.1, 0.5, 20, *[np.zeros((4, 20), dt) for dt in
                                                                  (np.int32, np.int32, np.float32, np.float32)])
+
+
+@pytest.mark.parametrize("n,k", [(16, 5), (17, 5), (31, 20), (41, 20), (41, 40), (64, 20), (65, 31), (81, 40),
+                                 (100, 50), (127, 63), (128, 20)])
+def test_exact_topk_selection_paths(zt, oracle, n, k):
+    """The top-k prune must reproduce np.argsort(values)[-k:] under numba's
+    quicksort for any tie pattern.  Every path (rank fast path, wave-parallel
+    quicksort replay, sequential replay) is driven on its own with tie-heavy
+    inputs and compared with the oracle's restatement."""
+    import ctypes as C
+    import torch
+    from zebra_amd import _capi
+    rng = np.random.RandomState(n * 100 + k)
+    cases = 600
+    vals = np.empty((cases, n), np.float64)
+    for c in range(cases):
+        kind = c % 6
+        if kind == 0:
+            vals[c] = rng.random_sample(n)                                  # all distinct
+        elif kind == 1:
+            vals[c] = rng.randint(0, 3, n)                                  # massive ties
+        elif kind == 2:
+            vals[c] = rng.randint(0, max(2, n // 3), n) * 0.125             # some ties
+        elif kind == 3:
+            vals[c] = np.sort(rng.randint(0, 6, n))[::(-1 if c % 2 else 1)]  # sorted / reversed with ties
+        elif kind == 4:
+            vals[c] = 0.5 ** rng.randint(1, 8, n)                           # powers of beta=0.5, like the weights
+        else:
+            vals[c] = 1.0                                                   # all equal
+    want = np.stack([oracle.numba_argsort(v)[-k:] for v in vals])
+    dv = torch.from_numpy(vals).cuda()
+    for mode in (0, 1, 2):
+        sel = torch.full((cases, k), -1, dtype=torch.int32, device="cuda")
+        path = torch.full((cases,), -1, dtype=torch.int32, device="cuda")
+        _capi.check(_capi.lib().zt_test_topk(_capi.ptr(dv), C.c_int32(n), C.c_int32(k), C.c_int32(cases),
+                                             C.c_int32(mode), _capi.ptr(sel), _capi.ptr(path), _capi.stream_ptr()))
+        got = sel.cpu().numpy()
+        bad = np.where((got != want).any(axis=1))[0]
+        assert len(bad) == 0, "mode %d: %d/%d cases differ, first %d: %s vs %s" % (
+            mode, len(bad), cases, bad[0] if len(bad) else -1, got[bad[0]] if len(bad) else None,
+            want[bad[0]] if len(bad) else None)
+        if mode == 0:
+            p = path.cpu().numpy()
+            assert (p == 0).any() and (p == 1).any()        # both production paths were exercised

@@ -1,0 +1,61 @@
+// Test hooks: direct access to device primitives whose rare paths need their
+// own tests (exact top-k selection under ties).  Not part of the product API.
+#include "numba_sort.hpp"
+
+using namespace zt;
+
+namespace {
+
+struct HookLds {
+    double a[1536];
+    int sel[64];
+    int perm[1536];
+    int stk[96];
+    SortLds sort;
+};
+
+// one wavefront per case; mode 0 = production dispatch (fast / wave / seq),
+// 1 = force the wave-parallel exact sort, 2 = force the sequential replay
+__global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ vals, int n, int k, int cases, int mode,
+                                                  int *sel_out, int *path_out)
+{
+    __shared__ HookLds L;
+    const int c = blockIdx.x;
+    if (c >= cases) return;
+    const int lane = lane_id();
+    for (int q = lane; q < n; q += WAVE) L.a[q] = vals[(size_t)c * n + q];
+    wave_sync();
+    int path;
+    if (mode == 0) {
+        path = topk_select_wave(L.a, n, k, L.sel, L.sort, L.perm, L.stk);
+    } else if (mode == 1) {
+        numba_argsort_wave(L.a, n, L.sort);
+        if (lane < k) L.sel[lane] = L.sort.r2[n - k + lane];
+        wave_sync();
+        path = 1;
+    } else {
+        if (lane == 0) {
+            numba_argsort_seq(L.a, n, L.perm, L.stk);
+            for (int q = 0; q < k; ++q) L.sel[q] = L.perm[n - k + q];
+        }
+        wave_sync();
+        path = 2;
+    }
+    if (lane < k) sel_out[(size_t)c * k + lane] = L.sel[lane];
+    if (lane == 0) path_out[c] = path;
+}
+
+}  // namespace
+
+extern "C" int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases, int32_t mode,
+                            int32_t *sel_out_dev, int32_t *path_out_dev, void *stream)
+{
+    if (!vals_dev || !sel_out_dev || !path_out_dev || n < 2 || k < 1 || k >= n || k > 64 || cases < 1 || n > 1536 ||
+        (mode == 1 && n > 128)) {
+        set_error("zt_test_topk: bad argument");
+        return ZT_ERR_ARG;
+    }
+    k_test_topk<<<cases, 64, 0, (hipStream_t)stream>>>(vals_dev, n, k, cases, mode, sel_out_dev, path_out_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}

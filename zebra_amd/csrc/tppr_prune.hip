@@ -43,6 +43,7 @@ struct PruneLds {
     int *stk;       // 96
     int *f_cnt;     // per frontier entry: number of states it emits
     int *f_off;
+    SortLds *sort;  // wave-parallel exact argsort scratch (n <= 128)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -50,7 +51,7 @@ __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t
 __host__ __device__ inline size_t prune_lds_bytes(int cap_c, int cap_f)
 {
     return 3 * align16((size_t)cap_c * 8) + align16((size_t)cap_c * 4) + align16(64 * 4) + align16(96 * 4) +
-           2 * align16((size_t)cap_f * 4);
+           2 * align16((size_t)cap_f * 4) + align16(sizeof(SortLds));
 }
 
 __device__ inline PruneLds carve(char *base, int cap_c, int cap_f)
@@ -64,7 +65,8 @@ __device__ inline PruneLds carve(char *base, int cap_c, int cap_f)
     L.sel = reinterpret_cast<int *>(p); p += align16(64 * 4);
     L.stk = reinterpret_cast<int *>(p); p += align16(96 * 4);
     L.f_cnt = reinterpret_cast<int *>(p); p += align16((size_t)cap_f * 4);
-    L.f_off = reinterpret_cast<int *>(p);
+    L.f_off = reinterpret_cast<int *>(p); p += align16((size_t)cap_f * 4);
+    L.sort = reinterpret_cast<SortLds *>(p);
     return L;
 }
 
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
         }
         return;
     }
-    topk_select_wave(L.w, nd, k, L.sel, L.perm, L.stk);
+    topk_select_wave(L.w, nd, k, L.sel, *L.sort, L.perm, L.stk);
     if (lane < k) {
         const int c = L.sel[lane];
         out_nodes[ob + lane] = (int)(unsigned)(L.key[c] & 0xffffffffull);

@@ -153,9 +153,8 @@ struct WaveLds {
     u64 key[CAP];
     double ts[CAP];
     double w[CAP];
-    int perm[CAP];
     int sel[64];
-    int stk[96];
+    SortLds sort;
 };
 
 // ---------------------------------------------------------------- prepass ----
@@ -324,7 +323,7 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         wave_sync();
         return n;
     }
-    topk_select_wave(L.w, n, k, L.sel, L.perm, L.stk);   // :553-559
+    topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);   // :553-559
     if (lane < k) {
         const int c = L.sel[lane];
         ok = L.key[c]; ot = L.ts[c]; ow = L.w[c];
