@@ -5,18 +5,30 @@
 // and add separately (utils/util.py:523-541) and results must be bit-exact.
 //
 // Design (DESIGN.md "P1"):
-//   * state is device resident, SoA [model][node][k]: key = (edge_idx << 32 |
-//     node) u64, timestamp f64, weight f64, plus len i32 and norm f64 per row;
-//   * the edges of a batch must be applied in order, each reading the rows the
-//     previous edges wrote.  A 4-kernel prepass groups the batch's 3B node
-//     accesses by node (atomic count / reserve / fill) and gives every access
-//     the index of the latest EARLIER edge touching the same node;
-//   * the update kernel is persistent: one wavefront per (edge, model) task,
-//     tasks dequeued in order from an atomic head (so a task only ever waits
-//     on tasks that are already resident -> no deadlock), each wave spins on
-//     the done-flags of its <= 3 predecessor edges, merges in LDS, prunes with
-//     the exact numba argsort semantics and publishes its rows write-through
-//     (sc1) followed by its own done-flag (Guideline 16 recipe R1).
+//   * State is device resident.  A node's dictionary (one per model) is a ROW
+//     of 8-byte GRANULES {tag:32 | payload:32}: header (len, norm) and, per
+//     entry, key = (edge_idx, node), timestamp, weight split into 32-bit
+//     halves, stored as six entry-major arrays so that lane j owns entry j.
+//     Every granule of a row carries the tag (launch epoch, writer ordinal) of
+//     the edge that wrote it: a row is self-validating, and "the data is the
+//     flag" (cdna_hip_programming.md Guideline 16, recipe R2): a dependent edge
+//     re-reads the row until all tags match -- ONE memory round trip per hop of
+//     a hub chain, no release fence, no acquire, no separate flag.
+//   * The edges of a batch must be applied in order, each reading the rows the
+//     previous edges wrote.  A prepass groups the batch's node accesses by node
+//     (atomic count / reserve / fill) and gives every access (a) the ordinal of
+//     the last earlier WRITER of its node = the tag to expect, and (b) if its
+//     immediate predecessor on that node was only a reader (a negative
+//     sample), that edge's index: writers must not overwrite a row such a
+//     reader has not read yet, which is what the per-edge "reads done" flag is
+//     for.
+//   * The update kernel is persistent: one wavefront per (edge, model) task,
+//     tasks dequeued in order from an atomic head (a task only ever waits on
+//     tasks that are already resident -> no deadlock); it loads its rows
+//     (polling tags where a predecessor exists, with a back-off proportional to
+//     the number of chain hops still ahead), publishes "reads done", merges in
+//     LDS, prunes with the exact numba argsort semantics, and stores the new
+//     rows as write-through (sc1) granules, fire and forget.
 #include "numba_sort.hpp"
 
 #include <cstdarg>
@@ -117,26 +129,29 @@ extern "C" const char *zt_last_error(void) { return g_err; }
 extern "C" const char *zt_version(void) { return "zebra_amd 0.1 gfx950"; }
 
 // ---- handle --------------------------------------------------------------------
+namespace {
+constexpr int HDR = 4;                 // header granules: len, norm lo, norm hi, pad
+constexpr int ORD_BITS = 14;           // writer ordinal inside one launch
+constexpr int MAX_CHUNK = 8192;        // edges per launch (ordinals must fit ORD_BITS)
+constexpr unsigned EPOCH_MAX = (1u << (32 - ORD_BITS)) - 1;
+}  // namespace
+
 struct zt_tppr {
     int64_t N;
     int32_t k, M;
+    int32_t rg;      // granules per row = HDR + 6k
     double alpha[16], beta[16];
-    // state (device)
-    int *len;      // [M][N]
-    double *norm;  // [M][N]
-    u64 *key;      // [M][N][k]
-    double *ts;    // [M][N][k]
-    double *w;     // [M][N][k]
+    u64 *rows;       // [M][N][rg] granules
     // per-node prepass scratch (device)
-    int *cnt;      // [N], zero between calls
-    int *off;      // [N]
-    // per-batch scratch (device), sized for cap_acc accesses
-    int64_t cap_acc;
-    int *slot;     // [cap_acc] position of the access inside its node group
-    int *list;     // [cap_acc] accesses grouped by node
-    int *prev;     // [cap_acc] latest earlier edge touching the same node, or -1
-    unsigned *done;  // [M][cap_acc/2 .. ] one flag per (model, edge)
-    int64_t cap_done;
+    int *cnt;        // [N], zero between calls
+    int *off;        // [N]
+    // per-launch scratch (device), sized for 3*MAX_CHUNK accesses
+    int *slot;       // position of the access inside its node group, -1 invalid, -2 shadow
+    int *list;       // accesses grouped by node
+    int *wo;         // ordinal of the last earlier writer of the access' node (0 = none in this launch)
+    int *pflag;      // edge whose "reads done" flag must be seen first, or -1
+    int *nxt;        // next edge of the launch touching the access' node (INT_MAX = none)
+    unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
     // control words (device): [0] cursor, [1] queue head, [2] status
     int *ctl;
     unsigned epoch;
@@ -157,18 +172,24 @@ struct WaveLds {
     SortLds sort;
 };
 
+__host__ __device__ inline u64 granule(unsigned tag, unsigned payload) { return ((u64)tag << 32) | payload; }
+
 // ---------------------------------------------------------------- prepass ----
+// One access = (role r, edge i) of the chunk; a = r*B + i.  Roles 0/1 (source,
+// destination) write their node's row, role 2 (negative) only reads it.  An
+// edge's second access to the same node (self-loop, negative == endpoint) is a
+// SHADOW: it is not entered into the node's group.
 // K1: validate ids; count accesses per node; remember each access' slot.
-__global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long B,
-                        int n_roles, long long N, int *cnt, int *slot, int *ctl)
+__global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
+                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl)
 {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long A = B * n_roles;
-    if (a >= A) return;
-    const int x = nodes[a];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= B * n_roles) return;
+    const int r = a / B, i = a % B;
+    const int x = nodes[(long long)r * role_stride + i];
     bool ok = x >= 0 && x < N;
-    if (a < B) {
-        const long long e = eidx[a];
+    if (r == 0) {
+        const long long e = eidx[i];
         ok = ok && e >= 0 && e <= 0x7fffffffll;
     }
     if (!ok) {
@@ -176,56 +197,73 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
         slot[a] = -1;
         return;
     }
+    bool shadow = false;
+    if (r >= 1) shadow = nodes[i] == x;                                    // same as the source
+    if (r == 2) shadow = shadow || nodes[role_stride + i] == x;           // same as the destination
+    if (shadow) { slot[a] = -2; return; }
     slot[a] = atomicAdd(&cnt[x], 1);
 }
 
 // K2: the first access of each node reserves a contiguous range of `list`.
-__global__ void k_reserve(const int *__restrict__ nodes, long long A, const int *cnt, int *off, const int *slot,
-                          int *ctl)
+__global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                          int *off, const int *slot, int *ctl)
 {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= B * n_roles) return;
     if (slot[a] == 0) {
-        const int x = nodes[a];
+        const int x = nodes[(long long)(a / B) * role_stride + a % B];
         off[x] = atomicAdd(&ctl[0], cnt[x]);
     }
 }
 
 // K3: scatter accesses into their node's range.
-__global__ void k_fill(const int *__restrict__ nodes, long long A, const int *off, const int *slot, int *list)
+__global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
+                       const int *slot, int *list)
 {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A) return;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= B * n_roles) return;
     const int s = slot[a];
     if (s < 0) return;
-    list[off[nodes[a]] + s] = (int)a;
+    list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = a;
 }
 
-// K4: prev[a] = largest edge index < edge(a) among the accesses of a's node.
-__global__ void k_prev(const int *__restrict__ nodes, long long A, long long B, const int *cnt, const int *off,
-                       const int *slot, const int *list, int *prev)
+// K4: per access, from its node's group:
+//   wo    = number of writer accesses by earlier edges  (= ordinal of the last earlier writer)
+//   pflag = the latest earlier edge touching the node, if that access was a reader, else -1
+//   nxt   = the next later edge touching the node (who waits for this access' result)
+__global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
 {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A) return;
-    if (slot[a] < 0) { prev[a] = -1; return; }
-    const int x = nodes[a];
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= B * n_roles) return;
+    if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0x7fffffff; return; }
+    const int x = nodes[(long long)(a / B) * role_stride + a % B];
     const int o = off[x], c = cnt[x];
-    const int me = (int)(a % B);
-    int best = -1;
+    const int me = a % B;
+    int best = -1, best_role = 0, writers = 0, nx = 0x7fffffff;
     for (int p = 0; p < c; ++p) {
-        const int e = list[o + p] % (int)B;
-        if (e < me && e > best) best = e;
+        const int b = list[o + p];
+        const int e = b % B, r = b / B;
+        if (e < me) {
+            writers += (r < 2) ? 1 : 0;
+            if (e > best) { best = e; best_role = r; }
+        } else if (e > me && e < nx) {
+            nx = e;
+        }
     }
-    prev[a] = best;
+    wo[a] = writers;
+    nxt[a] = nx;
+    pflag[a] = (best >= 0 && best_role == 2) ? best : -1;
 }
 
 // K5: restore the per-node counters and the control words for the next call.
-__global__ void k_cleanup(const int *__restrict__ nodes, long long A, const int *slot, int *cnt, int *ctl)
+__global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
+                          int *cnt, int *ctl)
 {
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a == 0) { ctl[0] = 0; ctl[1] = 0; }
-    if (a >= A) return;
-    if (slot[a] == 0) cnt[nodes[a]] = 0;
+    if (a >= B * n_roles) return;
+    if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
 }
 
 // ------------------------------------------------------------- row access ----
@@ -236,20 +274,46 @@ struct Row {
     double norm;
 };
 
-__device__ __forceinline__ Row load_row(const zt_tppr &h, int m, long long x, int lane)
+// Loads one row.  expect != 0: every granule must carry that tag; returns the
+// first mismatching tag seen (or `expect` when the row is complete).
+__device__ __forceinline__ unsigned load_row(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r)
 {
-    Row r;
-    const long long row = (long long)m * h.N + x;
-    r.len = ld_agent(h.len + row);
-    r.norm = ld_agent(h.norm + row);
-    r.key = 0; r.ts = 0.0; r.w = 0.0;
-    if (lane < h.k) {
-        const long long p = row * h.k + lane;
-        r.key = ld_agent(h.key + p);
-        r.ts = ld_agent(h.ts + p);
-        r.w = ld_agent(h.w + p);
+    const u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
+    const int k = h.k;
+    u64 g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, gh = 0;
+    if (lane < 3) gh = ld_agent(base + lane);
+    if (lane < k) {
+        const u64 *e = base + HDR + lane;
+        g0 = ld_agent(e);
+        g1 = ld_agent(e + k);
+        g2 = ld_agent(e + 2 * k);
+        g3 = ld_agent(e + 3 * k);
+        g4 = ld_agent(e + 4 * k);
+        g5 = ld_agent(e + 5 * k);
     }
-    return r;
+    const unsigned h0 = (unsigned)__shfl((unsigned)gh, 0), h1 = (unsigned)__shfl((unsigned)gh, 1),
+                   h2 = (unsigned)__shfl((unsigned)gh, 2);
+    r.len = (int)h0;
+    r.norm = __longlong_as_double((long long)(((u64)h2 << 32) | h1));
+    r.key = ((u64)(unsigned)g1 << 32) | (unsigned)g0;
+    r.ts = __longlong_as_double((long long)(((u64)(unsigned)g3 << 32) | (unsigned)g2));
+    r.w = __longlong_as_double((long long)(((u64)(unsigned)g5 << 32) | (unsigned)g4));
+    if (expect == 0) return 0;
+    unsigned bad = expect;
+    if (lane < 3 && (unsigned)(gh >> 32) != expect) bad = (unsigned)(gh >> 32);
+    if (lane < k) {
+        const unsigned t0 = (unsigned)(g0 >> 32), t1 = (unsigned)(g1 >> 32), t2 = (unsigned)(g2 >> 32),
+                       t3 = (unsigned)(g3 >> 32), t4 = (unsigned)(g4 >> 32), t5 = (unsigned)(g5 >> 32);
+        if (t0 != expect) bad = t0;
+        if (t1 != expect) bad = t1;
+        if (t2 != expect) bad = t2;
+        if (t3 != expect) bad = t3;
+        if (t4 != expect) bad = t4;
+        if (t5 != expect) bad = t5;
+    }
+    const u64 bm = __ballot(bad != expect);
+    if (bm == 0ull) return expect;
+    return (unsigned)__shfl(bad, __ffsll((long long)bm) - 1);
 }
 
 // extract_streaming_tppr (utils/util.py:447-469)
@@ -332,27 +396,83 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     return k;
 }
 
+// Write a whole row (all k entries, zeros beyond n) with one tag.
 __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, int lane, int n, u64 key, double ts,
-                                          double w, double new_norm)
+                                          double w, double new_norm, unsigned tag)
 {
-    const long long row = (long long)m * h.N + x;
-    if (lane < n) {
-        const long long p = row * h.k + lane;
-        st_agent(h.key + p, key);
-        st_agent(h.ts + p, ts);
-        st_agent(h.w + p, w);
+    u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
+    const int k = h.k;
+    if (lane < k) {
+        const bool a = lane < n;
+        const u64 kk = a ? key : 0ull;
+        const u64 tt = a ? (u64)__double_as_longlong(ts) : 0ull;
+        const u64 ww = a ? (u64)__double_as_longlong(w) : 0ull;
+        u64 *e = base + HDR + lane;
+        st_agent(e, granule(tag, (unsigned)kk));
+        st_agent(e + k, granule(tag, (unsigned)(kk >> 32)));
+        st_agent(e + 2 * k, granule(tag, (unsigned)tt));
+        st_agent(e + 3 * k, granule(tag, (unsigned)(tt >> 32)));
+        st_agent(e + 4 * k, granule(tag, (unsigned)ww));
+        st_agent(e + 5 * k, granule(tag, (unsigned)(ww >> 32)));
     }
-    if (lane == 0) {
-        st_agent(h.len + row, n);
-        st_agent(h.norm + row, new_norm);
+    if (lane < 3) {
+        const u64 nn = (u64)__double_as_longlong(new_norm);
+        const unsigned pay = lane == 0 ? (unsigned)n : (lane == 1 ? (unsigned)nn : (unsigned)(nn >> 32));
+        st_agent(base + lane, granule(tag, pay));
+    }
+}
+
+// Spin until flag == epoch (bounded).  Returns false on timeout.
+__device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, int *status)
+{
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (ld_agent(flag) != epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 1023u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > WAIT_TICKS) { atomicExch(status, ZT_ERR_TIMEOUT); return false; }
+        }
+    }
+    return true;
+}
+
+// Load a row that an earlier edge of this launch rewrites: poll until every
+// granule carries `expect`.  The mismatching tag tells how many chain hops are
+// still ahead, which sets the back-off.
+__device__ inline void load_row_wait(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r,
+                                     int *status)
+{
+    unsigned polls = 0;
+    long long t0 = 0;
+    for (;;) {
+        const unsigned seen = load_row(h, m, x, lane, expect, r);
+        if (seen == expect) return;
+        // hops still to go on this node's chain (tags of older launches count as ordinal 0)
+        const unsigned cur = (seen >> ORD_BITS) == (expect >> ORD_BITS) ? (seen & ((1u << ORD_BITS) - 1)) : 0u;
+        const unsigned want = expect & ((1u << ORD_BITS) - 1);
+        int ahead = (int)want - (int)cur - 1;               // 0: my predecessor is being written right now
+        if (ahead > 0) {
+            int naps = ahead > 64 ? 64 : ahead;             // ~1.5 us per hop ahead, capped
+            for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(56);
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if ((++polls & 255u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > WAIT_TICKS) { atomicExch(status, ZT_ERR_TIMEOUT); return; }
+        }
     }
 }
 
 // ------------------------------------------------------------ main kernel ----
 __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const int *__restrict__ nodes,
                                                                 const double *__restrict__ tsv,
-                                                                const long long *__restrict__ eidx, long long B,
-                                                                int n_roles, int emit, int m_lo, int n_models,
+                                                                const long long *__restrict__ eidx,
+                                                                long long role_stride, int B, int n_roles, int emit,
+                                                                int m_lo, int n_models, long long out_rows,
                                                                 int *out_nodes, int *out_eidx, float *out_dt,
                                                                 float *out_w, unsigned epoch)
 {
@@ -361,106 +481,94 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
     const int lane = lane_id();
     const int k = h.k;
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) return;   // rejected by k_count: touch nothing
-    const long long total = B * n_models;
-    const long long rows = B * n_roles;
+    const int total = B * n_models;
+    const unsigned tag_base = epoch << ORD_BITS;
     for (;;) {
         // Dequeue with NO divergent branch: every lane issues the add (lane 0
         // adds 1, the rest 0; the compiler folds it into one wave-level atomic).
-        // An `if (lane == 0)` here gets jump-threaded with the `if (lane == 0)`
-        // publish at the end of the previous iteration, and the structurizer
-        // then replays the body for the remaining lanes (seen in the ISA).
+        // An `if (lane == 0)` here gets jump-threaded with lane-0 code at the
+        // end of the previous iteration and the structurizer then replays the
+        // body for the remaining lanes (seen in the ISA).
         int idx = atomicAdd(h.ctl + 1, lane == 0 ? 1 : 0);
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= total) return;
-        const long long i = idx / n_models;
+        const int i = idx / n_models;
         const int mo = idx % n_models;          // emitted-model index
         const int m = m_lo + mo;
         const double alpha = h.alpha[m], beta = h.beta[m];
+        unsigned *done = h.done + (long long)m * MAX_CHUNK;
 
-        // ---- wait for the predecessors of this edge's nodes ----
-        if (lane < n_roles) {
-            const int p = h.prev[(long long)lane * B + i];
-            if (p >= 0) {
-                const unsigned *flag = h.done + (long long)m * h.cap_done + p;
-                unsigned spins = 0;
-                long long t0 = 0;
-                while (ld_agent(flag) != epoch) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if ((++spins & 1023u) == 0) {           // bounded: give up after WAIT_TICKS
-                        const long long now = (long long)wall_clock64();
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > WAIT_TICKS) { atomicExch(h.ctl + 2, ZT_ERR_TIMEOUT); break; }
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // ---- dependencies of this edge's three accesses ----
+        int my_wo = 0, my_pf = -1, my_nx = 0x7fffffff;
+        if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i]; }
+        if (my_pf >= 0) wait_flag(done + my_pf, epoch, h.ctl + 2);   // a reader before me has not read yet
+        const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
+        // the endpoint whose next toucher comes first is merged and published first
+        const bool v_first = __shfl(my_nx, 1) < __shfl(my_nx, 0);
 
-        const long long u = nodes[i], v = nodes[B + i];
+        const long long u = nodes[i], v = nodes[role_stride + i];
+        const long long g = n_roles == 3 ? nodes[2 * role_stride + i] : u;
         const double tnow = tsv[i];
         const long long e = eidx[i];
-        const Row ru = load_row(h, m, u, lane);
-        const Row rv = load_row(h, m, v, lane);
 
-        if (emit) {                             // utils/util.py:504-506
-            const long long ob = (long long)mo * rows * k;
-            emit_row(ru, k, lane, tnow, out_nodes + ob + i * k, out_eidx + ob + i * k, out_dt + ob + i * k,
-                     out_w + ob + i * k);
-            emit_row(rv, k, lane, tnow, out_nodes + ob + (B + i) * k, out_eidx + ob + (B + i) * k,
-                     out_dt + ob + (B + i) * k, out_w + ob + (B + i) * k);
-            if (n_roles == 3) {
-                const long long g = nodes[2 * B + i];
-                const Row rg = load_row(h, m, g, lane);
-                emit_row(rg, k, lane, tnow, out_nodes + ob + (2 * B + i) * k, out_eidx + ob + (2 * B + i) * k,
-                         out_dt + ob + (2 * B + i) * k, out_w + ob + (2 * B + i) * k);
+        // ---- rows: one memory round trip; poll where a writer of this launch precedes us ----
+        Row ru, rv, rg;
+        unsigned su = load_row(h, m, u, lane, wo_u ? (tag_base | (unsigned)wo_u) : 0u, ru);
+        unsigned sv = 0, sg = 0;
+        if (v != u) sv = load_row(h, m, v, lane, wo_v ? (tag_base | (unsigned)wo_v) : 0u, rv);
+        const bool g_own = n_roles == 3 && g != u && g != v;
+        if (g_own) sg = load_row(h, m, g, lane, wo_g ? (tag_base | (unsigned)wo_g) : 0u, rg);
+        if (wo_u && su != (tag_base | (unsigned)wo_u)) load_row_wait(h, m, u, lane, tag_base | (unsigned)wo_u, ru, h.ctl + 2);
+        if (v != u && wo_v && sv != (tag_base | (unsigned)wo_v))
+            load_row_wait(h, m, v, lane, tag_base | (unsigned)wo_v, rv, h.ctl + 2);
+        if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
+            load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2);
+        if (v == u) rv = ru;
+        if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
+
+        // ---- all reads done: later writers of these rows may go ahead ----
+        st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see above)
+
+        // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
+        // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
+        {
+            const bool sw = v_first && u != v;
+            const Row &r1 = sw ? rv : ru, &r2 = sw ? ru : rv;
+            const long long x1 = sw ? v : u, x2 = sw ? u : v;
+            const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
+            u64 nk = 0;
+            double nt = 0, nw = 0;
+            // (edge_idx, s2, ts) is the key entering s1's dictionary
+            int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
+                               nt, nw);
+            store_row(h, m, x1, lane, n, nk, nt, nw, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
+            if (u != v) {
+                n = merge_pair(L, lane, k, alpha, beta, r2, r1, ((u64)(unsigned)e << 32) | (u64)(unsigned)x1, tnow, nk,
+                               nt, nw);
+                store_row(h, m, x2, lane, n, nk, nt, nw, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
             }
         }
 
-        // ---- both directions from the OLD rows (utils/util.py:509-564) ----
-        const u64 key_uv = ((u64)(unsigned)e << 32) | (u64)(unsigned)v;   // (edge_idx, s2=v, ts) into u
-        const u64 key_vu = ((u64)(unsigned)e << 32) | (u64)(unsigned)u;
-        u64 ak = 0, bk = 0;
-        double at = 0, aw = 0, bt = 0, bw = 0;
-        const int na = merge_pair(L, lane, k, alpha, beta, ru, rv, key_uv, tnow, ak, at, aw);
-        int nb = 0;
-        if (u != v) nb = merge_pair(L, lane, k, alpha, beta, rv, ru, key_vu, tnow, bk, bt, bw);
-
-        // ---- write back (utils/util.py:567-574) and publish ----
-        store_row(h, m, u, lane, na, ak, at, aw, ru.norm * beta + beta);
-        if (u != v) store_row(h, m, v, lane, nb, bk, bt, bw, rv.norm * beta + beta);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // all lanes store the same word (one store instruction, one address):
-        // no lane-0 branch at the loop tail, see the dequeue comment above.
-        st_agent(h.done + (long long)m * h.cap_done + i, epoch);
+        // ---- emission is off the critical path (utils/util.py:504-506) ----
+        if (emit) {
+            const long long ob = (long long)mo * out_rows * k;
+            emit_row(ru, k, lane, tnow, out_nodes + ob + (long long)i * k, out_eidx + ob + (long long)i * k,
+                     out_dt + ob + (long long)i * k, out_w + ob + (long long)i * k);
+            const long long rv_o = ob + (role_stride + i) * k;
+            emit_row(rv, k, lane, tnow, out_nodes + rv_o, out_eidx + rv_o, out_dt + rv_o, out_w + rv_o);
+            if (n_roles == 3) {
+                const long long rg_o = ob + (2 * role_stride + i) * k;
+                emit_row(rg, k, lane, tnow, out_nodes + rg_o, out_eidx + rg_o, out_dt + rg_o, out_w + rg_o);
+            }
+        }
     }
 }
 
-__global__ void k_fill_zero(u64 *p, long long n)
+// tags -> 0 for every granule (run when the launch epoch wraps)
+__global__ void k_retag(u64 *rows, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        p[i] = 0;
-}
-
-int ensure_batch_capacity(zt_tppr *h, int64_t A, int64_t B)
-{
-    if (A > h->cap_acc) {
-        int64_t cap = h->cap_acc ? h->cap_acc : 1024;
-        while (cap < A) cap *= 2;
-        if (h->slot) { ZT_HIP(hipFree(h->slot)); ZT_HIP(hipFree(h->list)); ZT_HIP(hipFree(h->prev)); }
-        ZT_HIP(hipMalloc(&h->slot, sizeof(int) * cap));
-        ZT_HIP(hipMalloc(&h->list, sizeof(int) * cap));
-        ZT_HIP(hipMalloc(&h->prev, sizeof(int) * cap));
-        h->cap_acc = cap;
-    }
-    if (B > h->cap_done) {
-        int64_t cap = h->cap_done ? h->cap_done : 512;
-        while (cap < B) cap *= 2;
-        if (h->done) ZT_HIP(hipFree(h->done));
-        ZT_HIP(hipMalloc(&h->done, sizeof(unsigned) * cap * h->M));
-        ZT_HIP(hipMemset(h->done, 0, sizeof(unsigned) * cap * h->M));
-        h->cap_done = cap;
-    }
-    return ZT_OK;
+        rows[i] &= 0xffffffffull;
 }
 
 }  // namespace
@@ -479,19 +587,22 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     }
     zt_tppr *h = new zt_tppr();
     memset(h, 0, sizeof(*h));
-    h->N = num_nodes; h->k = k; h->M = n_tppr;
+    h->N = num_nodes; h->k = k; h->M = n_tppr; h->rg = HDR + 6 * k;
     for (int m = 0; m < n_tppr; ++m) { h->alpha[m] = alpha_host[m]; h->beta[m] = beta_host[m]; }
     const size_t rows = (size_t)n_tppr * (size_t)num_nodes;
-    ZT_HIP(hipMalloc(&h->len, rows * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->norm, rows * sizeof(double)));
-    ZT_HIP(hipMalloc(&h->key, rows * k * sizeof(u64)));
-    ZT_HIP(hipMalloc(&h->ts, rows * k * sizeof(double)));
-    ZT_HIP(hipMalloc(&h->w, rows * k * sizeof(double)));
+    ZT_HIP(hipMalloc(&h->rows, rows * h->rg * sizeof(u64)));
     ZT_HIP(hipMalloc(&h->cnt, (size_t)num_nodes * sizeof(int)));
     ZT_HIP(hipMalloc(&h->off, (size_t)num_nodes * sizeof(int)));
     ZT_HIP(hipMalloc(&h->ctl, 16 * sizeof(int)));
+    ZT_HIP(hipMalloc(&h->slot, sizeof(int) * 3 * MAX_CHUNK));
+    ZT_HIP(hipMalloc(&h->list, sizeof(int) * 3 * MAX_CHUNK));
+    ZT_HIP(hipMalloc(&h->wo, sizeof(int) * 3 * MAX_CHUNK));
+    ZT_HIP(hipMalloc(&h->pflag, sizeof(int) * 3 * MAX_CHUNK));
+    ZT_HIP(hipMalloc(&h->nxt, sizeof(int) * 3 * MAX_CHUNK));
+    ZT_HIP(hipMalloc(&h->done, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     ZT_HIP(hipMemset(h->cnt, 0, (size_t)num_nodes * sizeof(int)));
     ZT_HIP(hipMemset(h->ctl, 0, 16 * sizeof(int)));
+    ZT_HIP(hipMemset(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     hipDeviceProp_t prop;
     int dev = 0;
     ZT_HIP(hipGetDevice(&dev));
@@ -508,10 +619,9 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
 extern "C" int zt_tppr_destroy(zt_tppr *h)
 {
     if (!h) return ZT_OK;
-    (void)hipFree(h->len); (void)hipFree(h->norm); (void)hipFree(h->key); (void)hipFree(h->ts); (void)hipFree(h->w);
-    (void)hipFree(h->cnt); (void)hipFree(h->off); (void)hipFree(h->ctl);
-    if (h->slot) { (void)hipFree(h->slot); (void)hipFree(h->list); (void)hipFree(h->prev); }
-    if (h->done) (void)hipFree(h->done);
+    (void)hipFree(h->rows); (void)hipFree(h->cnt); (void)hipFree(h->off); (void)hipFree(h->ctl);
+    (void)hipFree(h->slot); (void)hipFree(h->list); (void)hipFree(h->wo); (void)hipFree(h->pflag); (void)hipFree(h->nxt);
+    (void)hipFree(h->done);
     delete h;
     return ZT_OK;
 }
@@ -519,13 +629,8 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
 extern "C" int zt_tppr_reset(zt_tppr *h, void *stream)
 {
     if (!h) return ZT_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)h->M * (size_t)h->N;
-    ZT_HIP(hipMemsetAsync(h->len, 0, rows * sizeof(int), s));
-    ZT_HIP(hipMemsetAsync(h->norm, 0, rows * sizeof(double), s));
-    ZT_HIP(hipMemsetAsync(h->key, 0, rows * h->k * sizeof(u64), s));
-    ZT_HIP(hipMemsetAsync(h->ts, 0, rows * h->k * sizeof(double), s));
-    ZT_HIP(hipMemsetAsync(h->w, 0, rows * h->k * sizeof(double), s));
+    ZT_HIP(hipMemsetAsync(h->rows, 0, rows * h->rg * sizeof(u64), (hipStream_t)stream));
     return ZT_OK;
 }
 
@@ -537,12 +642,60 @@ extern "C" int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream)
         return ZT_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    const size_t rows = (size_t)src->M * (size_t)src->N;
-    ZT_HIP(hipMemcpyAsync(dst->len, src->len, rows * sizeof(int), hipMemcpyDeviceToDevice, s));
-    ZT_HIP(hipMemcpyAsync(dst->norm, src->norm, rows * sizeof(double), hipMemcpyDeviceToDevice, s));
-    ZT_HIP(hipMemcpyAsync(dst->key, src->key, rows * src->k * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    ZT_HIP(hipMemcpyAsync(dst->ts, src->ts, rows * src->k * sizeof(double), hipMemcpyDeviceToDevice, s));
-    ZT_HIP(hipMemcpyAsync(dst->w, src->w, rows * src->k * sizeof(double), hipMemcpyDeviceToDevice, s));
+    const size_t n = (size_t)src->M * (size_t)src->N * src->rg;
+    ZT_HIP(hipMemcpyAsync(dst->rows, src->rows, n * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    // tags are relative to the owner's launch epoch: strip them in the copy
+    k_retag<<<2048, 256, 0, s>>>(dst->rows, (long long)n);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, const long long *eidx, long long role_stride,
+                        int B, int n_roles, int emit, int model, long long out_rows, int32_t *on, int32_t *oe, float *od,
+                        float *ow, hipStream_t s)
+{
+    if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
+        k_retag<<<2048, 256, 0, s>>>(h->rows, (long long)h->M * h->N * h->rg);
+        h->epoch = 0;
+    }
+    h->epoch += 1;
+    const int A = B * n_roles;
+    const int tb = 256, gb = (A + tb - 1) / tb;
+    static const bool dbg = getenv("ZT_DEBUG_SYNC") != nullptr;
+#define ZT_DBG(tag)                                                                          \
+    do {                                                                                     \
+        if (dbg) {                                                                           \
+            hipError_t e__ = hipStreamSynchronize(s);                                        \
+            fprintf(stderr, "[zt] %s: %s\n", tag, hipGetErrorString(e__));                   \
+            fflush(stderr);                                                                  \
+        }                                                                                    \
+    } while (0)
+    ZT_PROF_BEGIN(s, P_PREPASS);
+    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
+    ZT_DBG("k_count");
+    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl);
+    ZT_DBG("k_reserve");
+    k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
+    ZT_DBG("k_fill");
+    k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
+    ZT_DBG("k_deps");
+    ZT_PROF_END(s, P_PREPASS);
+    const int m_lo = model < 0 ? 0 : model;
+    const int n_models = model < 0 ? h->M : 1;
+    long long waves = (long long)B * n_models;
+    const long long max_waves = (long long)h->n_cu * WAVES_PER_WG * 2;
+    if (waves > max_waves) waves = max_waves;
+    const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    ZT_PROF_BEGIN(s, P_STREAM);
+    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, nodes, ts, eidx, role_stride, B, n_roles, emit, m_lo, n_models,
+                                                  out_rows, on, oe, od, ow, h->epoch);
+    ZT_PROF_END(s, P_STREAM);
+    ZT_DBG("k_stream");
+    ZT_PROF_BEGIN(s, P_CLEANUP);
+    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl);
+    ZT_PROF_END(s, P_CLEANUP);
+    ZT_DBG("k_cleanup");
+    ZT_LAUNCH_CHECK();
     return ZT_OK;
 }
 
@@ -560,52 +713,18 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
         set_error("zt_tppr_stream: NULL buffer");
         return ZT_ERR_ARG;
     }
-    if (B > (1ll << 24)) { set_error("zt_tppr_stream: batch too large"); return ZT_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
-    const int64_t A = B * n_roles;
-    int rc = ensure_batch_capacity(h, A, B);
-    if (rc != ZT_OK) return rc;
-    h->epoch += 1;
-    if (h->epoch == 0) h->epoch = 1;
-    const int tb = 256;
-    const int gb = (int)((A + tb - 1) / tb);
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
-    static const bool dbg = getenv("ZT_DEBUG_SYNC") != nullptr;
-#define ZT_DBG(tag)                                                                          \
-    do {                                                                                     \
-        if (dbg) {                                                                           \
-            hipError_t e__ = hipStreamSynchronize(s);                                        \
-            fprintf(stderr, "[zt] %s: %s\n", tag, hipGetErrorString(e__));                   \
-            fflush(stderr);                                                                  \
-        }                                                                                    \
-    } while (0)
-    ZT_PROF_BEGIN(s, P_PREPASS);
-    k_count<<<gb, tb, 0, s>>>(nodes_dev, e64, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
-    ZT_DBG("k_count");
-    k_reserve<<<gb, tb, 0, s>>>(nodes_dev, A, h->cnt, h->off, h->slot, h->ctl);
-    ZT_DBG("k_reserve");
-    k_fill<<<gb, tb, 0, s>>>(nodes_dev, A, h->off, h->slot, h->list);
-    ZT_DBG("k_fill");
-    k_prev<<<gb, tb, 0, s>>>(nodes_dev, A, B, h->cnt, h->off, h->slot, h->list, h->prev);
-    ZT_DBG("k_prev");
-    ZT_PROF_END(s, P_PREPASS);
-    const int m_lo = model < 0 ? 0 : model;
-    const int n_models = model < 0 ? h->M : 1;
-    const long long total = B * n_models;
-    long long waves = total;
-    const long long max_waves = (long long)h->n_cu * WAVES_PER_WG * 2;
-    if (waves > max_waves) waves = max_waves;
-    const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    ZT_PROF_BEGIN(s, P_STREAM);
-    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, nodes_dev, ts_dev, e64, B, n_roles, emit, m_lo, n_models,
-                                                  out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, h->epoch);
-    ZT_PROF_END(s, P_STREAM);
-    ZT_DBG("k_stream");
-    ZT_PROF_BEGIN(s, P_CLEANUP);
-    k_cleanup<<<gb, tb, 0, s>>>(nodes_dev, A, h->slot, h->cnt, h->ctl);
-    ZT_PROF_END(s, P_CLEANUP);
-    ZT_DBG("k_cleanup");
-    ZT_LAUNCH_CHECK();
+    // launches of at most MAX_CHUNK edges: writer ordinals must fit the tag
+    for (int64_t c0 = 0; c0 < B; c0 += MAX_CHUNK) {
+        const int bc = (int)((B - c0) < MAX_CHUNK ? (B - c0) : MAX_CHUNK);
+        const size_t oo = (size_t)c0 * h->k;
+        int rc = stream_chunk(h, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
+                              (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr,
+                              emit ? out_eidx_dev + oo : nullptr, emit ? out_dt_dev + oo : nullptr,
+                              emit ? out_w_dev + oo : nullptr, s);
+        if (rc != ZT_OK) return rc;
+    }
     return ZT_OK;
 }
 
@@ -629,23 +748,29 @@ extern "C" int zt_tppr_export(zt_tppr *h, int32_t m, int32_t *len_host, double *
 {
     if (!h || m < 0 || m >= h->M) return ZT_ERR_ARG;
     ZT_HIP(hipDeviceSynchronize());
-    const size_t N = (size_t)h->N, k = (size_t)h->k, off = (size_t)m * N;
-    std::vector<u64> key(N * k);
-    ZT_HIP(hipMemcpy(len_host, h->len + off, N * sizeof(int), hipMemcpyDeviceToHost));
-    ZT_HIP(hipMemcpy(norm_host, h->norm + off, N * sizeof(double), hipMemcpyDeviceToHost));
-    ZT_HIP(hipMemcpy(key.data(), h->key + off * k, N * k * sizeof(u64), hipMemcpyDeviceToHost));
-    ZT_HIP(hipMemcpy(ts_host, h->ts + off * k, N * k * sizeof(double), hipMemcpyDeviceToHost));
-    ZT_HIP(hipMemcpy(w_host, h->w + off * k, N * k * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t v = 0; v < N; ++v)
+    const size_t N = (size_t)h->N, k = (size_t)h->k, rg = (size_t)h->rg;
+    std::vector<u64> g(N * rg);
+    ZT_HIP(hipMemcpy(g.data(), h->rows + (size_t)m * N * rg, N * rg * sizeof(u64), hipMemcpyDeviceToHost));
+    auto lo = [](u64 x) { return (u64)(unsigned)x; };
+    for (size_t v = 0; v < N; ++v) {
+        const u64 *r = g.data() + v * rg;
+        len_host[v] = (int)(unsigned)r[0];
+        const u64 nb = lo(r[1]) | (lo(r[2]) << 32);
+        memcpy(&norm_host[v], &nb, 8);
         for (size_t j = 0; j < k; ++j) {
             const size_t p = v * k + j;
+            const u64 *e = r + HDR + j;
             if ((int)j < len_host[v]) {
-                eidx_host[p] = (int64_t)(key[p] >> 32);
-                node_host[p] = (int64_t)(key[p] & 0xffffffffull);
+                node_host[p] = (int64_t)lo(e[0]);
+                eidx_host[p] = (int64_t)lo(e[k]);
+                const u64 tb = lo(e[2 * k]) | (lo(e[3 * k]) << 32), wb = lo(e[4 * k]) | (lo(e[5 * k]) << 32);
+                memcpy(&ts_host[p], &tb, 8);
+                memcpy(&w_host[p], &wb, 8);
             } else {
                 eidx_host[p] = 0; node_host[p] = 0; ts_host[p] = 0.0; w_host[p] = 0.0;
             }
         }
+    }
     return ZT_OK;
 }
 
@@ -654,22 +779,30 @@ extern "C" int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host, co
                               const double *w_host)
 {
     if (!h || m < 0 || m >= h->M) return ZT_ERR_ARG;
-    const size_t N = (size_t)h->N, k = (size_t)h->k, off = (size_t)m * N;
-    std::vector<u64> key(N * k);
-    for (size_t p = 0; p < N * k; ++p) {
-        if (eidx_host[p] < 0 || eidx_host[p] > 0x7fffffffll || node_host[p] < 0 || node_host[p] >= h->N) {
-            set_error("zt_tppr_import: id out of range");
-            return ZT_ERR_RANGE;
-        }
-        key[p] = ((u64)eidx_host[p] << 32) | (u64)node_host[p];
-    }
-    for (size_t v = 0; v < N; ++v)
+    const size_t N = (size_t)h->N, k = (size_t)h->k, rg = (size_t)h->rg;
+    std::vector<u64> g(N * rg, 0ull);
+    for (size_t v = 0; v < N; ++v) {
         if (len_host[v] < 0 || len_host[v] > (int)k) { set_error("zt_tppr_import: bad length"); return ZT_ERR_ARG; }
+        u64 *r = g.data() + v * rg;
+        u64 nb;
+        memcpy(&nb, &norm_host[v], 8);
+        r[0] = (u64)(unsigned)len_host[v]; r[1] = (u64)(unsigned)nb; r[2] = nb >> 32;
+        for (size_t j = 0; j < (size_t)len_host[v]; ++j) {
+            const size_t p = v * k + j;
+            if (eidx_host[p] < 0 || eidx_host[p] > 0x7fffffffll || node_host[p] < 0 || node_host[p] >= h->N) {
+                set_error("zt_tppr_import: id out of range");
+                return ZT_ERR_RANGE;
+            }
+            u64 tb, wb;
+            memcpy(&tb, &ts_host[p], 8);
+            memcpy(&wb, &w_host[p], 8);
+            u64 *e = r + HDR + j;
+            e[0] = (u64)node_host[p]; e[k] = (u64)eidx_host[p];
+            e[2 * k] = (u64)(unsigned)tb; e[3 * k] = tb >> 32;
+            e[4 * k] = (u64)(unsigned)wb; e[5 * k] = wb >> 32;
+        }
+    }
     ZT_HIP(hipDeviceSynchronize());
-    ZT_HIP(hipMemcpy(h->len + off, len_host, N * sizeof(int), hipMemcpyHostToDevice));
-    ZT_HIP(hipMemcpy(h->norm + off, norm_host, N * sizeof(double), hipMemcpyHostToDevice));
-    ZT_HIP(hipMemcpy(h->key + off * k, key.data(), N * k * sizeof(u64), hipMemcpyHostToDevice));
-    ZT_HIP(hipMemcpy(h->ts + off * k, ts_host, N * k * sizeof(double), hipMemcpyHostToDevice));
-    ZT_HIP(hipMemcpy(h->w + off * k, w_host, N * k * sizeof(double), hipMemcpyHostToDevice));
+    ZT_HIP(hipMemcpy(h->rows + (size_t)m * N * rg, g.data(), N * rg * sizeof(u64), hipMemcpyHostToDevice));
     return ZT_OK;
 }
