@@ -146,6 +146,8 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     a = ap.parse_args()
 
     import torch
@@ -195,10 +197,18 @@ def main():
     else:
         step = tgn.step_device
 
+    if not a.no_pipeline:
+        tgn.enable_pipeline()       # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
+
+    def batch(b):
+        s, e = b * bs, (b + 1) * bs
+        return src_d[s:e], dst_d[s:e], neg_d[s:e], ts_d[s:e], eidx_d[s:e]
+
     def run(b0, nb):
+        # exactly nb steps; nothing of step b0+nb is enqueued (no prefetch on the last one)
         for b in range(b0, b0 + nb):
-            s, e = b * bs, (b + 1) * bs
-            step(src_d[s:e], dst_d[s:e], neg_d[s:e], ts_d[s:e], eidx_d[s:e])
+            nxt = batch(b + 1) if (not a.no_pipeline and b + 1 < b0 + nb) else None
+            step(*batch(b), prefetch=nxt)
 
     lib = _capi.lib()
     run(0, prefill)

@@ -124,3 +124,33 @@ def test_protocol_vs_oracle(oracle, cfg):
     assert np.array_equal(tgn.memory.last_update.cpu().numpy(), mem.last_update)
     assert np.abs(tgn.memory.messages.cpu().numpy() - mem.messages).max() <= TOL
     assert np.array_equal(tgn.memory.nodes.astype(np.uint8), mem.flags)
+
+
+def test_pipelined_step_matches_sequential():
+    """The side-stream T-PPR prefetch must not change any result."""
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    outs = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode == "pipe":
+            tgn.enable_pipeline()
+        nbt = E // bs
+        embs = []
+        for b in range(nbt):
+            cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
+            nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
+            embs.append(tgn.step_device(*cur, prefetch=nxt).clone())
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(),
+                      tgn.embedding_module.tppr_finder.export_state(0))
+    assert np.array_equal(outs["seq"][0], outs["pipe"][0])
+    assert np.array_equal(outs["seq"][1], outs["pipe"][1])
+    for kk in outs["seq"][2]:
+        assert np.array_equal(outs["seq"][2][kk], outs["pipe"][2][kk])

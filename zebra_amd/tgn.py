@@ -101,18 +101,60 @@ class TGN(torch.nn.Module):
                                       ptr(self._n_uniq), ptr(self._status), stream_ptr()), "zt_store_messages")
         return B
 
+    # -- P1 on a side stream: the T-PPR state depends only on the edge stream, never on the node
+    # -- memory, so the query of batch b+1 can run while batch b is being aggregated / written back.
+    def enable_pipeline(self, on=True):
+        """Run the T-PPR query on its own HIP stream and allow ``prefetch`` in step_device."""
+        self._side = torch.cuda.Stream(device=self.device) if on else None
+        self._pending = None
+
+    def _tppr_launch(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status):
+        em = self.embedding_module
+        nodes_d = torch.cat([src_d, dst_d, neg_d])
+        ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
+        return (nodes_d,) + tuple(em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status))
+
+    def tppr_batch_device(self, batch, prefetch=None, check_status=False):
+        """T-PPR query of ``batch`` = (src, dst, neg, ts, eidx) -> (nodes, nbr, eidx, dt, w) device
+        tensors, valid on the current stream.  With the pipeline enabled, ``prefetch`` (the NEXT
+        batch) is enqueued on the side stream before returning."""
+        side = getattr(self, "_side", None)
+        if side is None:
+            return self._tppr_launch(*batch, check_status)
+        main = torch.cuda.current_stream()
+        key = (batch[4].data_ptr(), batch[4].numel())
+        if self._pending is not None and self._pending[0] == key:
+            _, outs, ev = self._pending
+        else:
+            with torch.cuda.stream(side):
+                outs = self._tppr_launch(*batch, False)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        self._pending = None
+        main.wait_event(ev)
+        for t in outs:
+            t.record_stream(main)
+        if prefetch is not None:
+            with torch.cuda.stream(side):
+                nxt = self._tppr_launch(*prefetch, False)
+                ev2 = torch.cuda.Event()
+                ev2.record(side)
+            self._pending = ((prefetch[4].data_ptr(), prefetch[4].numel()), nxt, ev2)
+        if check_status and self.embedding_module.tppr_strategy == "streaming":
+            self.embedding_module.tppr_finder.check_status()
+        return outs
+
     @torch.no_grad()
-    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False):
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None):
         """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
         int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
-        ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings."""
+        ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings.
+        ``prefetch`` = the next batch's five tensors (pipeline mode only)."""
         if not self.test_mode:
             self.update_memory_in_test(self.memory)
             self.test_mode = True
         em = self.embedding_module
-        nodes_d = torch.cat([src_d, dst_d, neg_d])
-        ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
-        on, oe, od, ow = em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status)
+        nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status)
         emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
         B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
         self.memory_updater.update_device(self.memory, self._uniq, 2 * B, self._n_uniq)
