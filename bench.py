@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with the
 host cores, N = 1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -146,6 +147,8 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--tppr-cus", type=int, default=0,
+                    help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     a = ap.parse_args()
@@ -198,7 +201,9 @@ def main():
         step = tgn.step_device
 
     if not a.no_pipeline:
-        tgn.enable_pipeline()       # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
+        # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
+        tgn.enable_pipeline(tppr_cus=a.tppr_cus)
+    main_stream = getattr(tgn, "main_stream", None)
 
     def batch(b):
         s, e = b * bs, (b + 1) * bs
@@ -206,9 +211,11 @@ def main():
 
     def run(b0, nb):
         # exactly nb steps; nothing of step b0+nb is enqueued (no prefetch on the last one)
-        for b in range(b0, b0 + nb):
-            nxt = batch(b + 1) if (not a.no_pipeline and b + 1 < b0 + nb) else None
-            step(*batch(b), prefetch=nxt)
+        ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
+        with ctx:
+            for b in range(b0, b0 + nb):
+                nxt = batch(b + 1) if (not a.no_pipeline and b + 1 < b0 + nb) else None
+                step(*batch(b), prefetch=nxt)
 
     lib = _capi.lib()
     run(0, prefill)

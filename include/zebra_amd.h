@@ -44,6 +44,13 @@ const char *zt_last_error(void);
 /* Library / build information ("zebra_amd <version> gfx950"). */
 const char *zt_version(void);
 
+/* HIP streams restricted to the compute units [cu_lo, cu_hi) (CU masking):
+ * the dependency-bound T-PPR kernel and the throughput-bound aggregation can
+ * then run side by side without sharing CUs.  New work; the reference is
+ * single-stream (train.py:145-146). */
+int zt_stream_create_masked(void **stream_out, int32_t cu_lo, int32_t cu_hi);
+int zt_stream_destroy(void *stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (replaces
  * the reference's unsynchronised wall-clock accumulators t_tppr etc.,
  * modules/embedding_module.py:73,220-225).  Names: tppr_prepass, tppr_stream,
@@ -221,13 +228,15 @@ typedef struct {
  * Memory.clear_messages (modules/memory.py:59-60) for the same ids.
  *   ids_dev == NULL : every node (update_memory_in_test);
  *   ids_dev != NULL : ids_dev[0 .. *n_ids_dev) if n_ids_dev != NULL, else
- *                     ids_dev[0 .. n_ids); ids must be unique.
+ *                     ids_dev[0 .. n_ids); duplicates are allowed.
  *   Flagged ids get last_update = msg_ts and memory = GRU(messages, memory);
  *   flags of all ids are cleared.
  *   flags_dev must be 4-byte aligned and padded to a multiple of 4 bytes (flag
  *   bytes are cleared with 32-bit atomics).
  *   workspace_dev: zt_gru_workspace_bytes(max_rows, D, msg_dim) bytes, where
- *   max_rows = n_ids (or num_nodes when ids_dev == NULL). */
+ *   max_rows = n_ids (or num_nodes when ids_dev == NULL).  On return its first
+ *   int32 holds the number of rows updated and the int32 array at byte 256
+ *   their ids (duplicates in ids_dev are updated once). */
 int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t msg_dim);
 int zt_gru_update(float *memory_dev, float *last_update_dev,
                   const float *messages_dev, const float *msg_ts_dev,
@@ -240,8 +249,8 @@ int zt_gru_update(float *memory_dev, float *last_update_dev,
 /* Test hook (not product API): the exact top-k selection primitive on its    */
 /* own.  vals [cases][n] float64; writes np.argsort(vals[c])[-k:] under       */
 /* numba's quicksort semantics into sel_out [cases][k] and the path taken     */
-/* (0 fast rank, 1 wave-parallel exact, 2 sequential exact) into path_out.    */
-/* mode: 0 = production dispatch, 1 = force wave-parallel, 2 = force sequential */
+/* (0 fast rank, 1 wave-parallel exact in LDS, 2 sequential exact, 3 exact in  */
+/* registers) into path_out.  mode: 0 = production dispatch, 1/2/3 = force.    */
 /* ------------------------------------------------------------------------ */
 int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases,
                  int32_t mode, int32_t *sel_out_dev, int32_t *path_out_dev,

@@ -10,7 +10,7 @@ def main(path, last):
     rows = defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            name = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "")
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             rows[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     tot_all = sum(sum(v) for v in rows.values())
     print("%-40s %7s %12s %12s | last %d launches: %12s" % ("kernel", "calls", "avg_us", "total_ms", last, "avg_us"))

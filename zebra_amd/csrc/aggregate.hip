@@ -78,34 +78,78 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const int K1 = D + F + T;
     const size_t mb = ((size_t)m * N + q0) * k;                       // first entry of this tile in [M][N][k]
 
-    // ---- normalised weights: w / sum(w), 0 where the sum is 0 (:267-270) ----
-    for (int q = tid; q < nq; q += AGG_THREADS) {
-        float s = 0.f;
-        for (int j = 0; j < k; ++j) s += w[mb + (size_t)q * k + j];
-        for (int j = 0; j < k; ++j) wn[q * k + j] = (s == 0.f) ? 0.f : w[mb + (size_t)q * k + j] / s;
-        S[(size_t)m * N + q0 + q] = (s == 0.f) ? 0.f : 1.f;
-    }
-    for (int g = rows + tid; g < rows_p; g += AGG_THREADS) wn[g] = 0.f;
+    // per-row gather indices, staged once so that the row loads below are independent
+    int *g_nb = reinterpret_cast<int *>(wn + rows_p);                 // [mt*16]
+    int *g_ei = g_nb + rows_p;
+    float *g_dt = reinterpret_cast<float *>(g_ei + rows_p);
 
-    // ---- gather: one wave per row, lanes sweep the columns (coalesced) ----
-    for (int g = wave; g < rows_p; g += AGG_WAVES) {
-        float *row = A + (size_t)g * lda;
-        if (g >= rows) {
-            for (int c = lane; c < K1p; c += WAVE) row[c] = 0.f;
-            continue;
+    // ---- stage the per-row scalars (coalesced), then normalise the weights in LDS ----
+    for (int g = tid; g < rows_p; g += AGG_THREADS) {
+        int nb = 0, ei = 0;
+        float d = 0.f, wv = 0.f;
+        if (g < rows) {
+            nb = nbr[mb + g]; ei = eix[mb + g]; d = dt[mb + g]; wv = w[mb + g];
+            if (nb < 0 || nb >= num_nodes || ei < 0 || ei >= num_edges) {
+                atomicExch(status, ZT_ERR_RANGE);
+                nb = 0; ei = 0;
+            }
         }
-        int nb = nbr[mb + g], ei = eix[mb + g];
-        const float d = dt[mb + g];
-        if (nb < 0 || nb >= num_nodes || ei < 0 || ei >= num_edges) {
-            if (lane == 0) atomicExch(status, ZT_ERR_RANGE);
-            nb = 0; ei = 0;
+        g_nb[g] = nb; g_ei[g] = ei; g_dt[g] = d; wn[g] = wv;
+    }
+    __syncthreads();
+    // w / sum(w), 0 where the sum is 0 (:267-270); sum in entry order like torch.sum(dim=1)
+    float my_sum = 0.f;
+    if (tid < rows) {
+        const int q = tid / k;
+        for (int j = 0; j < k; ++j) my_sum += wn[q * k + j];
+    }
+    __syncthreads();
+    if (tid < rows) {
+        wn[tid] = (my_sum == 0.f) ? 0.f : wn[tid] / my_sum;
+        if (tid % k == 0) S[(size_t)m * N + q0 + tid / k] = (my_sum == 0.f) ? 0.f : 1.f;
+    }
+
+    // ---- gather: flat (row, column) loops, GU loads in flight per thread before any LDS store
+    // ---- (a row-at-a-time loop serialises on HBM latency: 20 rows x ~3 us per wave)
+    constexpr int GU = 8;
+    for (int f0 = tid; f0 < rows_p * D; f0 += AGG_THREADS * GU) {
+        float v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = f / D, c = f - g * D;
+            v[u] = (f < rows_p * D && g < rows) ? memory[(size_t)g_nb[g] * D + c] : 0.f;
         }
-        const float *mr = memory + (size_t)nb * D;
-        const float *er = efeat + (size_t)ei * F;
-        for (int c = lane; c < D; c += WAVE) row[c] = mr[c];
-        for (int c = lane; c < F; c += WAVE) row[D + c] = er[c];
-        for (int c = lane; c < T; c += WAVE) row[D + F + c] = cosf(d * time_w[c]);   // cos(t*w + 0)
-        for (int c = K1 + lane; c < K1p; c += WAVE) row[c] = 0.f;
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = f / D, c = f - g * D;
+            if (f < rows_p * D) A[(size_t)g * lda + c] = v[u];
+        }
+    }
+    for (int f0 = tid; f0 < rows_p * F; f0 += AGG_THREADS * GU) {
+        float v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = f / F, c = f - g * F;
+            v[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = f / F, c = f - g * F;
+            if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+        }
+    }
+    for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
+        const int g = f / T, c = f - g * T;
+        A[(size_t)g * lda + D + F + c] = g < rows ? cosf(g_dt[g] * time_w[c]) : 0.f;   // cos(t*w + 0)
+    }
+    const int padw = K1p - K1;
+    for (int f = tid; f < rows_p * padw; f += AGG_THREADS) {
+        const int g = f / padw, c = f - g * padw;
+        A[(size_t)g * lda + K1 + c] = 0.f;
     }
     __syncthreads();
 
@@ -288,18 +332,18 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     p.lda = p.K1p + 4;
     // M-tiles per workgroup: as many whole query rows as fit in 5 tiles / the LDS budget
     int mt = MAX_MT;
-    while (mt > 1 && ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4) > (size_t)LDS_BUDGET) --mt;
+    while (mt > 1 && ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
     int rq = (mt * 16) / k;
     if (rq < 1) {
         // one query row must fit: grow to ceil(k/16) tiles if the budget allows
         mt = (k + 15) / 16;
         rq = 1;
-        if (mt > MAX_MT || ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4) > (size_t)LDS_BUDGET) return false;
+        if (mt > MAX_MT || ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) return false;
     }
     mt = (rq * k + 15) / 16;
     p.mt = mt;
     p.rq = rq;
-    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 4;
+    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16;   // A tile + wn, nbr, eix, dt per row
     // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
     if ((size_t)mt * 16 * (p.Dp + 1) * 4 > (size_t)mt * 16 * p.lda * 4) return false;
     size_t o = 0;

@@ -80,20 +80,31 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long n = ids ? (n_ids_dev ? (long long)*n_ids_dev : n_ids) : num_nodes;
-    if (ids && n > n_ids && n_ids_dev == nullptr) n = n_ids;
-    if (t >= n) return;
-    const int v = ids ? ids[t] : (int)t;
-    if (v < 0 || v >= num_nodes) return;
-    // clear the flag byte atomically (32-bit word) so that a duplicated id is
-    // selected once
-    unsigned *wp = reinterpret_cast<unsigned *>(flags + (v & ~3));
-    const unsigned mask = 0xffu << (8 * (v & 3));
-    const unsigned old = atomicAnd(wp, ~mask);
-    if (old & mask) rows[atomicAdd(n_rows, 1)] = v;
+    if (ids && n > n_ids) n = n_ids;
+    bool take = false;
+    int v = -1;
+    if (t < n) {
+        v = ids ? ids[t] : (int)t;
+        if (v >= 0 && v < num_nodes) {
+            // clear the flag byte atomically (32-bit word): a duplicated id is selected once
+            unsigned *wp = reinterpret_cast<unsigned *>(flags + (v & ~3));
+            const unsigned mask = 0xffu << (8 * (v & 3));
+            take = (atomicAnd(wp, ~mask) & mask) != 0;
+        }
+    }
+    // one counter add per wavefront (thousands of adds to one word cost ~12 ns each)
+    const u64 bm = __ballot(take);
+    if (bm == 0ull) return;
+    int base = 0;
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(n_rows, __popcll(bm));
+    base = __shfl(base, __ffsll((long long)bm) - 1);
+    if (take) rows[base + __popcll(bm & ((1ull << lane) - 1ull))] = v;
 }
 
 constexpr int GRU_MT = 2;      // 32 rows per workgroup
-constexpr int GRU_NTW = 2;     // hidden N-tiles per wave -> D <= 128
+constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
+constexpr int GRU_WAVES = 8;
 
 // Zero-padded gate-major copy: W[3D][K] -> Wp[3][Dp][Kp]
 __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *__restrict__ Wp, int Dp, int Kp)
@@ -104,7 +115,7 @@ __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *_
     Wp[i] = (r < D && c < K) ? W[((size_t)g * D + r) * K + c] : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, const float *__restrict__ messages,
+__global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *last_update, const float *__restrict__ messages,
                                              const float *__restrict__ msg_ts, const int *__restrict__ rows,
                                              const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
                                              int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
@@ -119,16 +130,30 @@ __global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, 
     const int nr = (total - r0) < GRU_MT * 16 ? (total - r0) : GRU_MT * 16;
     const int Dp = Hp;
 
-    for (int g = wave; g < GRU_MT * 16; g += 4) {
-        float *row = A + (size_t)g * lda;
-        if (g >= nr) {
-            for (int c = lane; c < Xp + Hp; c += WAVE) row[c] = 0.f;
-            continue;
+    // flat (row, column) gather, GU loads in flight per thread before any LDS store (see aggregate.hip)
+    const int nthr = 64 * GRU_WAVES;
+    constexpr int GU = 8;
+    int *rid = reinterpret_cast<int *>(A + (size_t)GRU_MT * 16 * lda);     // this tile's node ids
+    if (tid < GRU_MT * 16) rid[tid] = tid < nr ? rows[r0 + tid] : 0;
+    __syncthreads();
+    for (int f0 = tid; f0 < GRU_MT * 16 * Xp; f0 += nthr * GU) {
+        float v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * nthr;
+            const int g = f / Xp, c = f - g * Xp;
+            v[u] = (f < GRU_MT * 16 * Xp && g < nr && c < msg_dim) ? messages[(size_t)rid[g] * msg_dim + c] : 0.f;
         }
-        const int v = rows[r0 + g];
-        const float *x = messages + (size_t)v * msg_dim, *h = memory + (size_t)v * D;
-        for (int c = lane; c < Xp; c += WAVE) row[c] = c < msg_dim ? x[c] : 0.f;
-        for (int c = lane; c < Hp; c += WAVE) row[Xp + c] = c < D ? h[c] : 0.f;
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = f0 + u * nthr;
+            const int g = f / Xp, c = f - g * Xp;
+            if (f < GRU_MT * 16 * Xp) A[(size_t)g * lda + c] = v[u];
+        }
+    }
+    for (int f = tid; f < GRU_MT * 16 * Hp; f += nthr) {
+        const int g = f / Hp, c = f - g * Hp;
+        A[(size_t)g * lda + Xp + c] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
     }
     __syncthreads();
 
@@ -146,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, 
     int colrow[GRU_NTW];
 #pragma unroll
     for (int b = 0; b < GRU_NTW; ++b) {
-        const int nt = wave + b * 4;
+        const int nt = wave + b * GRU_WAVES;
         live[b] = nt < NT;
         colrow[b] = (live[b] ? nt : 0) * 16 + r16;
     }
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, 
 #pragma unroll
     for (int b = 0; b < GRU_NTW; ++b) {
         if (!live[b]) continue;
-        const int col = (wave + b * 4) * 16 + r16;
+        const int col = (wave + b * GRU_WAVES) * 16 + r16;
         if (col >= D) continue;
         const float bir = b_ih[col], biz = b_ih[D + col], bin = b_ih[2 * D + col];
         const float bhr = b_hh[col], bhz = b_hh[D + col], bhn = b_hh[2 * D + col];
@@ -214,10 +239,10 @@ __global__ __launch_bounds__(256) void k_gru(float *memory, float *last_update, 
                 const float z = 1.f / (1.f + expf(-(az[a][b][j] + biz + bhz)));
                 const float n = tanhf(ani[a][b][j] + bin + r * (anh[a][b][j] + bhn));
                 const float hold = A[(size_t)g * lda + Xp + col];
-                memory[(size_t)rows[r0 + g] * D + col] = (1.f - z) * n + z * hold;
+                memory[(size_t)rid[g] * D + col] = (1.f - z) * n + z * hold;
             }
     }
-    for (int g = tid; g < nr; g += 256) {
+    for (int g = tid; g < nr; g += nthr) {
         const int v = rows[r0 + g];
         last_update[v] = msg_ts[v];                   // memory_updater.py:40
     }
@@ -233,7 +258,7 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.Xp = round_up(msg_dim, 16);
     p.Hp = round_up(D, 16);
     p.lda = p.Xp + p.Hp + 4;
-    p.lds = (size_t)GRU_MT * 16 * p.lda * 4;
+    p.lds = (size_t)GRU_MT * 16 * p.lda * 4 + GRU_MT * 16 * 4;   // A tile + node ids
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     p.off_cnt = take(256);
@@ -334,7 +359,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
         attr_lds = p.lds;
     }
     const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
-    k_gru<<<grid, 256, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
+    k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh);
     ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();

@@ -176,18 +176,142 @@ __device__ inline void numba_argsort_wave(const double *a, int n, SortLds &S)
         const int lo = S.seg_lo[p], hi = S.seg_hi[p];
         const double v = S.v[p];
         int rank = 0;
-        for (int q = lo; q <= hi; ++q) {
-            const double x = S.v[q];
-            rank += (x < v || (x == v && q < p)) ? 1 : 0;
+        for (int q0 = lo; q0 <= hi; q0 += 8) {       // segments hold at most 15 entries
+            double x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = S.v[(q0 + t) <= hi ? (q0 + t) : hi];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = q0 + t;
+                rank += (q <= hi && (x[t] < v || (x[t] == v && q < p))) ? 1 : 0;
+            }
         }
         S.r2[lo + rank] = S.r[p];
     }
     wave_sync();
 }
 
+// ---------------------------------------------------------------------------
+// Register-resident, level-synchronous replay for n <= 64 (no NaN): lane p IS
+// position p and holds (candidate index r, value v).  Every segment that still
+// needs a partition (size >= 16) is partitioned in the same pass: segments are
+// disjoint lane ranges, ballots are masked per segment, the three
+// median-of-3 reads, the pair swaps and the final pivot swap are cross-lane
+// permutes.  The order in which numba pops segments off its stack does not
+// change the result (partitions of disjoint ranges commute), so levels can be
+// processed side by side.  Result: S.r2[0..n) = argsort.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_f64(double x, int src)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __shfl((int)(unsigned)(b & 0xffffffffll), src), hi = __shfl((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int src /* wave-uniform */)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ inline void numba_argsort_reg(const double *a, int n, SortLds &S)
+{
+    const int p = lane_id();
+    const bool live = p < n;
+    int r = p;
+    double v = live ? a[p] : 0.0;
+    int lo = 0, hi = live ? n - 1 : -1;               // my segment (inclusive)
+    const u64 below = lanemask_lt();
+    const u64 above = ~below & ~(1ull << p);
+    for (;;) {
+        const bool act = live && (hi - lo >= 15);
+        const u64 actm = __ballot(act);
+        if (actm == 0ull) break;
+        // ---- median of three of MY segment (every lane of a segment computes the same) ----
+        const int mid = (lo + hi) >> 1;
+        int rl, rm, rh;
+        double al, am, ah;
+        const int first = __ffsll((long long)actm) - 1;
+        const int lo0 = __builtin_amdgcn_readlane(lo, first), hi0 = __builtin_amdgcn_readlane(hi, first);
+        if (__ballot(act && lo != lo0) == 0ull) {      // one segment in this level: scalar lane reads, no LDS
+            const int mid0 = (lo0 + hi0) >> 1;
+            rl = __builtin_amdgcn_readlane(r, lo0); rm = __builtin_amdgcn_readlane(r, mid0);
+            rh = __builtin_amdgcn_readlane(r, hi0);
+            al = readlane_f64(v, lo0); am = readlane_f64(v, mid0); ah = readlane_f64(v, hi0);
+        } else {
+            const int sl = act ? lo : p, sm = act ? mid : p, sh = act ? hi : p;
+            rl = __shfl(r, sl); rm = __shfl(r, sm); rh = __shfl(r, sh);
+            al = shfl_f64(v, sl); am = shfl_f64(v, sm); ah = shfl_f64(v, sh);
+        }
+        if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+        if (lt_f(ah, am)) { int t = rh; rh = rm; rm = t; double x = ah; ah = am; am = x; }
+        if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+        const double pivot = am;
+        if (act) {                                     // pivot stashed at `hi`
+            if (p == lo) { r = rl; v = al; }
+            else if (p == mid) { r = rh; v = ah; }
+            else if (p == hi) { r = rm; v = am; }
+        }
+        // ---- stops over lo .. hi-1, ranks inside the segment ----
+        const bool in = act && p <= hi - 1;
+        const bool ge = in && !lt_f(v, pivot), le = in && !lt_f(pivot, v);
+        const u64 GE = __ballot(ge), LE = __ballot(le);
+        // bits lo .. hi-1 of my segment (act => hi-1 >= lo, hi-1 <= 62)
+        const u64 seg = act ? ((((1ull << (hi - 1)) << 1) - 1ull) & ~((1ull << lo) - 1ull)) : 0ull;
+        const u64 GEs = GE & seg, LEs = LE & seg;
+        const int nI = __popcll(GEs), nJ = __popcll(LEs);
+        const int mi = __popcll(GEs & below), mj = __popcll(LEs & above);
+        if (ge) S.ilist[lo + mi] = p;                  // slots lo.. are private to the segment
+        if (le) S.jlist[lo + mj] = p;
+        wave_sync();
+        // partner of an i-stop of rank m: the j-stop of rank m (and vice versa); swap while I < J
+        int src1 = p;
+        bool swi = false, swj = false;
+        if (ge && mi < nJ) { const int q = S.jlist[lo + mi]; if (p < q) { src1 = q; swi = true; } }
+        if (le && mj < nI) { const int q = S.ilist[lo + mj]; if (q < p) { src1 = q; swj = true; } }
+        // where the i-scan finally stops: the first i-stop that did not swap (or `hi`), or the
+        // slot the last swap filled with a >= pivot value (the lowest swapped j-stop), whichever is first
+        const u64 stay = __ballot(ge && !swi) & seg, swapped_j = __ballot(swj) & seg;
+        int ifin = stay ? __ffsll((long long)stay) - 1 : hi;
+        if (swapped_j) { const int jl = __ffsll((long long)swapped_j) - 1; ifin = jl < ifin ? jl : ifin; }
+        // pair swaps, then pivot (stashed at hi) <-> ifin, applied as ONE permutation
+        const int src2 = act ? (p == ifin ? hi : (p == hi ? ifin : p)) : p;
+        const int csrc = __shfl(src1, src2);
+        r = __shfl(r, csrc);
+        v = shfl_f64(v, csrc);
+        if (act) {
+            if (p < ifin) hi = ifin - 1;
+            else if (p > ifin) lo = ifin + 1;
+            else { lo = p; hi = p; }
+        }
+        wave_sync();                                   // the lists are rewritten by the next level
+    }
+    // ---- stable rank inside every finished segment (insertion sort with strict <) ----
+    if (live) S.v[p] = v;
+    wave_sync();
+    if (live) {
+        int rank = 0;
+        for (int q0 = lo; q0 <= hi; q0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = S.v[(q0 + t) <= hi ? (q0 + t) : hi];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int q = q0 + t;
+                rank += (q <= hi && (x[t] < v || (x[t] == v && q < p))) ? 1 : 0;
+            }
+        }
+        S.r2[lo + rank] = r;
+    }
+    wave_sync();
+}
+
 // Wave-cooperative top-k selection.  On return sel[0..k) holds the indices of
 // np.argsort(a)[-k:] in that order.  Requires n > k.  `a` and `sel` are LDS
-// arrays owned by this wave.  Returns 0 = fast path, 1 = exact wave-parallel,
+// arrays owned by this wave.  Returns the path taken: 3 = exact replay in
+// registers (n <= 64), 0 = rank fast path, 1 = exact wave-parallel in LDS,
 // 2 = exact sequential.
 __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, SortLds &S, int *seq_perm,
                                        int *seq_stk)
@@ -195,6 +319,17 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
     const int lane = lane_id();
     const int drop = n - k;
     bool slow = false, has_nan = false;
+    if (n <= WAVE) {
+        // one lane per candidate: the exact replay in registers is cheaper than
+        // first testing whether ties matter, so it is the only path here
+        const bool nan = lane < n && (a[lane] != a[lane]);
+        if (__ballot(nan) == 0ull) {
+            numba_argsort_reg(a, n, S);
+            if (lane < k) sel[lane] = S.r2[drop + lane];
+            wave_sync();
+            return 3;
+        }
+    }
     // rank counting: every candidate c (strided over lanes) counts smaller /
     // equal values; all lanes read a[q] at the same address (LDS broadcast).
     for (int c = lane; c < ((n + WAVE - 1) / WAVE) * WAVE; c += WAVE) {
@@ -202,10 +337,16 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
         const bool live = c < n;
         const double v = live ? a[c] : 0.0;
         const bool nan = live && (v != v);
-        for (int q = 0; q < n; ++q) {
-            const double x = a[q];
-            lt += (x < v) ? 1 : 0;
-            eq += (x == v) ? 1 : 0;
+        for (int q0 = 0; q0 < n; q0 += 8) {          // 8 broadcast reads in flight per step
+            double x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = a[(q0 + t) < n ? (q0 + t) : (n - 1)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = (q0 + t) < n;
+                lt += (in && x[t] < v) ? 1 : 0;
+                eq += (in && x[t] == v) ? 1 : 0;
+            }
         }
         eq -= 1;  // itself
         // a tie group [lt, lt+eq] that reaches rank >= drop makes the order

@@ -15,7 +15,8 @@ struct HookLds {
 };
 
 // one wavefront per case; mode 0 = production dispatch (fast / wave / seq),
-// 1 = force the wave-parallel exact sort, 2 = force the sequential replay
+// 1 = force the wave-parallel exact sort (LDS), 2 = force the sequential replay,
+// 3 = force the register-resident replay (n <= 64)
 __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ vals, int n, int k, int cases, int mode,
                                                   int *sel_out, int *path_out)
 {
@@ -26,8 +27,14 @@ __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ val
     for (int q = lane; q < n; q += WAVE) L.a[q] = vals[(size_t)c * n + q];
     wave_sync();
     int path;
+    const long long t0 = (long long)wall_clock64();
     if (mode == 0) {
         path = topk_select_wave(L.a, n, k, L.sel, L.sort, L.perm, L.stk);
+    } else if (mode == 3) {
+        numba_argsort_reg(L.a, n, L.sort);
+        if (lane < k) L.sel[lane] = L.sort.r2[n - k + lane];
+        wave_sync();
+        path = 3;
     } else if (mode == 1) {
         numba_argsort_wave(L.a, n, L.sort);
         if (lane < k) L.sel[lane] = L.sort.r2[n - k + lane];
@@ -41,8 +48,9 @@ __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ val
         wave_sync();
         path = 2;
     }
+    const long long t1 = (long long)wall_clock64();
     if (lane < k) sel_out[(size_t)c * k + lane] = L.sel[lane];
-    if (lane == 0) path_out[c] = path;
+    if (lane == 0) path_out[c] = path | ((int)(t1 - t0) << 8);   // bits 8..: duration in 10 ns ticks
 }
 
 }  // namespace
@@ -51,7 +59,7 @@ extern "C" int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_
                             int32_t *sel_out_dev, int32_t *path_out_dev, void *stream)
 {
     if (!vals_dev || !sel_out_dev || !path_out_dev || n < 2 || k < 1 || k >= n || k > 64 || cases < 1 || n > 1536 ||
-        (mode == 1 && n > 128)) {
+        (mode == 1 && n > 128) || (mode == 3 && n > 64)) {
         set_error("zt_test_topk: bad argument");
         return ZT_ERR_ARG;
     }

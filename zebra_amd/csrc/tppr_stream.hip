@@ -150,7 +150,7 @@ struct zt_tppr {
     int *list;       // accesses grouped by node
     int *wo;         // ordinal of the last earlier writer of the access' node (0 = none in this launch)
     int *pflag;      // edge whose "reads done" flag must be seen first, or -1
-    int *nxt;        // next edge of the launch touching the access' node (INT_MAX = none)
+    int *nxt;        // number of later edges of the launch touching the access' node (chain still ahead)
     unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
     // control words (device): [0] cursor, [1] queue head, [2] status
     int *ctl;
@@ -163,6 +163,16 @@ namespace {
 constexpr int CAP = 128;          // candidates per merge: 2k+1 <= 127
 constexpr int WAVES_PER_WG = 4;
 constexpr long long WAIT_TICKS = 400000000ll;   // 4 s of the 100 MHz wall clock: bound on any dependency wait
+
+#ifdef ZT_STAMP
+__device__ long long g_stamps[8192 * 4];
+__device__ long long g_stamps2[8192 * 8];
+#define STAMP2(slot) do { if (lane_id() == 0 && g_stamp_i >= 0 && g_stamp_i < 8192) g_stamps2[g_stamp_i * 8 + (slot)] = (long long)wall_clock64(); } while (0)   // diagnostic build only: per task t_deq, t_rows, t_x1, t_end (100 MHz ticks)
+#define STAMP(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps[i * 4 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#define STAMP2(slot) do { } while (0)
+#endif
 
 struct WaveLds {
     u64 key[CAP];
@@ -230,25 +240,26 @@ __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int
 // K4: per access, from its node's group:
 //   wo    = number of writer accesses by earlier edges  (= ordinal of the last earlier writer)
 //   pflag = the latest earlier edge touching the node, if that access was a reader, else -1
-//   nxt   = the next later edge touching the node (who waits for this access' result)
+//   nxt   = how many later edges touch the node (the length of the chain waiting for this access)
 __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
                        const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
-    if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0x7fffffff; return; }
+    if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0; return; }
     const int x = nodes[(long long)(a / B) * role_stride + a % B];
     const int o = off[x], c = cnt[x];
     const int me = a % B;
-    int best = -1, best_role = 0, writers = 0, nx = 0x7fffffff;
+    int best = -1, best_role = 0, writers = 0, nx = 0;
+#pragma unroll 8
     for (int p = 0; p < c; ++p) {
         const int b = list[o + p];
         const int e = b % B, r = b / B;
         if (e < me) {
             writers += (r < 2) ? 1 : 0;
             if (e > best) { best = e; best_role = r; }
-        } else if (e > me && e < nx) {
-            nx = e;
+        } else if (e > me) {
+            ++nx;
         }
     }
     wo[a] = writers;
@@ -333,8 +344,10 @@ __device__ __forceinline__ void emit_row(const Row &r, int k, int lane, double t
 // One (s1, s2) pair of the update block (utils/util.py:509-564).  Returns the
 // new length of s1's dictionary; lane j < length holds entry j in (ok, ot, ow).
 __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
-                                 const Row &r2, u64 newkey, double newts, u64 &ok, double &ot, double &ow)
+                                 const Row &r2, u64 newkey, double newts, u64 &ok, double &ot, double &ow,
+                                 int g_stamp_i = -1)
 {
+    STAMP2(0);
     int n1;
     double scale_s1 = 0.0, scale_s2;
     if (r1.norm == 0.0) {                       // :514-519
@@ -348,14 +361,24 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     }
     if (lane < n1) { L.key[lane] = r1.key; L.ts[lane] = r1.ts; L.w[lane] = r1.w * scale_s1; }
     wave_sync();
+    STAMP2(1);
     int n = n1;
     if (r2.norm != 0.0) {                       // :532-538
         const bool active = lane < r2.len;
         const double add = r2.w * scale_s2;
         int f = -1;
-        for (int q = 0; q < n1; ++q) {
-            const bool hit = (L.key[q] == r2.key) && (L.ts[q] == r2.ts);
-            f = (hit && f < 0) ? q : f;
+        // all lanes read the same LDS words (broadcast); 8 entries are fetched before they are
+        // compared so that the LDS latency is paid once per 8, not once per entry
+        for (int q0 = 0; q0 < n1; q0 += 8) {
+            u64 kq[8];
+            double tq[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { kq[t] = L.key[(q0 + t) & (CAP - 1)]; tq[t] = L.ts[(q0 + t) & (CAP - 1)]; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool hit = (q0 + t < n1) && (kq[t] == r2.key) && (tq[t] == r2.ts);
+                f = (hit && f < 0) ? q0 + t : f;
+            }
         }
         const bool unmatched = active && f < 0;
         const u64 um = __ballot(unmatched);
@@ -367,6 +390,7 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         n = n1 + __popcll(um);
         wave_sync();
     }
+    STAMP2(2);
     {                                           // :531 / :540-541
         const double v = (alpha != 0.0) ? scale_s2 * alpha : scale_s2;
         int f = -1;
@@ -382,17 +406,20 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         if (f < 0) ++n;
         wave_sync();
     }
+    STAMP2(3);
     if (n <= k) {                               // :549-551
         if (lane < n) { ok = L.key[lane]; ot = L.ts[lane]; ow = L.w[lane]; }
         wave_sync();
         return n;
     }
     topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);   // :553-559
+    STAMP2(4);
     if (lane < k) {
         const int c = L.sel[lane];
         ok = L.key[c]; ot = L.ts[c]; ow = L.w[c];
     }
     wave_sync();
+    STAMP2(5);
     return k;
 }
 
@@ -481,6 +508,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
     const int lane = lane_id();
     const int k = h.k;
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) return;   // rejected by k_count: touch nothing
+    __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     const int total = B * n_models;
     const unsigned tag_base = epoch << ORD_BITS;
     for (;;) {
@@ -497,14 +525,15 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
         const int m = m_lo + mo;
         const double alpha = h.alpha[m], beta = h.beta[m];
         unsigned *done = h.done + (long long)m * MAX_CHUNK;
+        STAMP(0);
 
         // ---- dependencies of this edge's three accesses ----
-        int my_wo = 0, my_pf = -1, my_nx = 0x7fffffff;
+        int my_wo = 0, my_pf = -1, my_nx = 0;
         if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i]; }
         if (my_pf >= 0) wait_flag(done + my_pf, epoch, h.ctl + 2);   // a reader before me has not read yet
         const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
-        // the endpoint whose next toucher comes first is merged and published first
-        const bool v_first = __shfl(my_nx, 1) < __shfl(my_nx, 0);
+        // the endpoint with the longer chain still waiting behind it is merged and published first
+        const bool v_first = __shfl(my_nx, 1) > __shfl(my_nx, 0);
 
         const long long u = nodes[i], v = nodes[role_stride + i];
         const long long g = n_roles == 3 ? nodes[2 * role_stride + i] : u;
@@ -526,6 +555,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
         if (v == u) rv = ru;
         if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
 
+        STAMP(1);
         // ---- all reads done: later writers of these rows may go ahead ----
         st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see above)
 
@@ -540,8 +570,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
             double nt = 0, nw = 0;
             // (edge_idx, s2, ts) is the key entering s1's dictionary
             int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
-                               nt, nw);
+                               nt, nw, mo == 0 ? i : -1);
             store_row(h, m, x1, lane, n, nk, nt, nw, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
+            STAMP(2);
             if (u != v) {
                 n = merge_pair(L, lane, k, alpha, beta, r2, r1, ((u64)(unsigned)e << 32) | (u64)(unsigned)x1, tnow, nk,
                                nt, nw);
@@ -561,6 +592,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
                 emit_row(rg, k, lane, tnow, out_nodes + rg_o, out_eidx + rg_o, out_dt + rg_o, out_w + rg_o);
             }
         }
+        STAMP(3);
     }
 }
 
@@ -683,7 +715,11 @@ static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, cons
     const int m_lo = model < 0 ? 0 : model;
     const int n_models = model < 0 ? h->M : 1;
     long long waves = (long long)B * n_models;
-    const long long max_waves = (long long)h->n_cu * WAVES_PER_WG * 2;
+    // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
+    // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
+    // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 4 waves).
+    static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
+    const long long max_waves = (long long)(h->n_cu * WAVES_PER_WG * wgs_per_cu);
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
     ZT_PROF_BEGIN(s, P_STREAM);
@@ -725,6 +761,46 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
                               emit ? out_w_dev + oo : nullptr, s);
         if (rc != ZT_OK) return rc;
     }
+    return ZT_OK;
+}
+
+#ifdef ZT_STAMP
+extern "C" int zt_debug_stamps(long long *host, int n)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n * 4));
+    return ZT_OK;
+}
+extern "C" int zt_debug_stamps2(long long *host, int n)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(long long) * n * 8));
+    return ZT_OK;
+}
+#endif
+
+// A HIP stream restricted to the compute units [cu_lo, cu_hi): lets the latency-bound T-PPR
+// kernel run beside the throughput-bound aggregation without sharing CUs with it.
+extern "C" int zt_stream_create_masked(void **out, int32_t cu_lo, int32_t cu_hi)
+{
+    if (!out || cu_lo < 0 || cu_hi <= cu_lo) { set_error("zt_stream_create_masked: bad argument"); return ZT_ERR_ARG; }
+    hipDeviceProp_t prop;
+    int dev = 0;
+    ZT_HIP(hipGetDevice(&dev));
+    ZT_HIP(hipGetDeviceProperties(&prop, dev));
+    const int n = prop.multiProcessorCount;
+    if (cu_hi > n) cu_hi = n;
+    std::vector<uint32_t> mask((n + 31) / 32, 0u);
+    for (int c = cu_lo; c < cu_hi; ++c) mask[c / 32] |= 1u << (c % 32);
+    hipStream_t s;
+    ZT_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    *out = s;
+    return ZT_OK;
+}
+
+extern "C" int zt_stream_destroy(void *stream)
+{
+    if (stream) ZT_HIP(hipStreamDestroy((hipStream_t)stream));
     return ZT_OK;
 }
 

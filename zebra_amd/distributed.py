@@ -99,8 +99,10 @@ class ShardedTGN:
                               check_status=check_status)
         p0, p1 = shard_range(2 * B, self.rank, self.world)
         tgn.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=(p0, p1))
-        tgn.memory_updater.update_device(tgn.memory, tgn._uniq, p1 - p0, tgn._n_uniq)
+        # only this rank's winners are flagged: the GRU compacts them out of the endpoint list
+        tgn.memory_updater.update_device(tgn.memory, nodes_d[: 2 * B], 2 * B)
+        rows, count = tgn.memory_updater.last_rows()
         m = tgn.memory
-        exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], tgn._uniq, tgn._n_uniq,
+        exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,
                               shard_capacity(2 * B, self.world), self.group)
         return emb

@@ -168,6 +168,11 @@ class GRUMemoryUpdater(nn.Module):
                                   C.c_int32(D), C.c_int32(self.message_dimension), ptr(ids_d), C.c_int64(n_ids),
                                   ptr(n_ids_d), C.byref(self._weights()), ptr(ws), stream_ptr()), "zt_gru_update")
 
+    def last_rows(self):
+        """(rows int32[max_rows], count int32[1]) views of the ids the last update_device
+        call updated (layout of the zt_gru_update workspace: count at byte 0, rows at 256)."""
+        return self._ws[256:].view(torch.int32), self._ws[:4].view(torch.int32)
+
     @torch.no_grad()
     def update_memory(self, memory, positives):                 # modules/memory_updater.py:29-43
         ids = torch.as_tensor(np.ascontiguousarray(positives, np.int32), device=self.device)

@@ -70,8 +70,6 @@ class TGN(torch.nn.Module):
         self.affinity_score = MergeLayer(hidden_dim, hidden_dim, hidden_dim, 1)
         # device scratch of the message-store kernel: last occurrence per node (all -1 between calls)
         self._scratch = torch.full((self.n_nodes,), -1, dtype=torch.int32, device=self.device)
-        self._uniq = None
-        self._n_uniq = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.reset_timer()
 
@@ -84,12 +82,11 @@ class TGN(torch.nn.Module):
     # ------------------------------------------------------------------ device protocol
     def store_messages_device(self, src_d, dst_d, ts_d, eidx_d, pos_range=None):
         """get_raw_messages + store_raw_messages (tgn_model.py:204-226) on the device.
-        Leaves the unique endpoint ids in self._uniq[: self._n_uniq].  ``pos_range``
-        = (lo, hi) restricts the work to winners at batch positions lo..hi-1."""
+        ``pos_range`` = (lo, hi) restricts the work to winners at batch positions lo..hi-1.
+        The touched nodes are exactly those whose flag is set afterwards; the GRU update
+        finds them from the (duplicated) endpoint list, no compaction needed here."""
         B = src_d.numel()
         lo, hi = pos_range if pos_range is not None else (0, 2 * B)
-        if self._uniq is None or self._uniq.numel() < 2 * B:
-            self._uniq = torch.empty(2 * B, dtype=torch.int32, device=self.device)
         m = self.memory
         check(lib().zt_store_messages_range(ptr(m.memory), ptr(m.last_update), ptr(self.edge_raw_features),
                                       ptr(self.time_encoder.w.weight), C.c_int64(m.n_nodes),
@@ -97,16 +94,30 @@ class TGN(torch.nn.Module):
                                       C.c_int32(self.n_edge_features), C.c_int32(self.time_dimension), ptr(src_d),
                                       ptr(dst_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B), C.c_int64(lo), C.c_int64(hi),
                                       ptr(m.messages),
-                                      ptr(m.timestamps), ptr(m._flag_buf), ptr(self._scratch), ptr(self._uniq),
-                                      ptr(self._n_uniq), ptr(self._status), stream_ptr()), "zt_store_messages")
+                                      ptr(m.timestamps), ptr(m._flag_buf), ptr(self._scratch), None,
+                                      None, ptr(self._status), stream_ptr()), "zt_store_messages")
         return B
 
     # -- P1 on a side stream: the T-PPR state depends only on the edge stream, never on the node
     # -- memory, so the query of batch b+1 can run while batch b is being aggregated / written back.
-    def enable_pipeline(self, on=True):
-        """Run the T-PPR query on its own HIP stream and allow ``prefetch`` in step_device."""
-        self._side = torch.cuda.Stream(device=self.device) if on else None
+    def enable_pipeline(self, on=True, tppr_cus=0):
+        """Run the T-PPR query on its own HIP stream and allow ``prefetch`` in step_device.
+        ``tppr_cus`` > 0 pins that stream to the first tppr_cus compute units (CU mask) and the
+        caller should run everything else on ``self.main_stream`` (the remaining CUs)."""
         self._pending = None
+        self.main_stream = None
+        if not on:
+            self._side = None
+            return
+        if tppr_cus > 0:
+            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+            hs, hm = C.c_void_p(), C.c_void_p()
+            check(lib().zt_stream_create_masked(C.byref(hs), C.c_int32(0), C.c_int32(tppr_cus)))
+            check(lib().zt_stream_create_masked(C.byref(hm), C.c_int32(tppr_cus), C.c_int32(n_cu)))
+            self._side = torch.cuda.ExternalStream(hs.value, device=self.device)
+            self.main_stream = torch.cuda.ExternalStream(hm.value, device=self.device)
+        else:
+            self._side = torch.cuda.Stream(device=self.device)
 
     def _tppr_launch(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status):
         em = self.embedding_module
@@ -157,7 +168,7 @@ class TGN(torch.nn.Module):
         nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status)
         emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
         B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
-        self.memory_updater.update_device(self.memory, self._uniq, 2 * B, self._n_uniq)
+        self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each
         if check_status:
             st = int(self._status.item())
             if st != 0:
