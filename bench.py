@@ -259,6 +259,15 @@ def main():
         return
 
     edges = a.steps * bs
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (separate
+    # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction; see profiles/make_pmc_summary.py)
+    pmc = {}
+    if world == 1:
+        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % a.workload)
+            if os.path.isfile(pj):
+                pmc = json.load(open(pj)).get("kernels", {})
+                break
     ab = algorithmic_bytes(k, F, M)
     af = algorithmic_flops(k, F, M)
     # dominant kernel = the one with the largest total time in the timed region
@@ -273,7 +282,7 @@ def main():
                 byts = (3 * 110 * 16 + 48 * k) * bs
             ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=None,
+                        frac=ach / HBM_PEAK_GBS, traffic=pmc.get(dom, {}).get("traffic"),
                         note="dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in "
                              "order along per-node chains")
         elif dom == "fc1_agg":
@@ -281,12 +290,12 @@ def main():
             fl = fl * M
             ach = fl / (kern[dom]["avg_us"] * 1e-6) / 1e12
             roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=None)
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=pmc.get(dom, {}).get("traffic"))
         else:
             byts = ab["p3"] * bs
             ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=None)
+                        frac=ach / HBM_PEAK_GBS, traffic=pmc.get(dom, {}).get("traffic"))
 
     cpu = None
     if world == 1 and a.cpu_edges != 0:
@@ -297,10 +306,11 @@ def main():
 
     value = edges / dt
     out = {
-        "metric": "temporal edges/sec embedded (k=%d, %d T-PPR models)" % (k, M),
+        "metric": "temporal edges/sec embedded (k=%d, 2-layer)" % k if M == 2 else
+                  "temporal edges/sec embedded (k=%d, %d T-PPR models)" % (k, M),
         "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64 (T-PPR) / f32 (aggregate, GRU)", "data": "synthetic",
+        "dtype": "f64+f32", "data": "synthetic",
         "config": {"workload": "%s: synthetic %s stream, %d nodes, bs=%d, k=%d, alpha=%s beta=%s, %s T-PPR, F=%d, "
                                "prefill %d + warmup %d batches" % (a.workload, "bipartite" if wl["bipartite"] else
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],

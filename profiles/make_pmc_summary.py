@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
+share a pass on gfx950).  Units and correction as MI355X_MICROARCH.md "HBM" prescribes: the counters
+are in KB; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (doubled here; 8-byte-per-lane
+accesses are uncalibrated, so the corrected read figure is an upper bound for the T-PPR kernel);
+WRITE_SIZE is exact.
+
+    python profiles/make_pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <last_n> <workload>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter, last):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v[-last:]) / len(v[-last:]) for k, v in agg.items()}
+
+
+def main():
+    fetch, write, last, workload = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    f, w = per_kernel(fetch, "FETCH_SIZE", last), per_kernel(write, "WRITE_SIZE", last)
+    out = {"workload": workload, "launches_averaged": last, "unit": "bytes per launch", "kernels": {}}
+    names = {"k_stream": "tppr_stream", "k_fc1_agg": "fc1_agg", "k_embed_out": "embed_out", "k_gru": "gru_update",
+             "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass"}
+    for k, n in names.items():
+        if k in f or k in w:
+            fr, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
+            out["kernels"][n] = {"fetch_raw": fr, "write": wr, "traffic": 2 * fr + wr}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
