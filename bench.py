@@ -161,11 +161,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: ZT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)

@@ -255,6 +255,9 @@ int zt_gru_update(float *memory_dev, float *last_update_dev,
 int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases,
                  int32_t mode, int32_t *sel_out_dev, int32_t *path_out_dev,
                  void *stream);
+/* Test hook: set the T-PPR handle's launch epoch (the row tags' high bits), to
+ * exercise the wrap-around (all tags are cleared when it reaches 2^18 - 1). */
+int zt_test_set_epoch(zt_tppr *h, uint32_t epoch);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,80 @@
+"""Sharded (multi-rank) execution must equal single-rank execution bit for bit.
+Two ranks share the one GPU of the test box (gloo rendezvous, exchange staged
+through the host); on a real node the same code runs one rank per GPU over RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, cfg, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import build_tgn
+    from zebra_amd.distributed import ShardedTGN, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, D, F, T, k, al, be, seed, bs = cfg
+        src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+        w = I.model_weights(D, F, T, len(al), seed)
+        _, efeat = I.random_tables(N, E + 1, D, F, seed)
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        runner = ShardedTGN(tgn, rank, world) if world > 1 else tgn
+        dev = torch.device("cuda")
+        t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+        embs = []
+        for b in range(E // bs):
+            cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
+            embs.append(runner.step_device(*cur).cpu().numpy())
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        m = tgn.memory
+        out[rank] = dict(emb=embs, memory=m.memory.cpu().numpy(), last_update=m.last_update.cpu().numpy(),
+                         messages=m.messages.cpu().numpy(), ts=m.timestamps.cpu().numpy(), flags=m.nodes.copy(),
+                         state=tgn.embedding_module.tppr_finder.export_state(0),
+                         shard=shard_range(3 * bs, rank, world))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single(world):
+    cfg = (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200)
+    mgr = mp.Manager()
+    ref = mgr.dict()
+    mp.spawn(_run, args=(1, _free_port(), cfg, ref), nprocs=1, join=True)
+    out = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
+    single = ref[0]
+    for r in range(world):
+        o = out[r]
+        lo, hi = o["shard"]
+        for b, e in enumerate(o["emb"]):
+            assert np.array_equal(e, single["emb"][b][lo:hi]), "rank %d batch %d embeddings differ" % (r, b)
+        for kk in ("memory", "last_update", "messages", "ts", "flags"):
+            assert np.array_equal(o[kk], single[kk]), "rank %d %s differs from the single-GPU run" % (r, kk)
+        for kk in o["state"]:
+            assert np.array_equal(o["state"][kk], single["state"][kk])

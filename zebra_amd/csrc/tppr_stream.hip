@@ -804,6 +804,14 @@ extern "C" int zt_stream_destroy(void *stream)
     return ZT_OK;
 }
 
+// test hook: move the launch epoch (e.g. next to its wrap-around)
+extern "C" int zt_test_set_epoch(zt_tppr *h, uint32_t epoch)
+{
+    if (!h) return ZT_ERR_ARG;
+    h->epoch = epoch > EPOCH_MAX ? EPOCH_MAX : epoch;
+    return ZT_OK;
+}
+
 extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
 {
     if (!h) return ZT_ERR_ARG;

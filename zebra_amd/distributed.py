@@ -72,8 +72,14 @@ def exchange_touched_rows(tables, ids, n_valid, cap, group=None):
     (cap rows per rank), one collective."""
     world = dist.get_world_size(group)
     send = pack_rows(tables, ids, n_valid, cap)
-    recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU in tests): gloo has no GPU all-gather
+        recv_h = torch.empty((world * cap, send.shape[1]), dtype=torch.float32)
+        dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
+        recv = recv_h.to(send.device)
+    else:
+        recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
     return unpack_rows(tables, recv)
 
 
