@@ -245,9 +245,9 @@ __device__ inline void numba_argsort_reg(const double *a, int n, SortLds &S)
             rl = __shfl(r, sl); rm = __shfl(r, sm); rh = __shfl(r, sh);
             al = shfl_f64(v, sl); am = shfl_f64(v, sm); ah = shfl_f64(v, sh);
         }
-        if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
-        if (lt_f(ah, am)) { int t = rh; rh = rm; rm = t; double x = ah; ah = am; am = x; }
-        if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+        if (am < al) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+        if (ah < am) { int t = rh; rh = rm; rm = t; double x = ah; ah = am; am = x; }
+        if (am < al) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
         const double pivot = am;
         if (act) {                                     // pivot stashed at `hi`
             if (p == lo) { r = rl; v = al; }
@@ -256,7 +256,7 @@ __device__ inline void numba_argsort_reg(const double *a, int n, SortLds &S)
         }
         // ---- stops over lo .. hi-1, ranks inside the segment ----
         const bool in = act && p <= hi - 1;
-        const bool ge = in && !lt_f(v, pivot), le = in && !lt_f(pivot, v);
+        const bool ge = in && !(v < pivot), le = in && !(pivot < v);   // no NaN here: lt(a,b) == a < b
         const u64 GE = __ballot(ge), LE = __ballot(le);
         // bits lo .. hi-1 of my segment (act => hi-1 >= lo, hi-1 <= 62)
         const u64 seg = act ? ((((1ull << (hi - 1)) << 1) - 1ull) & ~((1ull << lo) - 1ull)) : 0ull;

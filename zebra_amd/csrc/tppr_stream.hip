@@ -343,11 +343,22 @@ __device__ __forceinline__ void emit_row(const Row &r, int k, int lane, double t
 
 // One (s1, s2) pair of the update block (utils/util.py:509-564).  Returns the
 // new length of s1's dictionary; lane j < length holds entry j in (ok, ot, ow).
+__device__ __forceinline__ u64 readlane_u64(u64 x, int src /* wave-uniform */)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
                                  const Row &r2, u64 newkey, double newts, u64 &ok, double &ot, double &ow,
                                  int g_stamp_i = -1)
 {
     STAMP2(0);
+    // A lone wave issues one vector instruction per ~4 cycles, so this routine is written for
+    // instruction count: candidates stay in registers (s1's entries in lanes [0,n1), s2's in lanes
+    // [0,len2)), matches are found by broadcasting the SHORTER side with v_readlane, and LDS is
+    // touched once (the candidate list the top-k prune permutes).
     int n1;
     double scale_s1 = 0.0, scale_s2;
     if (r1.norm == 0.0) {                       // :514-519
@@ -359,53 +370,58 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         scale_s1 = r1.norm / new_norm * beta;
         scale_s2 = beta / new_norm * (1.0 - alpha);
     }
-    if (lane < n1) { L.key[lane] = r1.key; L.ts[lane] = r1.ts; L.w[lane] = r1.w * scale_s1; }
-    wave_sync();
-    STAMP2(1);
-    int n = n1;
-    if (r2.norm != 0.0) {                       // :532-538
-        const bool active = lane < r2.len;
-        const double add = r2.w * scale_s2;
-        int f = -1;
-        // all lanes read the same LDS words (broadcast); 8 entries are fetched before they are
-        // compared so that the LDS latency is paid once per 8, not once per entry
-        for (int q0 = 0; q0 < n1; q0 += 8) {
-            u64 kq[8];
-            double tq[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { kq[t] = L.key[(q0 + t) & (CAP - 1)]; tq[t] = L.ts[(q0 + t) & (CAP - 1)]; }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const bool hit = (q0 + t < n1) && (kq[t] == r2.key) && (tq[t] == r2.ts);
-                f = (hit && f < 0) ? q0 + t : f;
+    const bool in1 = lane < n1;
+    double w1 = r1.w * scale_s1;                // t_s1_PPR[key] = value * scale_s1
+    const int len2 = (r2.norm != 0.0) ? r2.len : 0;   // :530-538
+    const bool in2 = lane < len2;
+    const double add = r2.w * scale_s2;
+    bool matched2 = false;                      // this lane's s2 entry met its key in s1
+    const u64 ts1b = (u64)__double_as_longlong(r1.ts), ts2b = (u64)__double_as_longlong(r2.ts);
+    if (len2 <= n1) {
+        for (int q = 0; q < len2; ++q) {        // broadcast s2's entry q; s1 lanes compare
+            const u64 kq = readlane_u64(r2.key, q), tq = readlane_u64(ts2b, q);
+            const bool hit = in1 && r1.key == kq && r1.ts == __longlong_as_double((long long)tq);
+            const u64 hm = __ballot(hit);
+            if (hm != 0ull) {
+                const double aq = __longlong_as_double((long long)readlane_u64((u64)__double_as_longlong(add), q));
+                if (hit) w1 = w1 + aq;          // t_s1_PPR[key] += value * scale_s2
+                if (lane == q) matched2 = true;
             }
         }
-        const bool unmatched = active && f < 0;
-        const u64 um = __ballot(unmatched);
-        if (active && f >= 0) L.w[f] = L.w[f] + add;
-        if (unmatched) {
-            const int pos = n1 + __popcll(um & lanemask_lt());
-            L.key[pos] = r2.key; L.ts[pos] = r2.ts; L.w[pos] = add;
-        }
-        n = n1 + __popcll(um);
-        wave_sync();
-    }
-    STAMP2(2);
-    {                                           // :531 / :540-541
-        const double v = (alpha != 0.0) ? scale_s2 * alpha : scale_s2;
-        int f = -1;
-        for (int c = lane; c < CAP; c += WAVE) {
-            const bool hit = c < n && L.key[c] == newkey && L.ts[c] == newts;
+    } else {
+        for (int q = 0; q < n1; ++q) {          // broadcast s1's entry q; s2 lanes compare
+            const u64 kq = readlane_u64(r1.key, q), tq = readlane_u64(ts1b, q);
+            const bool hit = in2 && r2.key == kq && r2.ts == __longlong_as_double((long long)tq);
             const u64 hm = __ballot(hit);
-            if (hm != 0ull && f < 0) f = (c - lane) + __ffsll((long long)hm) - 1;
+            if (hm != 0ull) {
+                const int j = __ffsll((long long)hm) - 1;
+                const double aj = __longlong_as_double((long long)readlane_u64((u64)__double_as_longlong(add), j));
+                if (lane == q) w1 = w1 + aj;
+                if (hit) matched2 = true;
+            }
         }
-        if (lane == 0) {
-            if (f >= 0) L.w[f] = v;
-            else { L.key[n] = newkey; L.ts[n] = newts; L.w[n] = v; }
-        }
-        if (f < 0) ++n;
-        wave_sync();
     }
+    (void)ts2b;
+    const bool un2 = in2 && !matched2;          // appended after s1's entries, in s2's order
+    const u64 um = __ballot(un2);
+    const int pos2 = n1 + __popcll(um & lanemask_lt());
+    int n = n1 + __popcll(um);
+    // new key (edge_idx, s2, ts): overwrite if present, else append last (:531 / :540-541)
+    const double v = (alpha != 0.0) ? scale_s2 * alpha : scale_s2;
+    const bool h1 = in1 && r1.key == newkey && r1.ts == newts;
+    const bool h2 = un2 && r2.key == newkey && r2.ts == newts;
+    const bool present = __ballot(h1 || h2) != 0ull;
+    if (h1) w1 = v;
+    const double w2 = h2 ? v : add;
+    STAMP2(1);
+    if (in1) { L.key[lane] = r1.key; L.ts[lane] = r1.ts; L.w[lane] = w1; }
+    if (un2) { L.key[pos2] = r2.key; L.ts[pos2] = r2.ts; L.w[pos2] = w2; }
+    if (!present) {
+        if (lane == 0) { L.key[n] = newkey; L.ts[n] = newts; L.w[n] = v; }
+        ++n;
+    }
+    wave_sync();
+    STAMP2(2);
     STAMP2(3);
     if (n <= k) {                               // :549-551
         if (lane < n) { ok = L.key[lane]; ot = L.ts[lane]; ow = L.w[lane]; }
