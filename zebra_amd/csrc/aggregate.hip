@@ -15,8 +15,8 @@
 //               and the normalised T-PPR weight, and reduces over k in LDS.
 //               fc2 is linear, so sum_k w_k*fc2(h_k) = fc2(sum_k w_k*h_k) +
 //               b2*sum_k w_k: only the [N,D] reduced rows go through fc2.
-//   k_embed_out fc2 on the reduced rows, transform_source on memory[nodes],
-//               and the concat into out[N, D*(M+1)].
+//   k_embed_out fc2 on the reduced rows, transform_source on memory[nodes]
+//               (three D x D layers, also f32 MFMA) and the concat into out[N, D*(M+1)].
 // Arithmetic is float32 throughout (parity tolerance for embeddings: 1e-4).
 #include "common.hpp"
 
@@ -42,15 +42,6 @@ __global__ void k_pad_matrix(const float *__restrict__ W, int rows, int cols, fl
     if (i >= rows_p * cols_p) return;
     const int r = i / cols_p, c = i % cols_p;
     Wp[i] = (r < rows && c < cols) ? W[(size_t)r * cols + c] : 0.f;
-}
-
-// Transposed copy W[rows][cols] -> Wt[cols][rows].
-__global__ void k_transpose(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wt)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i % cols;
-    Wt[(size_t)c * rows + r] = W[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -112,18 +103,20 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     // ---- gather: flat (row, column) loops, GU loads in flight per thread before any LDS store
     // ---- (a row-at-a-time loop serialises on HBM latency: 20 rows x ~3 us per wave)
     constexpr int GU = 8;
+    const unsigned mD = fastdiv_magic((unsigned)D), mF = fastdiv_magic((unsigned)(F > 0 ? F : 1)),
+                   mT = fastdiv_magic((unsigned)(T > 0 ? T : 1));
     for (int f0 = tid; f0 < rows_p * D; f0 += AGG_THREADS * GU) {
         float v[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * AGG_THREADS;
-            const int g = f / D, c = f - g * D;
+            const int g = fastdiv(f, mD), c = f - g * D;
             v[u] = (f < rows_p * D && g < rows) ? memory[(size_t)g_nb[g] * D + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * AGG_THREADS;
-            const int g = f / D, c = f - g * D;
+            const int g = fastdiv(f, mD), c = f - g * D;
             if (f < rows_p * D) A[(size_t)g * lda + c] = v[u];
         }
     }
@@ -132,23 +125,24 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * AGG_THREADS;
-            const int g = f / F, c = f - g * F;
+            const int g = fastdiv(f, mF), c = f - g * F;
             v[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * AGG_THREADS;
-            const int g = f / F, c = f - g * F;
+            const int g = fastdiv(f, mF), c = f - g * F;
             if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
         }
     }
     for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
-        const int g = f / T, c = f - g * T;
-        A[(size_t)g * lda + D + F + c] = g < rows ? cosf(g_dt[g] * time_w[c]) : 0.f;   // cos(t*w + 0)
+        const int g = fastdiv(f, mT), c = f - g * T;
+        A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(g_dt[g] * time_w[c]) : 0.f;   // cos(t*w + 0)
     }
     const int padw = K1p - K1;
+    const unsigned mP = fastdiv_magic((unsigned)(padw > 0 ? padw : 1));
     for (int f = tid; f < rows_p * padw; f += AGG_THREADS) {
-        const int g = f / padw, c = f - g * padw;
+        const int g = fastdiv(f, mP), c = f - g * padw;
         A[(size_t)g * lda + K1 + c] = 0.f;
     }
     __syncthreads();
@@ -221,7 +215,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     __syncthreads();
     // ---- reduce over the k neighbours of each query row ----
     for (int idx = tid; idx < nq * D; idx += AGG_THREADS) {
-        const int q = idx / D, c = idx % D;
+        const int q = fastdiv(idx, mD), c = idx - q * D;
         float s = 0.f;
         for (int j = 0; j < k; ++j) s += Hs[(size_t)(q * k + j) * ldh + c];
         H[((size_t)m * N + q0 + q) * D + c] = s;
@@ -230,90 +224,127 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 
 // ---------------------------------------------------------------------------
 // out[n] = [ fc2s(relu(fc1s(memory[nodes[n]]))) | fc2(H_0[n]) + b2*S_0[n] | ... ]
-// Weights arrive transposed (Wt[in][out]) so that lanes read them coalesced.
-// One workgroup per 16 rows; thread = (output column, row half).
+// Three small D x D layers on f32 MFMA.  One workgroup per 32 rows; the input
+// rows sit in LDS, weights ([Dp][Dp], zero padded) stream from L2 as b128
+// fragments; wave w owns output N-tiles {w, w+4}.
 // ---------------------------------------------------------------------------
-constexpr int OUT_ROWS = 16;
+constexpr int OUT_ROWS = 32;
+constexpr int OUT_MT = OUT_ROWS / 16;
 
-__global__ __launch_bounds__(256) void k_embed_out(const float *__restrict__ memory, long long num_nodes,
-                                                   const int *__restrict__ nodes, long long N, int D, int M,
-                                                   const float *__restrict__ H, const float *__restrict__ S,
-                                                   const float *__restrict__ fc2_t, const float *__restrict__ fc2_b,
-                                                   const float *__restrict__ fc1s_t, const float *__restrict__ fc1s_b,
-                                                   const float *__restrict__ fc2s_t, const float *__restrict__ fc2s_b,
-                                                   float *__restrict__ out, int *status)
+// acc[a][b] = X[a-th 16 rows] * W[b-th owned N-tile]^T   (X in LDS [32][ldx], W padded [Dp][Dp])
+__device__ __forceinline__ void small_gemm(const float *X, int ldx, const float *__restrict__ Wp, int Dp, int NT,
+                                           int wave, int lane, f32x4 (&acc)[OUT_MT][NTW])
+{
+    const int r16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < Dp / 16; ++kc) {
+        f32x4 av[OUT_MT];
+#pragma unroll
+        for (int a = 0; a < OUT_MT; ++a)
+            av[a] = *reinterpret_cast<const f32x4 *>(X + (size_t)(a * 16 + r16) * ldx + 16 * kc + 4 * g4);
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            const int nt = wave + b * AGG_WAVES;
+            if (nt >= NT) continue;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(Wp + (size_t)(nt * 16 + r16) * Dp + 16 * kc + 4 * g4);
+#pragma unroll
+            for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bv[j], acc[a][b], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
+    const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
+    const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
+    const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
+    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *X = reinterpret_cast<float *>(smem);          // [OUT_ROWS][D] input rows
-    float *Y = X + OUT_ROWS * D;                         // [OUT_ROWS][D] hidden rows (source path)
-    const int tid = threadIdx.x;
+    const int Dp = (D + 15) / 16 * 16, ldx = Dp + 4, NT = Dp / 16;
+    float *X = reinterpret_cast<float *>(smem);          // [32][ldx] layer input
+    float *Y = X + OUT_ROWS * ldx;                       // [32][ldx] hidden rows of the source path
+    int *rid = reinterpret_cast<int *>(Y + OUT_ROWS * ldx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
     const long long r0 = (long long)blockIdx.x * OUT_ROWS;
     const int nr = (int)((N - r0) < OUT_ROWS ? (N - r0) : OUT_ROWS);
     const int OW = D * (M + 1);
-    const int col = tid % 128, half = tid / 128;          // rows [half*8, half*8+8)
+    const unsigned mL = fastdiv_magic((unsigned)ldx);
+    f32x4 acc[OUT_MT][NTW];
 
-    // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
-    for (int idx = tid; idx < OUT_ROWS * D; idx += 256) {
-        const int r = idx / D, c = idx % D;
-        float v = 0.f;
-        if (r < nr) {
-            int nd = nodes[r0 + r];
+    if (tid < OUT_ROWS) {
+        int nd = 0;
+        if (tid < nr) {
+            nd = nodes[r0 + tid];
             if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
-            v = memory[(size_t)nd * D + c];
         }
-        X[idx] = v;
+        rid[tid] = nd;
     }
     __syncthreads();
-    if (col < D) {
-        float acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = fc1s_b[col];
-        for (int i = 0; i < D; ++i) {
-            const float wv = fc1s_t[(size_t)i * D + col];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] += X[(half * 8 + r) * D + i] * wv;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) Y[(half * 8 + r) * D + col] = acc[r] > 0.f ? acc[r] : 0.f;
+    // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
+    for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
+        const int g = fastdiv(f, mL), c = f - g * ldx;
+        X[f] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
     }
     __syncthreads();
-    if (col < D) {
-        float acc[8];
+    small_gemm(X, ldx, fc1s_p, Dp, NT, wave, lane, acc);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = fc2s_b[col];
-        for (int i = 0; i < D; ++i) {
-            const float wv = fc2s_t[(size_t)i * D + col];
+    for (int b = 0; b < NTW; ++b) {
+        const int col = (wave + b * AGG_WAVES) * 16 + r16;
+        if (col >= Dp) continue;
+        const float bias = col < D ? fc1s_b[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] += Y[(half * 8 + r) * D + i] * wv;
-        }
+        for (int a = 0; a < OUT_MT; ++a)
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (half * 8 + r < nr) out[(size_t)(r0 + half * 8 + r) * OW + col] = acc[r];
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[a][b][j] + bias;
+                Y[(size_t)(a * 16 + g4 * 4 + j) * ldx + col] = (col < D && v > 0.f) ? v : 0.f;
+            }
+    }
+    __syncthreads();
+    small_gemm(Y, ldx, fc2s_p, Dp, NT, wave, lane, acc);
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        const int col = (wave + b * AGG_WAVES) * 16 + r16;
+        if (col >= D) continue;
+        const float bias = fc2s_b[col];
+#pragma unroll
+        for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = a * 16 + g4 * 4 + j;
+                if (g < nr) out[(size_t)(r0 + g) * OW + col] = acc[a][b][j] + bias;
+            }
     }
     // ---- neighbour paths: fc2 on the reduced rows of each model ----
     for (int m = 0; m < M; ++m) {
         __syncthreads();
-        for (int idx = tid; idx < OUT_ROWS * D; idx += 256) {
-            const int r = idx / D, c = idx % D;
-            X[idx] = r < nr ? H[((size_t)m * N + r0 + r) * D + c] : 0.f;
+        for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
+            const int g = fastdiv(f, mL), c = f - g * ldx;
+            X[f] = (g < nr && c < D) ? H[((size_t)m * N + r0 + g) * D + c] : 0.f;
         }
         __syncthreads();
-        if (col < D) {
-            float acc[8];
+        small_gemm(X, ldx, fc2_p, Dp, NT, wave, lane, acc);
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            const int col = (wave + b * AGG_WAVES) * 16 + r16;
+            if (col >= D) continue;
             const float bias = fc2_b[col];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int rr = half * 8 + r;
-                acc[r] = rr < nr ? bias * S[(size_t)m * N + r0 + rr] : 0.f;
-            }
-            for (int i = 0; i < D; ++i) {
-                const float wv = fc2_t[(size_t)i * D + col];
+            for (int a = 0; a < OUT_MT; ++a)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) acc[r] += X[(half * 8 + r) * D + i] * wv;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r)
-                if (half * 8 + r < nr) out[(size_t)(r0 + half * 8 + r) * OW + (size_t)D * (m + 1) + col] = acc[r];
+                for (int j = 0; j < 4; ++j) {
+                    const int g = a * 16 + g4 * 4 + j;
+                    if (g < nr)
+                        out[(size_t)(r0 + g) * OW + (size_t)D * (m + 1) + col] =
+                            acc[a][b][j] + bias * S[(size_t)m * N + r0 + g];
+                }
         }
     }
 }
@@ -351,9 +382,9 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     p.off_w1p = take((size_t)p.Dp * p.K1p * 4);
     p.off_H = take((size_t)M * N * D * 4);
     p.off_S = take((size_t)M * N * 4);
-    p.off_fc2t = take((size_t)D * D * 4);
-    p.off_fc1st = take((size_t)D * D * 4);
-    p.off_fc2st = take((size_t)D * D * 4);
+    p.off_fc2t = take((size_t)p.Dp * p.Dp * 4);
+    p.off_fc1st = take((size_t)p.Dp * p.Dp * 4);
+    p.off_fc2st = take((size_t)p.Dp * p.Dp * 4);
     p.total = o;
     return true;
 }
@@ -400,9 +431,9 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     const int K1 = D + F + T;
     ZT_PROF_BEGIN(s, P_EMBED_PREP);
     k_pad_matrix<<<(p.Dp * p.K1p + 255) / 256, 256, 0, s>>>(wt->fc1_w, D, K1, W1p, p.Dp, p.K1p);
-    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2_w, D, D, fc2t);
-    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc1s_w, D, D, fc1st);
-    k_transpose<<<(D * D + 255) / 256, 256, 0, s>>>(wt->fc2s_w, D, D, fc2st);
+    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc2_w, D, D, fc2t, p.Dp, p.Dp);
+    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc1s_w, D, D, fc1st, p.Dp, p.Dp);
+    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc2s_w, D, D, fc2st, p.Dp, p.Dp);
     ZT_PROF_END(s, P_EMBED_PREP);
     static size_t attr_lds = 0;
     if (p.lds > 48 * 1024 && p.lds > attr_lds) {
@@ -417,8 +448,8 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
                                                wt->fc1_b, H, S, status_dev);
     ZT_PROF_END(s, P_FC1_AGG);
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
-    const size_t lds2 = (size_t)2 * OUT_ROWS * D * 4;
-    k_embed_out<<<(unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), 256, lds2, s>>>(
+    const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
+    k_embed_out<<<(unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), AGG_THREADS, lds2, s>>>(
         memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
         out_dev, status_dev);
     ZT_PROF_END(s, P_EMBED_OUT);

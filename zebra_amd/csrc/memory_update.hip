@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_build_messages(
         for (int c = lane; c < D; c += WAVE) row[c] = m1[c];
         for (int c = lane; c < D; c += WAVE) row[D + c] = m2[c];
         for (int c = lane; c < F; c += WAVE) row[2 * D + c] = er[c];
-        for (int c = lane; c < T; c += WAVE) row[2 * D + F + c] = cosf(delta * time_w[c]);
+        for (int c = lane; c < T; c += WAVE) row[2 * D + F + c] = time_cosf(delta * time_w[c]);
         if (lane == 0) {
             msg_ts[v] = tf;
             flags[v] = 1;
