@@ -246,6 +246,33 @@ int zt_gru_update(float *memory_dev, float *last_update_dev,
                   void *workspace_dev, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* TemporalAttentionLayer.forward -- model/temporal_attention.py:7-68        */
+/*   NOT on the reference's live path (never reachable from train.py); built */
+/*   because the north star names it.  Eval forward (dropout = identity).    */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const float *q_w;            /* multi_head_target.q_proj_weight [E][E], E = D+T      */
+    const float *k_w, *v_w;      /* k_proj_weight, v_proj_weight    [E][Ek], Ek = D+F+T   */
+    const float *in_b;           /* in_proj_bias [3E] (q, k, v)                          */
+    const float *out_w, *out_b;  /* out_proj [E][E], [E]                                 */
+    const float *m1_w, *m1_b;    /* merger.fc1 [hidden][E+D], [hidden]                   */
+    const float *m2_w, *m2_b;    /* merger.fc2 [out_dim][hidden], [out_dim]              */
+} zt_attn_weights;               /* device pointers */
+
+/*   src [N][D], src_time [N][T], nbr_feat [N][k][D], edge_feat [N][k][F],
+ *   nbr_time [N][k][T], mask uint8 [N][k] (non-zero = padding)
+ *   -> out [N][out_dim], attn_w [N][k] (head-averaged attention weights). */
+int64_t zt_attention_workspace_bytes(int32_t D, int32_t F, int32_t T, int32_t n_head,
+                                     int32_t hidden, int32_t out_dim, int32_t k);
+int zt_temporal_attention(const float *src_dev, const float *src_time_dev,
+                          const float *nbr_feat_dev, const float *edge_feat_dev,
+                          const float *nbr_time_dev, const uint8_t *mask_dev, int64_t N,
+                          int32_t k, int32_t D, int32_t F, int32_t T, int32_t n_head,
+                          int32_t hidden, int32_t out_dim, const zt_attn_weights *weights,
+                          float *out_dev, float *attn_w_dev, void *workspace_dev,
+                          void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Test hook (not product API): the exact top-k selection primitive on its    */
 /* own.  vals [cases][n] float64; writes np.argsort(vals[c])[-k:] under       */
 /* numba's quicksort semantics into sel_out [cases][k] and the path taken     */

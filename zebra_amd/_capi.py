@@ -26,13 +26,17 @@ SYMBOLS = [
     "zt_tppr_export", "zt_tppr_import",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
     "zt_embed_workspace_bytes", "zt_embed",
-    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_test_topk", "zt_test_set_epoch",
+    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
 ]
 
 
 class EmbedWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "fc1s_w", "fc1s_b", "fc2s_w",
                                           "fc2s_b", "time_w")]
+
+
+class AttnWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q_w", "k_w", "v_w", "in_b", "out_w", "out_b", "m1_w", "m1_b", "m2_w", "m2_b")]
 
 
 class GruWeights(C.Structure):
@@ -53,7 +57,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.zt_last_error.restype = C.c_char_p
         _lib.zt_version.restype = C.c_char_p
-        for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes"):
+        for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes", "zt_attention_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib

@@ -21,6 +21,7 @@ SOURCES = {
     "tppr_prune.hip": ["-ffp-contract=off"],
     "aggregate.hip": [],
     "memory_update.hip": [],
+    "attention.hip": [],
     "test_hooks.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -8,6 +8,7 @@ driver written against it (and its ``state_dict``) keeps working:
   Memory                    modules/memory.py:7-60
   GRUMemoryUpdater          modules/memory_updater.py:19-98
   GraphDiffusionEmbedding   modules/embedding_module.py:76-336
+  TemporalAttentionLayer    model/temporal_attention.py:7-68 (dead code in the reference)
 
 Eval-mode forward (the path the metric is defined on) runs entirely in
 libzebra_amd.so.  ``train=True`` needs autograd through the aggregation and
@@ -387,6 +388,73 @@ class GraphDiffusionEmbedding(nn.Module):
 
     def combine(self, x):
         return self.combiner(x)
+
+
+class TemporalAttentionLayer(nn.Module):
+    """model/temporal_attention.py:7-68.  Dead code in the reference (only GraphAttentionEmbedding builds it
+    and train.py can never reach that class); provided because the north star names it.
+    Without grad (eval) the forward runs in libzebra_amd.so; with grad it is the torch restatement below,
+    which is also what the HIP kernel is tested against (no reference outputs exist)."""
+
+    def __init__(self, n_node_features, n_neighbors_features, n_edge_features, time_dim, output_dimension,
+                 n_head=2, dropout=0.1):
+        super().__init__()
+        self.n_head = n_head
+        self.feat_dim = n_node_features
+        self.time_dim = time_dim
+        self.query_dim = n_node_features + time_dim
+        self.key_dim = n_neighbors_features + time_dim + n_edge_features
+        self.n_edge_features = n_edge_features
+        self.output_dimension = output_dimension
+        self.merger = MergeLayer(self.query_dim, n_node_features, n_node_features, output_dimension)
+        self.multi_head_target = nn.MultiheadAttention(embed_dim=self.query_dim, kdim=self.key_dim,
+                                                       vdim=self.key_dim, num_heads=n_head, dropout=dropout)
+        self._ws = None
+
+    def forward_torch(self, src_node_features, src_time_features, neighbors_features, neighbors_time_features,
+                      edge_features, neighbors_padding_mask):
+        query = torch.cat([src_node_features.unsqueeze(1), src_time_features], dim=2).permute([1, 0, 2])
+        key = torch.cat([neighbors_features, edge_features, neighbors_time_features], dim=2).permute([1, 0, 2])
+        mask = neighbors_padding_mask.clone()
+        invalid = mask.all(dim=1, keepdim=True)
+        mask[invalid.squeeze(1), 0] = False
+        out, w = self.multi_head_target(query=query, key=key, value=key, key_padding_mask=mask)
+        out = out.squeeze(0).masked_fill(invalid, 0)
+        w = w.squeeze(1).masked_fill(invalid, 0)
+        return self.merger(out, src_node_features), w
+
+    def forward(self, src_node_features, src_time_features, neighbors_features, neighbors_time_features,
+                edge_features, neighbors_padding_mask):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            return self.forward_torch(src_node_features, src_time_features, neighbors_features,
+                                      neighbors_time_features, edge_features, neighbors_padding_mask)
+        N, k, D = neighbors_features.shape
+        T, F = self.time_dim, edge_features.shape[2]
+        E = self.query_dim
+        need = lib().zt_attention_workspace_bytes(C.c_int32(D), C.c_int32(F), C.c_int32(T), C.c_int32(self.n_head),
+                                                  C.c_int32(self.feat_dim), C.c_int32(self.output_dimension),
+                                                  C.c_int32(k))
+        if need < 0:
+            raise ValueError("zt_temporal_attention: unsupported shape")
+        dev = src_node_features.device
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        mha = self.multi_head_target
+        c = lambda t: t.detach().contiguous().float()
+        ten = [c(src_node_features), c(src_time_features.reshape(N, T)), c(neighbors_features), c(edge_features),
+               c(neighbors_time_features), neighbors_padding_mask.detach().to(torch.uint8).contiguous()]
+        wts = [c(mha.q_proj_weight), c(mha.k_proj_weight), c(mha.v_proj_weight), c(mha.in_proj_bias),
+               c(mha.out_proj.weight), c(mha.out_proj.bias), c(self.merger.fc1.weight), c(self.merger.fc1.bias),
+               c(self.merger.fc2.weight), c(self.merger.fc2.bias)]
+        aw = _capi.AttnWeights(*[ptr(t) for t in wts])
+        out = torch.empty((N, self.output_dimension), dtype=torch.float32, device=dev)
+        attn_w = torch.empty((N, k), dtype=torch.float32, device=dev)
+        check(lib().zt_temporal_attention(ptr(ten[0]), ptr(ten[1]), ptr(ten[2]), ptr(ten[3]), ptr(ten[4]), ptr(ten[5]),
+                                          C.c_int64(N), C.c_int32(k), C.c_int32(D), C.c_int32(F), C.c_int32(T),
+                                          C.c_int32(self.n_head), C.c_int32(self.feat_dim),
+                                          C.c_int32(self.output_dimension), C.byref(aw), ptr(out), ptr(attn_w),
+                                          ptr(self._ws), stream_ptr()), "zt_temporal_attention")
+        return out, attn_w
 
 
 def get_embedding_module(module_type, **kw):
