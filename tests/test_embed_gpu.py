@@ -126,8 +126,9 @@ def test_protocol_vs_oracle(oracle, cfg):
     assert np.array_equal(tgn.memory.nodes.astype(np.uint8), mem.flags)
 
 
-def test_pipelined_step_matches_sequential():
-    """The side-stream T-PPR prefetch must not change any result."""
+@pytest.mark.parametrize("tppr_cus", [0, 32])
+def test_pipelined_step_matches_sequential(tppr_cus):
+    """The side-stream T-PPR prefetch (optionally on CU-masked streams) must not change any result."""
     name = "d100_f1"
     N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
     src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
@@ -139,13 +140,15 @@ def test_pipelined_step_matches_sequential():
     for mode in ("seq", "pipe"):
         tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
         if mode == "pipe":
-            tgn.enable_pipeline()
+            tgn.enable_pipeline(tppr_cus=tppr_cus)
         nbt = E // bs
         embs = []
-        for b in range(nbt):
-            cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
-            nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
-            embs.append(tgn.step_device(*cur, prefetch=nxt).clone())
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            for b in range(nbt):
+                cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
+                nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
+                embs.append(tgn.step_device(*cur, prefetch=nxt).clone())
         torch.cuda.synchronize()
         tgn.embedding_module.tppr_finder.check_status()
         outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(),

@@ -226,7 +226,7 @@ __global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, 
     }
 }
 
-// K3: scatter accesses into their node's range.
+// K3: scatter accesses into their node's range, encoded (edge << 2) | role.
 __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
                        const int *slot, int *list)
 {
@@ -234,7 +234,7 @@ __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int
     if (a >= B * n_roles) return;
     const int s = slot[a];
     if (s < 0) return;
-    list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = a;
+    list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = ((a % B) << 2) | (a / B);   // (edge << 2) | role
 }
 
 // K4: per access, from its node's group:
@@ -251,15 +251,22 @@ __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int
     const int o = off[x], c = cnt[x];
     const int me = a % B;
     int best = -1, best_role = 0, writers = 0, nx = 0;
-#pragma unroll 8
-    for (int p = 0; p < c; ++p) {
-        const int b = list[o + p];
-        const int e = b % B, r = b / B;
-        if (e < me) {
-            writers += (r < 2) ? 1 : 0;
-            if (e > best) { best = e; best_role = r; }
-        } else if (e > me) {
-            ++nx;
+    // 16 list entries are fetched before any is used: a hub's group has hundreds of members and the
+    // loop is otherwise one L2 round trip per entry
+    for (int p0 = 0; p0 < c; p0 += 16) {
+        int b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) b[t] = list[o + ((p0 + t) < c ? (p0 + t) : (c - 1))];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (p0 + t >= c) break;
+            const int e = b[t] >> 2, r = b[t] & 3;
+            if (e < me) {
+                writers += (r < 2) ? 1 : 0;
+                if (e > best) { best = e; best_role = r; }
+            } else if (e > me) {
+                ++nx;
+            }
         }
     }
     wo[a] = writers;
