@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
             continue
         op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         if force or _newer(sp, op) or any(_newer(h, op) for h in headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", sp, "-o", op]
+            cmd = [hipcc] + COMMON + extra + os.environ.get("ZT_EXTRA_HIPFLAGS", "").split() + ["-c", sp, "-o", op]
             if verbose:
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True)

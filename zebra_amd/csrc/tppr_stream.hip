@@ -134,6 +134,13 @@ constexpr int HDR = 4;                 // header granules: len, norm lo, norm hi
 constexpr int ORD_BITS = 14;           // writer ordinal inside one launch
 constexpr int MAX_CHUNK = 8192;        // edges per launch (ordinals must fit ORD_BITS)
 constexpr unsigned EPOCH_MAX = (1u << (32 - ORD_BITS)) - 1;
+// hub chains: the nodes touched most often in a launch get a workgroup of their own
+constexpr int HOT_MIN = 24;            // accesses in one launch that make a node a chain candidate
+constexpr int MAX_HOT = 128;           // candidates kept
+constexpr int MAX_CHAINS = 16;         // chains per model
+constexpr int CTL_LOG = 6;             // timeout reports kept per launch
+constexpr int CTL_WORDS = 16 + 8 * CTL_LOG;
+constexpr int CH_MAX = 2048;           // edges per chain (the rest go through the general queue)
 }  // namespace
 
 struct zt_tppr {
@@ -152,17 +159,30 @@ struct zt_tppr {
     int *pflag;      // edge whose "reads done" flag must be seen first, or -1
     int *nxt;        // number of later edges of the launch touching the access' node (chain still ahead)
     unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
-    // control words (device): [0] cursor, [1] queue head, [2] status
+    // hub chains of the launch
+    int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
+    int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts
+    int *hot_cnt;
+    int *chain_node;   // [MAX_CHAINS]
+    int *chain_len;    // [MAX_CHAINS]
+    int *chain_edges;  // [MAX_CHAINS][CH_MAX] edges owned by the chain, ascending
+    int *owner_of;     // [MAX_CHUNK] chain owning the edge, or -1
+    // control words (device): [0] cursor, [1] queue head, [2] status, [3] hot candidates, [4] chains,
+    // [13] timeout reports, [16..] the reports (see note_timeout)
     int *ctl;
     unsigned epoch;
     int n_cu;
+    // last launch (diagnostics)
+    const int *dbg_nodes;
+    long long dbg_stride;
+    int dbg_B, dbg_roles, dbg_models;
 };
 
 namespace {
 
 constexpr int CAP = 128;          // candidates per merge: 2k+1 <= 127
 constexpr int WAVES_PER_WG = 4;
-constexpr long long WAIT_TICKS = 400000000ll;   // 4 s of the 100 MHz wall clock: bound on any dependency wait
+constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
 #ifdef ZT_STAMP
 __device__ long long g_stamps[8192 * 4];
@@ -172,6 +192,14 @@ __device__ long long g_stamps2[8192 * 8];
 #else
 #define STAMP(slot) do { } while (0)
 #define STAMP2(slot) do { } while (0)
+#endif
+
+#ifdef ZT_WAITLOG
+// diagnostic build only: per (model, edge) task [state, wg*4+wave, wait kind, target, expect, chain pos, by_mail, clock]
+__device__ int g_wl[2 * MAX_CHUNK * 8];
+#define WL(f, v) do { if (mo < 2 && lane == __builtin_ctzll(__ballot(1))) __hip_atomic_store(&g_wl[(mo * MAX_CHUNK + i) * 8 + (f)], (int)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define WL(f, v) do { } while (0)
 #endif
 
 struct WaveLds {
@@ -216,13 +244,79 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
 
 // K2: the first access of each node reserves a contiguous range of `list`.
 __global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
-                          int *off, const int *slot, int *ctl)
+                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
     if (slot[a] == 0) {
         const int x = nodes[(long long)(a / B) * role_stride + a % B];
-        off[x] = atomicAdd(&ctl[0], cnt[x]);
+        const int c = cnt[x];
+        off[x] = atomicAdd(&ctl[0], c);
+        if (c >= HOT_MIN) {                        // hub candidate
+            const int hi = atomicAdd(&ctl[3], 1);
+            if (hi < MAX_HOT) { hot_node[hi] = x; hot_cnt[hi] = c; }
+        }
+    }
+}
+
+// K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
+__global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of, int *chain_node,
+                             int *chain_len, int max_chains)
+{
+    const int t = threadIdx.x;                     // MAX_HOT threads
+    int nh = ctl[3];
+    nh = nh < MAX_HOT ? nh : MAX_HOT;
+    if (t < MAX_CHAINS) chain_len[t] = 0;
+    if (ctl[2] == ZT_ERR_RANGE) { if (t == 0) ctl[4] = 0; return; }
+    int rank = 0;
+    if (t < nh) {
+        const int c = hot_cnt[t], x = hot_node[t];
+        for (int q = 0; q < nh; ++q) {
+            const int cq = hot_cnt[q];
+            rank += (cq > c || (cq == c && hot_node[q] < x)) ? 1 : 0;
+        }
+        if (rank < max_chains) { chain_of[x] = rank; chain_node[rank] = x; }
+    }
+    if (t == 0) ctl[4] = nh < max_chains ? nh : max_chains;
+}
+
+// K2c: every edge with a hub endpoint is owned by that hub's chain (the more-touched hub if both are).
+__global__ void k_own(const int *__restrict__ nodes, long long role_stride, int B, const int *cnt, const int *slot,
+                      const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    int owner = -1;
+    if (slot[i] >= 0 && slot[B + i] != -1) {        // valid edge
+        const int u = nodes[i], v = nodes[role_stride + i];
+        const int cu = chain_of[u], cv = chain_of[v];
+        if (cu >= 0 && (cv < 0 || cnt[u] >= cnt[v])) owner = cu;
+        else if (cv >= 0) owner = cv;
+        if (owner >= 0) {
+            const int p = atomicAdd(&chain_len[owner], 1);
+            if (p < CH_MAX) chain_edges[owner * CH_MAX + p] = i;
+            else owner = -1;                        // chain full: the general queue takes it
+        }
+    }
+    owner_of[i] = owner;
+}
+
+// K2d: one wavefront per chain sorts its edges ascending (rank by counting).
+__global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *chain_len, int *chain_edges)
+{
+    __shared__ int e[CH_MAX];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= ctl[4]) return;
+    int len = chain_len[c];
+    len = len < CH_MAX ? len : CH_MAX;
+    for (int p = lane; p < len; p += 64) e[p] = chain_edges[c * CH_MAX + p];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lane; p < len; p += 64) {
+        const int me = e[p];
+        int r = 0;
+        for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
+        chain_edges[c * CH_MAX + r] = me;           // edge indices are distinct
     }
 }
 
@@ -276,13 +370,16 @@ __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int
 
 // K5: restore the per-node counters and the control words for the next call.
 __global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
-                          int *cnt, int *ctl)
+                          int *cnt, int *ctl, const int *hot_node, int *chain_of)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a == 0) { ctl[0] = 0; ctl[1] = 0; }
+    if (a < MAX_HOT && a < ctl[3]) chain_of[hot_node[a]] = -1;
     if (a >= B * n_roles) return;
     if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
 }
+
+// K6: control words back to zero (after k_cleanup has read ctl[3]).
+__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 5 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
 
 // ------------------------------------------------------------- row access ----
 struct Row {
@@ -472,8 +569,27 @@ __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, 
     }
 }
 
+// A wait gave up: set the status word and log what was being waited for (the first CTL_LOG reports of
+// a launch are kept at ctl[16 + 8 * slot]; zt_tppr_status prints them).  status = ctl + 2.
+__device__ __noinline__ void note_timeout(int *status, int kind, int a, int b, int c, int d)
+{
+    if (lane_id() != (int)__builtin_ctzll(__ballot(1))) return;   // first active lane reports
+    int *ctl = status - 2;
+    const int slot = atomicAdd(ctl + 13, 1);
+    if (slot < CTL_LOG) {
+        int *r = ctl + 16 + 8 * slot;
+        r[0] = kind; r[1] = a; r[2] = b; r[3] = c; r[4] = d; r[5] = (int)blockIdx.x; r[6] = (int)(threadIdx.x / WAVE);
+        r[7] = (int)(wall_clock64() >> 10);
+    }
+    __threadfence();
+    atomicExch(status, ZT_ERR_TIMEOUT);
+}
+
+// One wait of the launch has already timed out: the others stop waiting too (their results are void).
+__device__ __forceinline__ bool launch_failed(const int *status) { return ld_agent(status) == ZT_ERR_TIMEOUT; }
+
 // Spin until flag == epoch (bounded).  Returns false on timeout.
-__device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, int *status)
+__device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, int *status, int what)
 {
     unsigned spins = 0;
     long long t0 = 0;
@@ -482,7 +598,8 @@ __device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, 
         if ((++spins & 1023u) == 0) {
             const long long now = (long long)wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > WAIT_TICKS) { atomicExch(status, ZT_ERR_TIMEOUT); return false; }
+            else if (now - t0 > WAIT_TICKS) { note_timeout(status, 1, what, (int)epoch, (int)ld_agent(flag), 0); return false; }
+            if (launch_failed(status)) return false;
         }
     }
     return true;
@@ -491,14 +608,15 @@ __device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, 
 // Load a row that an earlier edge of this launch rewrites: poll until every
 // granule carries `expect`.  The mismatching tag tells how many chain hops are
 // still ahead, which sets the back-off.
-__device__ inline void load_row_wait(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r,
-                                     int *status)
+__device__ inline bool load_row_wait(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r,
+                                     int *status, unsigned *last_seen = nullptr)
 {
     unsigned polls = 0;
     long long t0 = 0;
     for (;;) {
         const unsigned seen = load_row(h, m, x, lane, expect, r);
-        if (seen == expect) return;
+        if (last_seen) *last_seen = seen;
+        if (seen == expect) return true;
         // hops still to go on this node's chain (tags of older launches count as ordinal 0)
         const unsigned cur = (seen >> ORD_BITS) == (expect >> ORD_BITS) ? (seen & ((1u << ORD_BITS) - 1)) : 0u;
         const unsigned want = expect & ((1u << ORD_BITS) - 1);
@@ -512,28 +630,230 @@ __device__ inline void load_row_wait(const zt_tppr &h, int m, long long x, int l
         if ((++polls & 255u) == 0) {
             const long long now = (long long)wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > WAIT_TICKS) { atomicExch(status, ZT_ERR_TIMEOUT); return; }
+            else if (now - t0 > WAIT_TICKS) { note_timeout(status, 2, (int)x, (int)expect, (int)seen, m); return false; }
+            if (launch_failed(status)) return false;
         }
     }
 }
 
 // ------------------------------------------------------------ main kernel ----
-__global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const int *__restrict__ nodes,
-                                                                const double *__restrict__ tsv,
-                                                                const long long *__restrict__ eidx,
-                                                                long long role_stride, int B, int n_roles, int emit,
-                                                                int m_lo, int n_models, long long out_rows,
-                                                                int *out_nodes, int *out_eidx, float *out_dt,
-                                                                float *out_w, unsigned epoch)
+// LDS mailbox of a chain workgroup: the hub's newest row and the tag it was written with.  The next
+// edge of the chain (held by a sibling wave) takes the row from here -- an LDS round trip instead of a
+// write-through store plus a memory poll.  Single producer (chain task t), single consumer (task t+1).
+struct Mail {
+    u64 key[64];
+    double ts[64];
+    double w[64];
+    double norm;
+    int len;
+    unsigned tag;      // written last
+    int head;          // next position of the chain's edge list
+    int pad;
+};
+
+struct StreamArgs {
+    const int *nodes;
+    const double *tsv;
+    const long long *eidx;
+    long long role_stride;
+    int B, n_roles, emit, m_lo, n_models;
+    long long out_rows;
+    int *out_nodes, *out_eidx;
+    float *out_dt, *out_w;
+    unsigned epoch;
+};
+
+__device__ __forceinline__ unsigned lds_load_tag(const unsigned *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Apply edge i of the launch for emitted model mo.  mail != nullptr: this wave belongs to the chain
+// workgroup of node `hub`; prev_edge = the chain's previous edge (or -1).
+__device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
+                                    long long hub, int prev_edge, int next_edge)
+{
+    const int k = h.k, B = A.B, n_roles = A.n_roles;
+    const int m = A.m_lo + mo;
+    const double alpha = h.alpha[m], beta = h.beta[m];
+    unsigned *done = h.done + (long long)m * MAX_CHUNK;
+    const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS;
+    const long long role_stride = A.role_stride;
+    STAMP(0);
+    WL(0, 1); WL(1, blockIdx.x * 4 + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
+    int wl_fail = 0;
+    unsigned wl_seen = 0;
+
+    // ---- dependencies of this edge's three accesses ----
+    int my_wo = 0, my_pf = -1, my_nx = 0;
+    if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i]; }
+    if (my_pf >= 0 && !wait_flag(done + my_pf, epoch, h.ctl + 2, my_pf)) wl_fail |= 1;   // a reader before me has not read yet
+    wl_fail = __ballot(wl_fail != 0) != 0ull ? 1 : 0;
+    WL(0, 2);
+    const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
+    // the endpoint with the longer chain still waiting behind it is merged and published first
+    const bool v_first = __shfl(my_nx, 1) > __shfl(my_nx, 0);
+
+    const long long u = A.nodes[i], v = A.nodes[role_stride + i];
+    const long long g = n_roles == 3 ? A.nodes[2 * role_stride + i] : u;
+    const double tnow = A.tsv[i];
+    const long long e = A.eidx[i];
+
+    // Does the hub's row reach me through the mailbox?  Yes iff the chain's previous edge is the last
+    // writer of the hub before me (the tag it writes is the one I expect).
+    bool hub_by_mail = false;
+    if (mail != nullptr && prev_edge >= 0) {
+        const int prole = A.nodes[prev_edge] == hub ? 0 : 1;
+        const int prev_out = h.wo[prole * B + prev_edge] + 1;
+        const int mine = (u == hub) ? wo_u : wo_v;
+        hub_by_mail = prev_out == mine;
+    }
+
+    // Must the hub's new row also go to memory?  Not when the chain's next edge takes it from the
+    // mailbox and nobody reads it in between (no reader precedes that edge's access): the next edge's
+    // own row supersedes it.  This is a correctness rule, not only a saving: the mailbox hand-off is
+    // NOT ordered against this wave's row stores, so a successor could otherwise get its (newer) row
+    // into memory before ours and ours would then overwrite it.  Whenever the row IS stored, its next
+    // accessor waits for it in memory (directly, or through a reader's reads-done flag).
+    bool hub_to_memory = true;
+    if (mail != nullptr && next_edge >= 0) {
+        const int nrole = A.nodes[next_edge] == hub ? 0 : 1;
+        const int my_out = ((u == hub) ? wo_u : wo_v) + 1;
+        hub_to_memory = !(h.wo[nrole * B + next_edge] == my_out && h.pflag[nrole * B + next_edge] < 0);
+    }
+
+    // ---- rows: one memory round trip; poll where a writer of this launch precedes us ----
+    Row ru, rv, rg;
+    const bool u_mail = hub_by_mail && u == hub, v_mail = hub_by_mail && v == hub && v != u;
+    unsigned su = 0, sv = 0, sg = 0;
+    if (!u_mail) su = load_row(h, m, u, lane, wo_u ? (tag_base | (unsigned)wo_u) : 0u, ru);
+    if (v != u && !v_mail) sv = load_row(h, m, v, lane, wo_v ? (tag_base | (unsigned)wo_v) : 0u, rv);
+    const bool g_own = n_roles == 3 && g != u && g != v;
+    if (g_own) sg = load_row(h, m, g, lane, wo_g ? (tag_base | (unsigned)wo_g) : 0u, rg);
+    WL(0, 3);
+    if (!u_mail && wo_u && su != (tag_base | (unsigned)wo_u))
+        if (!load_row_wait(h, m, u, lane, tag_base | (unsigned)wo_u, ru, h.ctl + 2, &wl_seen)) wl_fail |= 2;
+    WL(0, 4);
+    if (v != u && !v_mail && wo_v && sv != (tag_base | (unsigned)wo_v))
+        if (!load_row_wait(h, m, v, lane, tag_base | (unsigned)wo_v, rv, h.ctl + 2, &wl_seen)) wl_fail |= 4;
+    WL(0, 5);
+    if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
+        if (!load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2, &wl_seen)) wl_fail |= 8;
+    if (hub_by_mail) {
+        // everything else is in registers by now; the hub's row arrives through LDS
+        const unsigned want = tag_base | (unsigned)((u == hub) ? wo_u : wo_v);
+        WL(0, 6);
+        unsigned spins = 0;
+        long long t0 = 0;
+        while (lds_load_tag(&mail->tag) != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 4095u) == 0) {
+                const long long now = (long long)wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > WAIT_TICKS) { note_timeout(h.ctl + 2, 3, i, (int)want, (int)lds_load_tag(&mail->tag), prev_edge); break; }
+                if (launch_failed(h.ctl + 2)) break;
+            }
+        }
+        if (lds_load_tag(&mail->tag) != want) { wl_fail |= 16; WL(7, lds_load_tag(&mail->tag)); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        Row rm;
+        rm.len = mail->len; rm.norm = mail->norm;
+        rm.key = mail->key[lane]; rm.ts = mail->ts[lane]; rm.w = mail->w[lane];
+        if (u == hub) ru = rm; else rv = rm;
+    }
+    if (v == u) rv = ru;
+    if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
+
+    STAMP(1);
+    WL(0, 7); WL(3, wall_clock64() >> 7); WL(6, wl_fail | (hub_by_mail ? 256 : 0)); if (wl_fail & 14) WL(7, wl_seen);
+    // ---- all reads done: later writers of these rows may go ahead ----
+    st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
+
+    // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
+    // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
+    {
+        const bool sw = v_first && u != v;
+        const Row &r1 = sw ? rv : ru, &r2 = sw ? ru : rv;
+        const long long x1 = sw ? v : u, x2 = sw ? u : v;
+        const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
+        u64 nk = 0;
+        double nt = 0, nw = 0;
+        // (edge_idx, s2, ts) is the key entering s1's dictionary
+        int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
+                           nt, nw, mo == 0 ? i : -1);
+        if (mail != nullptr && x1 == hub) {     // mailbox first: the chain's next edge is spinning on it
+            mail->key[lane] = nk; mail->ts[lane] = nt; mail->w[lane] = nw;
+            if (lane == 0) { mail->len = n; mail->norm = r1.norm * beta + beta; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&mail->tag, tag_base | (unsigned)(o1 + 1), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (hub_to_memory || x1 != hub)
+            store_row(h, m, x1, lane, n, nk, nt, nw, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
+        STAMP(2);
+        WL(0, 8);
+        if (u != v) {
+            n = merge_pair(L, lane, k, alpha, beta, r2, r1, ((u64)(unsigned)e << 32) | (u64)(unsigned)x1, tnow, nk,
+                           nt, nw);
+            if (mail != nullptr && x2 == hub) {
+                mail->key[lane] = nk; mail->ts[lane] = nt; mail->w[lane] = nw;
+                if (lane == 0) { mail->len = n; mail->norm = r2.norm * beta + beta; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&mail->tag, tag_base | (unsigned)(o2 + 1), __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (hub_to_memory || x2 != hub)
+                store_row(h, m, x2, lane, n, nk, nt, nw, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
+        }
+    }
+
+    // ---- emission is off the critical path (utils/util.py:504-506) ----
+    if (A.emit) {
+        const long long ob = (long long)mo * A.out_rows * k;
+        emit_row(ru, k, lane, tnow, A.out_nodes + ob + (long long)i * k, A.out_eidx + ob + (long long)i * k,
+                 A.out_dt + ob + (long long)i * k, A.out_w + ob + (long long)i * k);
+        const long long rv_o = ob + (role_stride + i) * k;
+        emit_row(rv, k, lane, tnow, A.out_nodes + rv_o, A.out_eidx + rv_o, A.out_dt + rv_o, A.out_w + rv_o);
+        if (n_roles == 3) {
+            const long long rg_o = ob + (2 * role_stride + i) * k;
+            emit_row(rg, k, lane, tnow, A.out_nodes + rg_o, A.out_eidx + rg_o, A.out_dt + rg_o, A.out_w + rg_o);
+        }
+    }
+    STAMP(3);
+    WL(4, wall_clock64() >> 7); WL(0, 9);
+    (void)wl_fail;
+}
+
+__global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, StreamArgs A)
 {
     __shared__ WaveLds lds[WAVES_PER_WG];
+    __shared__ Mail mail;
     WaveLds &L = lds[threadIdx.x / WAVE];
     const int lane = lane_id();
-    const int k = h.k;
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) return;   // rejected by k_count: touch nothing
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
-    const int total = B * n_models;
-    const unsigned tag_base = epoch << ORD_BITS;
+    if (threadIdx.x == 0) { mail.head = 0; mail.tag = 0; }
+    __syncthreads();
+    const int n_models = A.n_models;
+
+    // ---- chain workgroups: blocks [0, chains * models) each own one hub of one model ----
+    const int n_chain_wg = h.ctl[4] * n_models;
+    if ((int)blockIdx.x < n_chain_wg) {
+        const int c = blockIdx.x / n_models, mo = blockIdx.x % n_models;
+        const long long hub = h.chain_node[c];
+        int len = h.chain_len[c];
+        len = len < CH_MAX ? len : CH_MAX;
+        const int *edges = h.chain_edges + c * CH_MAX;
+        for (;;) {
+            int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= len) break;
+            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1);
+        }
+    }
+
+    // ---- general queue: every (edge, model) task not owned by a chain, in order ----
+    const int total = A.B * n_models;
     for (;;) {
         // Dequeue with NO divergent branch: every lane issues the add (lane 0
         // adds 1, the rest 0; the compiler folds it into one wave-level atomic).
@@ -544,78 +864,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, const
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= total) return;
         const int i = idx / n_models;
-        const int mo = idx % n_models;          // emitted-model index
-        const int m = m_lo + mo;
-        const double alpha = h.alpha[m], beta = h.beta[m];
-        unsigned *done = h.done + (long long)m * MAX_CHUNK;
-        STAMP(0);
-
-        // ---- dependencies of this edge's three accesses ----
-        int my_wo = 0, my_pf = -1, my_nx = 0;
-        if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i]; }
-        if (my_pf >= 0) wait_flag(done + my_pf, epoch, h.ctl + 2);   // a reader before me has not read yet
-        const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
-        // the endpoint with the longer chain still waiting behind it is merged and published first
-        const bool v_first = __shfl(my_nx, 1) > __shfl(my_nx, 0);
-
-        const long long u = nodes[i], v = nodes[role_stride + i];
-        const long long g = n_roles == 3 ? nodes[2 * role_stride + i] : u;
-        const double tnow = tsv[i];
-        const long long e = eidx[i];
-
-        // ---- rows: one memory round trip; poll where a writer of this launch precedes us ----
-        Row ru, rv, rg;
-        unsigned su = load_row(h, m, u, lane, wo_u ? (tag_base | (unsigned)wo_u) : 0u, ru);
-        unsigned sv = 0, sg = 0;
-        if (v != u) sv = load_row(h, m, v, lane, wo_v ? (tag_base | (unsigned)wo_v) : 0u, rv);
-        const bool g_own = n_roles == 3 && g != u && g != v;
-        if (g_own) sg = load_row(h, m, g, lane, wo_g ? (tag_base | (unsigned)wo_g) : 0u, rg);
-        if (wo_u && su != (tag_base | (unsigned)wo_u)) load_row_wait(h, m, u, lane, tag_base | (unsigned)wo_u, ru, h.ctl + 2);
-        if (v != u && wo_v && sv != (tag_base | (unsigned)wo_v))
-            load_row_wait(h, m, v, lane, tag_base | (unsigned)wo_v, rv, h.ctl + 2);
-        if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
-            load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2);
-        if (v == u) rv = ru;
-        if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
-
-        STAMP(1);
-        // ---- all reads done: later writers of these rows may go ahead ----
-        st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see above)
-
-        // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
-        // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
-        {
-            const bool sw = v_first && u != v;
-            const Row &r1 = sw ? rv : ru, &r2 = sw ? ru : rv;
-            const long long x1 = sw ? v : u, x2 = sw ? u : v;
-            const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
-            u64 nk = 0;
-            double nt = 0, nw = 0;
-            // (edge_idx, s2, ts) is the key entering s1's dictionary
-            int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
-                               nt, nw, mo == 0 ? i : -1);
-            store_row(h, m, x1, lane, n, nk, nt, nw, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
-            STAMP(2);
-            if (u != v) {
-                n = merge_pair(L, lane, k, alpha, beta, r2, r1, ((u64)(unsigned)e << 32) | (u64)(unsigned)x1, tnow, nk,
-                               nt, nw);
-                store_row(h, m, x2, lane, n, nk, nt, nw, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
-            }
-        }
-
-        // ---- emission is off the critical path (utils/util.py:504-506) ----
-        if (emit) {
-            const long long ob = (long long)mo * out_rows * k;
-            emit_row(ru, k, lane, tnow, out_nodes + ob + (long long)i * k, out_eidx + ob + (long long)i * k,
-                     out_dt + ob + (long long)i * k, out_w + ob + (long long)i * k);
-            const long long rv_o = ob + (role_stride + i) * k;
-            emit_row(rv, k, lane, tnow, out_nodes + rv_o, out_eidx + rv_o, out_dt + rv_o, out_w + rv_o);
-            if (n_roles == 3) {
-                const long long rg_o = ob + (2 * role_stride + i) * k;
-                emit_row(rg, k, lane, tnow, out_nodes + rg_o, out_eidx + rg_o, out_dt + rg_o, out_w + rg_o);
-            }
-        }
-        STAMP(3);
+        if (h.owner_of[i] >= 0) continue;              // a chain workgroup applies this edge
+        process_edge(h, A, L, lane, i, idx % n_models, nullptr, -1, -1, -1);
     }
 }
 
@@ -648,15 +898,24 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     ZT_HIP(hipMalloc(&h->rows, rows * h->rg * sizeof(u64)));
     ZT_HIP(hipMalloc(&h->cnt, (size_t)num_nodes * sizeof(int)));
     ZT_HIP(hipMalloc(&h->off, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->ctl, 16 * sizeof(int)));
+    ZT_HIP(hipMalloc(&h->ctl, CTL_WORDS * sizeof(int)));
     ZT_HIP(hipMalloc(&h->slot, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->list, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->wo, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->pflag, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->nxt, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->done, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
+    ZT_HIP(hipMalloc(&h->chain_of, (size_t)num_nodes * sizeof(int)));
+    ZT_HIP(hipMalloc(&h->hot_node, sizeof(int) * MAX_HOT));
+    ZT_HIP(hipMalloc(&h->hot_cnt, sizeof(int) * MAX_HOT));
+    ZT_HIP(hipMalloc(&h->chain_node, sizeof(int) * MAX_CHAINS));
+    ZT_HIP(hipMalloc(&h->chain_len, sizeof(int) * MAX_CHAINS));
+    ZT_HIP(hipMalloc(&h->chain_edges, sizeof(int) * MAX_CHAINS * CH_MAX));
+    ZT_HIP(hipMalloc(&h->owner_of, sizeof(int) * MAX_CHUNK));
+    ZT_HIP(hipMemset(h->chain_of, 0xff, (size_t)num_nodes * sizeof(int)));
+    ZT_HIP(hipMemset(h->chain_len, 0, sizeof(int) * MAX_CHAINS));
     ZT_HIP(hipMemset(h->cnt, 0, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMemset(h->ctl, 0, 16 * sizeof(int)));
+    ZT_HIP(hipMemset(h->ctl, 0, CTL_WORDS * sizeof(int)));
     ZT_HIP(hipMemset(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     hipDeviceProp_t prop;
     int dev = 0;
@@ -676,7 +935,8 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
     if (!h) return ZT_OK;
     (void)hipFree(h->rows); (void)hipFree(h->cnt); (void)hipFree(h->off); (void)hipFree(h->ctl);
     (void)hipFree(h->slot); (void)hipFree(h->list); (void)hipFree(h->wo); (void)hipFree(h->pflag); (void)hipFree(h->nxt);
-    (void)hipFree(h->done);
+    (void)hipFree(h->done); (void)hipFree(h->chain_of); (void)hipFree(h->hot_node); (void)hipFree(h->hot_cnt);
+    (void)hipFree(h->chain_node); (void)hipFree(h->chain_len); (void)hipFree(h->chain_edges); (void)hipFree(h->owner_of);
     delete h;
     return ZT_OK;
 }
@@ -711,6 +971,7 @@ static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, cons
 {
     if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
         k_retag<<<2048, 256, 0, s>>>(h->rows, (long long)h->M * h->N * h->rg);
+        ZT_HIP(hipMemsetAsync(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * h->M, s));   // flags of old epochs
         h->epoch = 0;
     }
     h->epoch += 1;
@@ -728,13 +989,12 @@ static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, cons
     ZT_PROF_BEGIN(s, P_PREPASS);
     k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
     ZT_DBG("k_count");
-    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl);
+    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
     ZT_DBG("k_reserve");
     k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
     ZT_DBG("k_fill");
     k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
     ZT_DBG("k_deps");
-    ZT_PROF_END(s, P_PREPASS);
     const int m_lo = model < 0 ? 0 : model;
     const int n_models = model < 0 ? h->M : 1;
     long long waves = (long long)B * n_models;
@@ -745,13 +1005,39 @@ static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, cons
     const long long max_waves = (long long)(h->n_cu * WAVES_PER_WG * wgs_per_cu);
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
+    // hub chains: at most a quarter of the (co-resident) grid, so the general queue always keeps waves
+    static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
+    int max_chains = grid / (4 * n_models);
+    if (max_chains > chains_env) max_chains = chains_env;
+    if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
+    k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
+                                       max_chains);
+    ZT_DBG("k_hot_select");
+    k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
+                                           h->chain_edges, h->owner_of);
+    ZT_DBG("k_own");
+    if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges);
+    ZT_DBG("k_chain_sort");
+    ZT_PROF_END(s, P_PREPASS);
+    StreamArgs sa;
+    sa.nodes = nodes; sa.tsv = ts; sa.eidx = eidx; sa.role_stride = role_stride; sa.B = B; sa.n_roles = n_roles;
+    sa.emit = emit; sa.m_lo = m_lo; sa.n_models = n_models; sa.out_rows = out_rows; sa.out_nodes = on; sa.out_eidx = oe;
+    sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
+#ifdef ZT_WAITLOG
+    {
+        void *wl = nullptr;
+        ZT_HIP(hipGetSymbolAddress(&wl, HIP_SYMBOL(g_wl)));
+        ZT_HIP(hipMemsetAsync(wl, 0, sizeof(int) * 2 * MAX_CHUNK * 8, s));
+        h->dbg_nodes = nodes; h->dbg_stride = role_stride; h->dbg_B = B; h->dbg_roles = n_roles; h->dbg_models = n_models;
+    }
+#endif
     ZT_PROF_BEGIN(s, P_STREAM);
-    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, nodes, ts, eidx, role_stride, B, n_roles, emit, m_lo, n_models,
-                                                  out_rows, on, oe, od, ow, h->epoch);
+    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
     ZT_DBG("k_stream");
     ZT_PROF_BEGIN(s, P_CLEANUP);
-    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl);
+    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
+    k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
     ZT_PROF_END(s, P_CLEANUP);
     ZT_DBG("k_cleanup");
     ZT_LAUNCH_CHECK();
@@ -839,13 +1125,65 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
 {
     if (!h) return ZT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int st = 0;
-    ZT_HIP(hipMemcpyAsync(&st, h->ctl + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    int c[CTL_WORDS] = {0};
+    ZT_HIP(hipMemcpyAsync(c, h->ctl, sizeof(c), hipMemcpyDeviceToHost, s));
     ZT_HIP(hipStreamSynchronize(s));
+    const int st = c[2];
     if (st != 0) {
         ZT_HIP(hipMemsetAsync(h->ctl + 2, 0, sizeof(int), s));
+        ZT_HIP(hipMemsetAsync(h->ctl + 13, 0, sizeof(int), s));
         ZT_HIP(hipStreamSynchronize(s));
-        set_error(st == ZT_ERR_RANGE ? "node or edge id out of range" : "dependency wait timed out");
+        if (st == ZT_ERR_RANGE) {
+            set_error("node or edge id out of range");
+        } else {
+            // kind 1: reads-done flag, 2: row tag (node, expect, seen, model), 3: mailbox (edge, expect, seen, prev edge)
+            char msg[480];
+            int o = snprintf(msg, sizeof(msg), "dependency wait timed out; %d waits gave up:", c[13]);
+            for (int q = 0; q < CTL_LOG && q < c[13] && o < (int)sizeof(msg) - 80; ++q) {
+                const int *r = c + 16 + 8 * q;
+                o += snprintf(msg + o, sizeof(msg) - o, " [kind %d: %d expect 0x%x seen 0x%x aux %d wg %d wave %d t %d]", r[0],
+                              r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+            }
+            set_error("%s", msg);
+#ifdef ZT_WAITLOG
+            {
+                const int B = h->dbg_B, R = h->dbg_roles;
+                std::vector<int> wl(2 * MAX_CHUNK * 8), nodes((size_t)R * B), wo(3 * MAX_CHUNK), own(MAX_CHUNK), cn(MAX_CHAINS),
+                    cl(MAX_CHAINS), ce(MAX_CHAINS * CH_MAX);
+                (void)hipMemcpyFromSymbol(wl.data(), HIP_SYMBOL(g_wl), wl.size() * 4);
+                for (int r = 0; r < R; ++r)
+                    (void)hipMemcpy(nodes.data() + (size_t)r * B, h->dbg_nodes + r * h->dbg_stride, (size_t)B * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(wo.data(), h->wo, wo.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(own.data(), h->owner_of, own.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(cn.data(), h->chain_node, cn.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(cl.data(), h->chain_len, cl.size() * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(ce.data(), h->chain_edges, ce.size() * 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[waitlog] B %d roles %d models %d ctl4(after reset) %d\n", B, R, h->dbg_models, c[4]);
+                for (int q = 0; q < MAX_CHAINS; ++q) {
+                    fprintf(stderr, "[waitlog] chain %d node %d len %d:", q, cn[q], cl[q]);
+                    for (int t = 0; t < cl[q] && t < 12; ++t) fprintf(stderr, " %d", ce[q * CH_MAX + t]);
+                    fprintf(stderr, "\n");
+                }
+                for (int mo = 0; mo < h->dbg_models && mo < 2; ++mo) {
+                    int tmin = 0x7fffffff;
+                    for (int i = 0; i < B; ++i) {
+                        const int *w = wl.data() + (mo * MAX_CHUNK + i) * 8;
+                        if (w[0] && w[2] < tmin) tmin = w[2];
+                    }
+                    int shown = 0;
+                    for (int i = 0; i < B && shown < 40; ++i) {
+                        const int *w = wl.data() + (mo * MAX_CHUNK + i) * 8;
+                        const bool slow = w[0] == 9 && (w[4] - w[2]) > 20000;     // > 25 ms
+                        if (w[0] == 9 && !slow && (w[6] & 255) == 0) continue;
+                        ++shown;
+                        fprintf(stderr, "[waitlog] m%d edge %d (u %d v %d wo %d %d owner %d): state %d wg %d wave %d start %d rows +%d end +%d prev %d fail 0x%x seen 0x%x\n",
+                                mo, i, nodes[i], nodes[B + i], wo[i], wo[B + i], own[i], w[0], w[1] >> 2, w[1] & 3, w[2] - tmin,
+                                w[3] - w[2], w[4] - w[2], w[5], w[6], w[7]);
+                    }
+                }
+            }
+#endif
+        }
     }
     return st;
 }
