@@ -234,11 +234,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(prefill + a.warmup, a.steps)
+    t_host = time.perf_counter() - t0          # host time to enqueue the timed steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    sys.stderr.write("[bench] host enqueue %.3f ms/step, wall %.3f ms/step\n" % (1e3 * t_host / a.steps, 1e3 * dt / a.steps))
     lib.zt_profile_enable(0)
     if wl["strategy"] == "streaming":
         tgn.embedding_module.tppr_finder.check_status()

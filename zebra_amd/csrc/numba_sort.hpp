@@ -308,11 +308,48 @@ __device__ inline void numba_argsort_reg(const double *a, int n, SortLds &S)
     wave_sync();
 }
 
+// Rank counting in registers (n <= 64, no NaN): lane c holds candidate c's value and counts the
+// smaller ones from n scalar-lane broadcasts (a lone wave is issue-bound: ~4 instructions per
+// candidate here against ~2 us per quicksort level).  With all kept values distinct the argsort is
+// simply the rank order.  Returns false -- sel is then undefined -- when a tie group reaches the
+// kept ranks [n-k, n): either the group straddles the cut (fewer than k lanes see rank >= n-k) or two
+// kept lanes claim the same slot.  Ties among dropped candidates do not matter.
+__device__ inline bool topk_rank_reg(double v, int n, int k, int *sel)
+{
+    const int lane = lane_id();
+    const int drop = n - k;
+    // lanes past n hold +inf: never smaller than anything, so whole groups of 8 lanes can be
+    // broadcast without a bounds test; constant lane numbers and four counters keep the VALU busy
+    const double vc = lane < n ? v : __longlong_as_double(0x7ff0000000000000ll);
+    int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < WAVE; q0 += 8) {
+        if (q0 >= n) break;
+        l0 += (readlane_f64(vc, q0 + 0) < vc) ? 1 : 0;
+        l1 += (readlane_f64(vc, q0 + 1) < vc) ? 1 : 0;
+        l2 += (readlane_f64(vc, q0 + 2) < vc) ? 1 : 0;
+        l3 += (readlane_f64(vc, q0 + 3) < vc) ? 1 : 0;
+        l0 += (readlane_f64(vc, q0 + 4) < vc) ? 1 : 0;
+        l1 += (readlane_f64(vc, q0 + 5) < vc) ? 1 : 0;
+        l2 += (readlane_f64(vc, q0 + 6) < vc) ? 1 : 0;
+        l3 += (readlane_f64(vc, q0 + 7) < vc) ? 1 : 0;
+    }
+    const int lt = (l0 + l1) + (l2 + l3);
+    const bool keep = lane < n && lt >= drop;
+    if (__popcll(__ballot(keep)) != k) return false;
+    if (keep) sel[lt - drop] = lane;
+    wave_sync();
+    const bool clash = keep && sel[lt - drop] != lane;
+    const bool ok = __ballot(clash) == 0ull;
+    wave_sync();
+    return ok;
+}
+
 // Wave-cooperative top-k selection.  On return sel[0..k) holds the indices of
 // np.argsort(a)[-k:] in that order.  Requires n > k.  `a` and `sel` are LDS
-// arrays owned by this wave.  Returns the path taken: 3 = exact replay in
-// registers (n <= 64), 0 = rank fast path, 1 = exact wave-parallel in LDS,
-// 2 = exact sequential.
+// arrays owned by this wave.  Returns the path taken: 0 = rank fast path (no
+// tie reaches the kept ranks), 3 = exact replay in registers (n <= 64),
+// 1 = exact wave-parallel in LDS, 2 = exact sequential.
 __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, SortLds &S, int *seq_perm,
                                        int *seq_stk)
 {
@@ -320,10 +357,10 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
     const int drop = n - k;
     bool slow = false, has_nan = false;
     if (n <= WAVE) {
-        // one lane per candidate: the exact replay in registers is cheaper than
-        // first testing whether ties matter, so it is the only path here
-        const bool nan = lane < n && (a[lane] != a[lane]);
-        if (__ballot(nan) == 0ull) {
+        // one lane per candidate: ranks by counting; the quicksort replay only when ties decide
+        const double v = lane < n ? a[lane] : 0.0;
+        if (__ballot(v != v) == 0ull) {
+            if (topk_rank_reg(v, n, k, sel)) return 0;
             numba_argsort_reg(a, n, S);
             if (lane < k) sel[lane] = S.r2[drop + lane];
             wave_sync();

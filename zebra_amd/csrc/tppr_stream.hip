@@ -185,6 +185,7 @@ constexpr int WAVES_PER_WG = 4;
 constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
 #ifdef ZT_STAMP
+__device__ int g_paths[4];
 __device__ long long g_stamps[8192 * 4];
 __device__ long long g_stamps2[8192 * 8];
 #define STAMP2(slot) do { if (lane_id() == 0 && g_stamp_i >= 0 && g_stamp_i < 8192) g_stamps2[g_stamp_i * 8 + (slot)] = (long long)wall_clock64(); } while (0)   // diagnostic build only: per task t_deq, t_rows, t_x1, t_end (100 MHz ticks)
@@ -459,10 +460,10 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
                                  int g_stamp_i = -1)
 {
     STAMP2(0);
-    // A lone wave issues one vector instruction per ~4 cycles, so this routine is written for
-    // instruction count: candidates stay in registers (s1's entries in lanes [0,n1), s2's in lanes
-    // [0,len2)), matches are found by broadcasting the SHORTER side with v_readlane, and LDS is
-    // touched once (the candidate list the top-k prune permutes).
+    // A lone wave is bound by dependent-instruction latency, so this routine is written for the
+    // length of its dependency chain: s1's entries live in lanes [0,n1), s2's in lanes [0,len2),
+    // key matches are found for all pairs at once through LDS, and the merged candidate list is
+    // written to LDS once (the top-k prune permutes it).
     int n1;
     double scale_s1 = 0.0, scale_s2;
     if (r1.norm == 0.0) {                       // :514-519
@@ -480,32 +481,46 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     const bool in2 = lane < len2;
     const double add = r2.w * scale_s2;
     bool matched2 = false;                      // this lane's s2 entry met its key in s1
-    const u64 ts1b = (u64)__double_as_longlong(r1.ts), ts2b = (u64)__double_as_longlong(r2.ts);
-    if (len2 <= n1) {
-        for (int q = 0; q < len2; ++q) {        // broadcast s2's entry q; s1 lanes compare
-            const u64 kq = readlane_u64(r2.key, q), tq = readlane_u64(ts2b, q);
-            const bool hit = in1 && r1.key == kq && r1.ts == __longlong_as_double((long long)tq);
-            const u64 hm = __ballot(hit);
-            if (hm != 0ull) {
-                const double aq = __longlong_as_double((long long)readlane_u64((u64)__double_as_longlong(add), q));
-                if (hit) w1 = w1 + aq;          // t_s1_PPR[key] += value * scale_s2
-                if (lane == q) matched2 = true;
+    if (n1 > 0 && len2 > 0) {
+        // Key matching through LDS, all pairs at once: the rows are staged (s1 in slots [0,64), s2
+        // in [64,128)), lane (c, i) compares s1's entry i with every S-th entry of s2 starting at c.
+        // Keys are unique inside a dictionary, so an entry has at most one partner.  Four dependent
+        // LDS round trips instead of one broadcast + ballot per entry of the shorter row.
+        int *m1 = L.sel, *m2 = L.sort.r;
+        if (in1) { L.key[lane] = r1.key; L.ts[lane] = r1.ts; }
+        if (in2) { L.key[WAVE + lane] = r2.key; L.ts[WAVE + lane] = r2.ts; L.w[WAVE + lane] = add; }
+        m1[lane] = -1;
+        m2[lane] = 0;
+        wave_sync();
+        // S lanes share one s1 entry: lane = c * n1 + i probes s2's entries c, c + S, c + 2S, ...
+        const int S = n1 <= 16 ? 4 : (n1 <= 21 ? 3 : (n1 <= 32 ? 2 : 1));
+        const int c = (lane >= n1 ? 1 : 0) + (lane >= 2 * n1 ? 1 : 0) + (lane >= 3 * n1 ? 1 : 0);
+        const int i = lane - c * n1;
+        if (c < S && i < n1) {
+            const u64 ki = L.key[i];
+            const double ti = L.ts[i];
+            int jm = -1;
+            for (int j0 = c; j0 < len2; j0 += 8 * S) {            // eight probes in flight
+                u64 kj[8];
+                double tj[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int j = j0 + t * S, jj = j < len2 ? j : len2 - 1;
+                    kj[t] = L.key[WAVE + jj]; tj[t] = L.ts[WAVE + jj];
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int j = j0 + t * S;
+                    if (j < len2 && kj[t] == ki && tj[t] == ti) jm = j;
+                }
             }
+            if (jm >= 0) { m1[i] = jm; m2[jm] = 1; L.sort.v[i] = L.w[WAVE + jm]; }
         }
-    } else {
-        for (int q = 0; q < n1; ++q) {          // broadcast s1's entry q; s2 lanes compare
-            const u64 kq = readlane_u64(r1.key, q), tq = readlane_u64(ts1b, q);
-            const bool hit = in2 && r2.key == kq && r2.ts == __longlong_as_double((long long)tq);
-            const u64 hm = __ballot(hit);
-            if (hm != 0ull) {
-                const int j = __ffsll((long long)hm) - 1;
-                const double aj = __longlong_as_double((long long)readlane_u64((u64)__double_as_longlong(add), j));
-                if (lane == q) w1 = w1 + aj;
-                if (hit) matched2 = true;
-            }
-        }
+        wave_sync();
+        if (in1 && m1[lane] >= 0) w1 = w1 + L.sort.v[lane];       // t_s1_PPR[key] += value * scale_s2
+        matched2 = in2 && m2[lane] != 0;
+        wave_sync();                                              // the staging area is reused below
     }
-    (void)ts2b;
     const bool un2 = in2 && !matched2;          // appended after s1's entries, in s2's order
     const u64 um = __ballot(un2);
     const int pos2 = n1 + __popcll(um & lanemask_lt());
@@ -532,7 +547,11 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         wave_sync();
         return n;
     }
-    topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);   // :553-559
+    const int tk_path = topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);   // :553-559
+#ifdef ZT_STAMP
+    if (lane == 0) atomicAdd(&g_paths[tk_path & 3], 1);
+#endif
+    (void)tk_path;
     STAMP2(4);
     if (lane < k) {
         const int c = L.sel[lane];
@@ -1078,6 +1097,12 @@ extern "C" int zt_debug_stamps(long long *host, int n)
 {
     ZT_HIP(hipDeviceSynchronize());
     ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * n * 4));
+    return ZT_OK;
+}
+extern "C" int zt_debug_paths(int *host)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_paths), sizeof(int) * 4));
     return ZT_OK;
 }
 extern "C" int zt_debug_stamps2(long long *host, int n)
