@@ -277,7 +277,8 @@ int zt_temporal_attention(const float *src_dev, const float *src_time_dev,
 /* own.  vals [cases][n] float64; writes np.argsort(vals[c])[-k:] under       */
 /* numba's quicksort semantics into sel_out [cases][k] and the path taken     */
 /* (0 fast rank, 1 wave-parallel exact in LDS, 2 sequential exact, 3 exact in  */
-/* registers) into path_out.  mode: 0 = production dispatch, 1/2/3 = force.    */
+/* registers on values, 4 exact in registers on ranks) into path_out.          */
+/* mode: 0 = production dispatch, 1/2/3/4 = force that path.                   */
 /* ------------------------------------------------------------------------ */
 int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases,
                  int32_t mode, int32_t *sel_out_dev, int32_t *path_out_dev,

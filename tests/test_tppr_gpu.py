@@ -226,8 +226,8 @@ def test_exact_topk_selection_paths(zt, oracle, n, k):
             vals[c] = 1.0                                                   # all equal
     want = np.stack([oracle.numba_argsort(v)[-k:] for v in vals])
     dv = torch.from_numpy(vals).cuda()
-    for mode in (0, 1, 2, 3):
-        if mode == 3 and n > 64:
+    for mode in (0, 1, 2, 3, 4):
+        if mode in (3, 4) and n > 64:
             continue
         sel = torch.full((cases, k), -1, dtype=torch.int32, device="cuda")
         path = torch.full((cases,), -1, dtype=torch.int32, device="cuda")
@@ -241,7 +241,7 @@ def test_exact_topk_selection_paths(zt, oracle, n, k):
         if mode == 0:
             p = path.cpu().numpy() & 0xff
             if n <= 64:
-                assert (p == 0).any() and (p == 3).any() and ((p == 0) | (p == 3)).all()   # rank path, register replay
+                assert (p == 0).any() and (p == 4).any() and ((p == 0) | (p == 4)).all()   # rank path, replay on ranks
             else:
                 assert (p == 0).any() and (p == 1).any()    # rank fast path and the LDS replay were exercised
 

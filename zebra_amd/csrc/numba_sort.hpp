@@ -309,12 +309,13 @@ __device__ inline void numba_argsort_reg(const double *a, int n, SortLds &S)
 }
 
 // Rank counting in registers (n <= 64, no NaN): lane c holds candidate c's value and counts the
-// smaller ones from n scalar-lane broadcasts (a lone wave is issue-bound: ~4 instructions per
-// candidate here against ~2 us per quicksort level).  With all kept values distinct the argsort is
-// simply the rank order.  Returns false -- sel is then undefined -- when a tie group reaches the
-// kept ranks [n-k, n): either the group straddles the cut (fewer than k lanes see rank >= n-k) or two
-// kept lanes claim the same slot.  Ties among dropped candidates do not matter.
-__device__ inline bool topk_rank_reg(double v, int n, int k, int *sel)
+// smaller ones from n scalar-lane broadcasts.  With all kept values distinct the argsort is simply
+// the rank order.  Returns false -- sel is then undefined -- when a tie group reaches the kept
+// ranks [n-k, n): either the group straddles the cut (fewer than k lanes see rank >= n-k) or two
+// kept lanes claim the same slot.  Ties among dropped candidates do not matter.  *lt_out = number
+// of strictly smaller candidates (equal values <=> equal counts), which is all the quicksort
+// replay below needs to know about the values.
+__device__ inline bool topk_rank_reg(double v, int n, int k, int *sel, int *lt_out)
 {
     const int lane = lane_id();
     const int drop = n - k;
@@ -335,6 +336,7 @@ __device__ inline bool topk_rank_reg(double v, int n, int k, int *sel)
         l3 += (readlane_f64(vc, q0 + 7) < vc) ? 1 : 0;
     }
     const int lt = (l0 + l1) + (l2 + l3);
+    *lt_out = lt;
     const bool keep = lane < n && lt >= drop;
     if (__popcll(__ballot(keep)) != k) return false;
     if (keep) sel[lt - drop] = lane;
@@ -345,11 +347,115 @@ __device__ inline bool topk_rank_reg(double v, int n, int k, int *sel)
     return ok;
 }
 
+__device__ __forceinline__ int mbcnt64(u64 m)      // bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// ---------------------------------------------------------------------------
+// Exact top-k when ties decide (n <= 64, no NaN): numba's quicksort replayed on the value RANKS
+// (`lt` from topk_rank_reg), one segment at a time with everything about the segment in scalar
+// registers.  Lane p is position p and holds e = (rank << 8) | candidate.  Per partition: three
+// scalar lane reads + scalar compares for the median of three, two ballots for the scan stops, one
+// LDS round trip to pair the m-th i-stop with the m-th j-stop, one cross-lane permute for all the
+// swaps, scalar lane writes for the pivot.  Segments that lie wholly below the cut n-k are neither
+// partitioned nor ordered (partitions of disjoint ranges are independent).  Finished segments
+// (< 16 entries) get the stable rank = insertion sort with strict <.  Writes sel[0..k).
+// ---------------------------------------------------------------------------
+__device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S)
+{
+    const int p = lane_id();
+    const int drop = n - k;
+    int e = (lt << 8) | p;
+    int mylo = p, myhi = p - 1;                     // finished segment holding position p (empty: none)
+    u64 pending = 0ull;                             // segments still to partition, 16 bits each
+    int depth = 0;
+    int lo = 0, hi = n - 1;
+    bool work = true;
+    if (hi - lo < 15) {
+        if (p <= hi) { mylo = lo; myhi = hi; }
+        work = false;
+    }
+    while (work) {
+        // ---- median of three (uniform values, scalar unit) ----
+        const int mid = (lo + hi) >> 1;
+        int el = __builtin_amdgcn_readlane(e, lo), em = __builtin_amdgcn_readlane(e, mid),
+            eh = __builtin_amdgcn_readlane(e, hi);
+        if ((em >> 8) < (el >> 8)) { const int t = el; el = em; em = t; }
+        if ((eh >> 8) < (em >> 8)) { const int t = eh; eh = em; em = t; }
+        if ((em >> 8) < (el >> 8)) { const int t = el; el = em; em = t; }
+        const int pk = em >> 8;
+        e = (p == lo ? el : e);
+        e = (p == mid ? eh : e);
+        e = (p == hi ? em : e);  // pivot stashed at `hi`
+        // ---- stops of the two scans over lo .. hi-1 ----
+        const int key = e >> 8;
+        const bool in = p >= lo && p < hi;
+        const bool ge = in && key >= pk, le = in && key <= pk;
+        const u64 GE = __ballot(ge), LE = __ballot(le);
+        const int nI = __popcll(GE), nJ = __popcll(LE);
+        const int mi = mbcnt64(GE), mj = nJ - 1 - mbcnt64(LE);
+        if (ge) S.ilist[mi] = p;                    // i-stops ascending, j-stops descending
+        if (le) S.jlist[mj] = p;
+        wave_sync();
+        int src = p;
+        bool swi = false, swj = false;
+        if (ge && mi < nJ) { const int q = S.jlist[mi]; if (p < q) { src = q; swi = true; } }
+        if (le && mj < nI) { const int q = S.ilist[mj]; if (q < p) { src = q; swj = true; } }
+        // where the i-scan ends: the first i-stop that did not swap, or the lowest swapped j-stop
+        // (it received a >= pivot value), or `hi`
+        const u64 stay = __ballot(ge && !swi), sj = __ballot(swj);
+        int ifin = stay ? __ffsll((long long)stay) - 1 : hi;
+        if (sj) { const int jl = __ffsll((long long)sj) - 1; ifin = jl < ifin ? jl : ifin; }
+        e = __shfl(e, src);                         // all pair swaps at once
+        const int x = __builtin_amdgcn_readlane(e, ifin);
+        e = (p == ifin ? em : e);    // pivot <-> ifin
+        e = (p == hi ? x : e);
+        if (p == ifin) { mylo = p; myhi = p; }
+        // ---- children: only those reaching the kept ranks matter ----
+        const int lhi = ifin - 1, rlo = ifin + 1;
+        const bool lneed = lhi >= lo && lhi >= drop, rneed = hi >= rlo && hi >= drop;
+        const bool lpart = lneed && lhi - lo >= 15, rpart = rneed && hi - rlo >= 15;
+        if (lneed && !lpart && p >= lo && p <= lhi) { mylo = lo; myhi = lhi; }
+        if (rneed && !rpart && p >= rlo && p <= hi) { mylo = rlo; myhi = hi; }
+        if (lpart) {
+            if (rpart) { pending = (pending << 16) | (u64)(unsigned)(rlo | (hi << 8)); ++depth; }
+            hi = lhi;
+        } else if (rpart) {
+            lo = rlo;
+        } else if (depth > 0) {
+            lo = (int)(pending & 0xffull); hi = (int)((pending >> 8) & 0xffull);
+            pending >>= 16; --depth;
+        } else {
+            work = false;
+        }
+    }
+    // ---- stable rank inside every finished segment that reaches the cut ----
+    if (p < n) S.r[p] = (e & ~0xff) | p;            // (rank, current position)
+    wave_sync();
+    if (myhi >= mylo) {
+        const int cp = (e & ~0xff) | p;
+        int rank = 0;
+        for (int q0 = mylo; q0 <= myhi; q0 += 8) {  // segments hold at most 15 entries
+            int x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = S.r[(q0 + t) <= myhi ? (q0 + t) : myhi];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rank += ((q0 + t) <= myhi && x[t] < cp) ? 1 : 0;
+        }
+        const int f = mylo + rank;
+        if (f >= drop) sel[f - drop] = e & 0xff;
+    }
+    wave_sync();
+}
+
 // Wave-cooperative top-k selection.  On return sel[0..k) holds the indices of
 // np.argsort(a)[-k:] in that order.  Requires n > k.  `a` and `sel` are LDS
 // arrays owned by this wave.  Returns the path taken: 0 = rank fast path (no
-// tie reaches the kept ranks), 3 = exact replay in registers (n <= 64),
-// 1 = exact wave-parallel in LDS, 2 = exact sequential.
+// tie reaches the kept ranks), 4 = quicksort replay on ranks in registers
+// (n <= 64), 1 = exact wave-parallel in LDS, 2 = exact sequential.
+// (numba_argsort_reg, path 3, is the same replay on the values themselves; it
+// is kept as an independently tested cross-check.)
 __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, SortLds &S, int *seq_perm,
                                        int *seq_stk)
 {
@@ -360,11 +466,10 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
         // one lane per candidate: ranks by counting; the quicksort replay only when ties decide
         const double v = lane < n ? a[lane] : 0.0;
         if (__ballot(v != v) == 0ull) {
-            if (topk_rank_reg(v, n, k, sel)) return 0;
-            numba_argsort_reg(a, n, S);
-            if (lane < k) sel[lane] = S.r2[drop + lane];
-            wave_sync();
-            return 3;
+            int lt;
+            if (topk_rank_reg(v, n, k, sel, &lt)) return 0;
+            topk_ties_reg(lt, n, k, sel, S);
+            return 4;
         }
     }
     // rank counting: every candidate c (strided over lanes) counts smaller /

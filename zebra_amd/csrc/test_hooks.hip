@@ -30,6 +30,12 @@ __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ val
     const long long t0 = (long long)wall_clock64();
     if (mode == 0) {
         path = topk_select_wave(L.a, n, k, L.sel, L.sort, L.perm, L.stk);
+    } else if (mode == 4) {                       // the rank-domain replay on its own, ties or not
+        const double v = lane < n ? L.a[lane] : 0.0;
+        int lt;
+        (void)topk_rank_reg(v, n, k, L.sel, &lt);
+        topk_ties_reg(lt, n, k, L.sel, L.sort);
+        path = 4;
     } else if (mode == 3) {
         numba_argsort_reg(L.a, n, L.sort);
         if (lane < k) L.sel[lane] = L.sort.r2[n - k + lane];
@@ -59,7 +65,7 @@ extern "C" int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_
                             int32_t *sel_out_dev, int32_t *path_out_dev, void *stream)
 {
     if (!vals_dev || !sel_out_dev || !path_out_dev || n < 2 || k < 1 || k >= n || k > 64 || cases < 1 || n > 1536 ||
-        (mode == 1 && n > 128) || (mode == 3 && n > 64)) {
+        (mode == 1 && n > 128) || ((mode == 3 || mode == 4) && n > 64)) {
         set_error("zt_test_topk: bad argument");
         return ZT_ERR_ARG;
     }

@@ -185,7 +185,7 @@ constexpr int WAVES_PER_WG = 4;
 constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
 #ifdef ZT_STAMP
-__device__ int g_paths[4];
+__device__ int g_paths[8];
 __device__ long long g_stamps[8192 * 4];
 __device__ long long g_stamps2[8192 * 8];
 #define STAMP2(slot) do { if (lane_id() == 0 && g_stamp_i >= 0 && g_stamp_i < 8192) g_stamps2[g_stamp_i * 8 + (slot)] = (long long)wall_clock64(); } while (0)   // diagnostic build only: per task t_deq, t_rows, t_x1, t_end (100 MHz ticks)
@@ -549,7 +549,7 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     }
     const int tk_path = topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);   // :553-559
 #ifdef ZT_STAMP
-    if (lane == 0) atomicAdd(&g_paths[tk_path & 3], 1);
+    if (lane == 0) atomicAdd(&g_paths[tk_path & 7], 1);
 #endif
     (void)tk_path;
     STAMP2(4);
@@ -1102,7 +1102,7 @@ extern "C" int zt_debug_stamps(long long *host, int n)
 extern "C" int zt_debug_paths(int *host)
 {
     ZT_HIP(hipDeviceSynchronize());
-    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_paths), sizeof(int) * 4));
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_paths), sizeof(int) * 8));
     return ZT_OK;
 }
 extern "C" int zt_debug_stamps2(long long *host, int n)
