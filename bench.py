@@ -219,7 +219,8 @@ def main():
         with ctx:
             for b in range(b0, b0 + nb):
                 nxt = batch(b + 1) if (not a.no_pipeline and b + 1 < b0 + nb) else None
-                step(*batch(b), prefetch=nxt)
+                nxt2 = batch(b + 2) if (not a.no_pipeline and b + 2 < b0 + nb) else None
+                step(*batch(b), prefetch=nxt, plan=nxt2)
 
     lib = _capi.lib()
     run(0, prefill)

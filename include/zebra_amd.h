@@ -101,6 +101,17 @@ int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev,
                    int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
                    void *stream);
 
+/* Optional, no reference counterpart: run the dependency prepass of a coming
+ * zt_tppr_stream call ahead of time on another stream.  The prepass (which
+ * edges of the batch touch the same node, in which order) reads only the ids,
+ * never the T-PPR state, so it can overlap the previous call's update kernel.
+ * The next zt_tppr_stream call with the same nodes_dev, B, n_roles and model
+ * picks the plan up (ordering between the two streams is handled inside);
+ * any other call simply runs its own prepass.  Two plans can be outstanding.
+ * A no-op for B == 0 or B > 8192 (multi-launch calls plan inline). */
+int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev,
+                 int64_t B, int32_t n_roles, int32_t model, void *stream);
+
 /* Synchronises `stream` and returns the latched device status (ZT_OK,
  * ZT_ERR_RANGE or ZT_ERR_TIMEOUT), clearing it. */
 int zt_tppr_status(zt_tppr *h, void *stream);

@@ -128,7 +128,8 @@ def test_protocol_vs_oracle(oracle, cfg):
 
 @pytest.mark.parametrize("tppr_cus", [0, 32])
 def test_pipelined_step_matches_sequential(tppr_cus):
-    """The side-stream T-PPR prefetch (optionally on CU-masked streams) must not change any result."""
+    """The side-stream T-PPR prefetch (optionally on CU-masked streams) and the dependency prepass
+    planned two batches ahead on a third stream must not change any result."""
     name = "d100_f1"
     N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
     src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
@@ -148,7 +149,9 @@ def test_pipelined_step_matches_sequential(tppr_cus):
             for b in range(nbt):
                 cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
                 nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
-                embs.append(tgn.step_device(*cur, prefetch=nxt).clone())
+                # every third batch is left unplanned: planned and inline prepasses interleave
+                nx2 = tuple(x[(b + 2) * bs:(b + 3) * bs] for x in t) if (mode == "pipe" and b + 2 < nbt and b % 3) else None
+                embs.append(tgn.step_device(*cur, prefetch=nxt, plan=nx2).clone())
         torch.cuda.synchronize()
         tgn.embedding_module.tppr_finder.check_status()
         outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(),

@@ -172,6 +172,19 @@ struct zt_tppr {
     int *ctl;
     unsigned epoch;
     int n_cu;
+    // Two sets of the prepass buffers above (the fields above point into the set in use): the prepass of
+    // the next call can run on another stream while k_stream still reads the previous call's set.
+    struct PlanSet {
+        int *cnt, *off, *slot, *list, *wo, *pflag, *nxt, *chain_of, *hot_node, *hot_cnt, *chain_node, *chain_len,
+            *chain_edges, *owner_of, *ctl;
+        hipEvent_t planned, consumed;      // prepass finished / k_stream finished with the set
+        bool used;                         // `consumed` has been recorded at least once
+        // what the set was planned for (valid == a zt_tppr_plan result not consumed yet)
+        bool valid;
+        const int32_t *nodes;
+        int B, n_roles, model, grid;
+    } set[2];
+    int next_set;
     // last launch (diagnostics)
     const int *dbg_nodes;
     long long dbg_stride;
@@ -379,8 +392,8 @@ __global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, 
     if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
 }
 
-// K6: control words back to zero (after k_cleanup has read ctl[3]).
-__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 5 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
+// K6: control words back to zero (after k_cleanup has read ctl[3]); ctl[4] = chains stays for k_stream.
+__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 4 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
 
 // ------------------------------------------------------------- row access ----
 struct Row {
@@ -895,6 +908,15 @@ __global__ void k_retag(u64 *rows, long long n)
         rows[i] &= 0xffffffffull;
 }
 
+// point the handle's prepass fields at one of its two sets
+void use_set(zt_tppr *h, int q)
+{
+    const zt_tppr::PlanSet &P = h->set[q];
+    h->cnt = P.cnt; h->off = P.off; h->slot = P.slot; h->list = P.list; h->wo = P.wo; h->pflag = P.pflag; h->nxt = P.nxt;
+    h->chain_of = P.chain_of; h->hot_node = P.hot_node; h->hot_cnt = P.hot_cnt; h->chain_node = P.chain_node;
+    h->chain_len = P.chain_len; h->chain_edges = P.chain_edges; h->owner_of = P.owner_of; h->ctl = P.ctl;
+}
+
 }  // namespace
 
 // ---- C ABI ------------------------------------------------------------------------
@@ -915,27 +937,36 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     for (int m = 0; m < n_tppr; ++m) { h->alpha[m] = alpha_host[m]; h->beta[m] = beta_host[m]; }
     const size_t rows = (size_t)n_tppr * (size_t)num_nodes;
     ZT_HIP(hipMalloc(&h->rows, rows * h->rg * sizeof(u64)));
-    ZT_HIP(hipMalloc(&h->cnt, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->off, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->ctl, CTL_WORDS * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->slot, sizeof(int) * 3 * MAX_CHUNK));
-    ZT_HIP(hipMalloc(&h->list, sizeof(int) * 3 * MAX_CHUNK));
-    ZT_HIP(hipMalloc(&h->wo, sizeof(int) * 3 * MAX_CHUNK));
-    ZT_HIP(hipMalloc(&h->pflag, sizeof(int) * 3 * MAX_CHUNK));
-    ZT_HIP(hipMalloc(&h->nxt, sizeof(int) * 3 * MAX_CHUNK));
     ZT_HIP(hipMalloc(&h->done, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
-    ZT_HIP(hipMalloc(&h->chain_of, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMalloc(&h->hot_node, sizeof(int) * MAX_HOT));
-    ZT_HIP(hipMalloc(&h->hot_cnt, sizeof(int) * MAX_HOT));
-    ZT_HIP(hipMalloc(&h->chain_node, sizeof(int) * MAX_CHAINS));
-    ZT_HIP(hipMalloc(&h->chain_len, sizeof(int) * MAX_CHAINS));
-    ZT_HIP(hipMalloc(&h->chain_edges, sizeof(int) * MAX_CHAINS * CH_MAX));
-    ZT_HIP(hipMalloc(&h->owner_of, sizeof(int) * MAX_CHUNK));
-    ZT_HIP(hipMemset(h->chain_of, 0xff, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMemset(h->chain_len, 0, sizeof(int) * MAX_CHAINS));
-    ZT_HIP(hipMemset(h->cnt, 0, (size_t)num_nodes * sizeof(int)));
-    ZT_HIP(hipMemset(h->ctl, 0, CTL_WORDS * sizeof(int)));
     ZT_HIP(hipMemset(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
+    for (int q = 0; q < 2; ++q) {
+        zt_tppr::PlanSet &P = h->set[q];
+        ZT_HIP(hipMalloc(&P.cnt, (size_t)num_nodes * sizeof(int)));
+        ZT_HIP(hipMalloc(&P.off, (size_t)num_nodes * sizeof(int)));
+        ZT_HIP(hipMalloc(&P.ctl, CTL_WORDS * sizeof(int)));
+        ZT_HIP(hipMalloc(&P.slot, sizeof(int) * 3 * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.list, sizeof(int) * 3 * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.wo, sizeof(int) * 3 * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.pflag, sizeof(int) * 3 * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.nxt, sizeof(int) * 3 * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.chain_of, (size_t)num_nodes * sizeof(int)));
+        ZT_HIP(hipMalloc(&P.hot_node, sizeof(int) * MAX_HOT));
+        ZT_HIP(hipMalloc(&P.hot_cnt, sizeof(int) * MAX_HOT));
+        ZT_HIP(hipMalloc(&P.chain_node, sizeof(int) * MAX_CHAINS));
+        ZT_HIP(hipMalloc(&P.chain_len, sizeof(int) * MAX_CHAINS));
+        ZT_HIP(hipMalloc(&P.chain_edges, sizeof(int) * MAX_CHAINS * CH_MAX));
+        ZT_HIP(hipMalloc(&P.owner_of, sizeof(int) * MAX_CHUNK));
+        ZT_HIP(hipMemset(P.chain_of, 0xff, (size_t)num_nodes * sizeof(int)));
+        ZT_HIP(hipMemset(P.chain_len, 0, sizeof(int) * MAX_CHAINS));
+        ZT_HIP(hipMemset(P.cnt, 0, (size_t)num_nodes * sizeof(int)));
+        ZT_HIP(hipMemset(P.ctl, 0, CTL_WORDS * sizeof(int)));
+        ZT_HIP(hipEventCreateWithFlags(&P.planned, hipEventDisableTiming));
+        ZT_HIP(hipEventCreateWithFlags(&P.consumed, hipEventDisableTiming));
+        P.used = false;
+        P.valid = false;
+    }
+    h->next_set = 0;
+    use_set(h, 0);
     hipDeviceProp_t prop;
     int dev = 0;
     ZT_HIP(hipGetDevice(&dev));
@@ -952,10 +983,16 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
 extern "C" int zt_tppr_destroy(zt_tppr *h)
 {
     if (!h) return ZT_OK;
-    (void)hipFree(h->rows); (void)hipFree(h->cnt); (void)hipFree(h->off); (void)hipFree(h->ctl);
-    (void)hipFree(h->slot); (void)hipFree(h->list); (void)hipFree(h->wo); (void)hipFree(h->pflag); (void)hipFree(h->nxt);
-    (void)hipFree(h->done); (void)hipFree(h->chain_of); (void)hipFree(h->hot_node); (void)hipFree(h->hot_cnt);
-    (void)hipFree(h->chain_node); (void)hipFree(h->chain_len); (void)hipFree(h->chain_edges); (void)hipFree(h->owner_of);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->rows); (void)hipFree(h->done);
+    for (int q = 0; q < 2; ++q) {
+        zt_tppr::PlanSet &P = h->set[q];
+        (void)hipFree(P.cnt); (void)hipFree(P.off); (void)hipFree(P.ctl); (void)hipFree(P.slot); (void)hipFree(P.list);
+        (void)hipFree(P.wo); (void)hipFree(P.pflag); (void)hipFree(P.nxt); (void)hipFree(P.chain_of);
+        (void)hipFree(P.hot_node); (void)hipFree(P.hot_cnt); (void)hipFree(P.chain_node); (void)hipFree(P.chain_len);
+        (void)hipFree(P.chain_edges); (void)hipFree(P.owner_of);
+        (void)hipEventDestroy(P.planned); (void)hipEventDestroy(P.consumed);
+    }
     delete h;
     return ZT_OK;
 }
@@ -984,38 +1021,9 @@ extern "C" int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream)
     return ZT_OK;
 }
 
-static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, const long long *eidx, long long role_stride,
-                        int B, int n_roles, int emit, int model, long long out_rows, int32_t *on, int32_t *oe, float *od,
-                        float *ow, hipStream_t s)
+// grid of k_stream and the number of hub chains for a launch of B edges
+static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, int *max_chains_out)
 {
-    if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
-        k_retag<<<2048, 256, 0, s>>>(h->rows, (long long)h->M * h->N * h->rg);
-        ZT_HIP(hipMemsetAsync(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * h->M, s));   // flags of old epochs
-        h->epoch = 0;
-    }
-    h->epoch += 1;
-    const int A = B * n_roles;
-    const int tb = 256, gb = (A + tb - 1) / tb;
-    static const bool dbg = getenv("ZT_DEBUG_SYNC") != nullptr;
-#define ZT_DBG(tag)                                                                          \
-    do {                                                                                     \
-        if (dbg) {                                                                           \
-            hipError_t e__ = hipStreamSynchronize(s);                                        \
-            fprintf(stderr, "[zt] %s: %s\n", tag, hipGetErrorString(e__));                   \
-            fflush(stderr);                                                                  \
-        }                                                                                    \
-    } while (0)
-    ZT_PROF_BEGIN(s, P_PREPASS);
-    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
-    ZT_DBG("k_count");
-    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
-    ZT_DBG("k_reserve");
-    k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
-    ZT_DBG("k_fill");
-    k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
-    ZT_DBG("k_deps");
-    const int m_lo = model < 0 ? 0 : model;
-    const int n_models = model < 0 ? h->M : 1;
     long long waves = (long long)B * n_models;
     // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
     // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
@@ -1029,37 +1037,97 @@ static int stream_chunk(zt_tppr *h, const int32_t *nodes, const double *ts, cons
     int max_chains = grid / (4 * n_models);
     if (max_chains > chains_env) max_chains = chains_env;
     if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
+    *grid_out = grid;
+    *max_chains_out = max_chains;
+}
+
+// The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
+// edge ids, never the T-PPR rows, so it may run while k_stream works on the other set.
+static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *eidx, long long role_stride, int B,
+                      int n_roles, int model, hipStream_t s)
+{
+    zt_tppr::PlanSet &P = h->set[q];
+    if (P.used) ZT_HIP(hipStreamWaitEvent(s, P.consumed, 0));      // k_stream of two calls ago has let go of it
+    use_set(h, q);
+    const int A = B * n_roles;
+    const int tb = 256, gb = (A + tb - 1) / tb;
+    const int n_models = model < 0 ? h->M : 1;
+    int grid, max_chains;
+    launch_shape(h, B, n_models, &grid, &max_chains);
+    ZT_PROF_BEGIN(s, P_PREPASS);
+    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
+    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
+    k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
+    k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
     k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
                                        max_chains);
-    ZT_DBG("k_hot_select");
     k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
                                            h->chain_edges, h->owner_of);
-    ZT_DBG("k_own");
     if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges);
-    ZT_DBG("k_chain_sort");
     ZT_PROF_END(s, P_PREPASS);
+    // per-node counters and the control words back to their rest state: the set is ready for k_stream
+    ZT_PROF_BEGIN(s, P_CLEANUP);
+    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
+    k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
+    ZT_PROF_END(s, P_CLEANUP);
+    ZT_LAUNCH_CHECK();
+    ZT_HIP(hipEventRecord(P.planned, s));
+    P.nodes = nodes; P.B = B; P.n_roles = n_roles; P.model = model; P.grid = grid;
+    return ZT_OK;
+}
+
+// k_stream over plan set q (planned on any stream), on stream s.
+static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, const long long *eidx,
+                     long long role_stride, int B, int n_roles, int emit, int model, long long out_rows, int32_t *on,
+                     int32_t *oe, float *od, float *ow, hipStream_t s)
+{
+    zt_tppr::PlanSet &P = h->set[q];
+    if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
+        k_retag<<<2048, 256, 0, s>>>(h->rows, (long long)h->M * h->N * h->rg);
+        ZT_HIP(hipMemsetAsync(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * h->M, s));   // flags of old epochs
+        h->epoch = 0;
+    }
+    h->epoch += 1;
+    ZT_HIP(hipStreamWaitEvent(s, P.planned, 0));
+    use_set(h, q);
     StreamArgs sa;
     sa.nodes = nodes; sa.tsv = ts; sa.eidx = eidx; sa.role_stride = role_stride; sa.B = B; sa.n_roles = n_roles;
-    sa.emit = emit; sa.m_lo = m_lo; sa.n_models = n_models; sa.out_rows = out_rows; sa.out_nodes = on; sa.out_eidx = oe;
-    sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
+    sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
+    sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
 #ifdef ZT_WAITLOG
     {
         void *wl = nullptr;
         ZT_HIP(hipGetSymbolAddress(&wl, HIP_SYMBOL(g_wl)));
         ZT_HIP(hipMemsetAsync(wl, 0, sizeof(int) * 2 * MAX_CHUNK * 8, s));
-        h->dbg_nodes = nodes; h->dbg_stride = role_stride; h->dbg_B = B; h->dbg_roles = n_roles; h->dbg_models = n_models;
+        h->dbg_nodes = nodes; h->dbg_stride = role_stride; h->dbg_B = B; h->dbg_roles = n_roles; h->dbg_models = sa.n_models;
     }
 #endif
     ZT_PROF_BEGIN(s, P_STREAM);
-    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    k_stream<<<P.grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
-    ZT_DBG("k_stream");
-    ZT_PROF_BEGIN(s, P_CLEANUP);
-    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
-    k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
-    ZT_PROF_END(s, P_CLEANUP);
-    ZT_DBG("k_cleanup");
     ZT_LAUNCH_CHECK();
+    ZT_HIP(hipEventRecord(P.consumed, s));
+    P.used = true;
+    P.valid = false;
+    return ZT_OK;
+}
+
+extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev, int64_t B, int32_t n_roles,
+                            int32_t model, void *stream)
+{
+    if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M) {
+        set_error("zt_tppr_plan: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (B == 0 || B > MAX_CHUNK) return ZT_OK;      // nothing to prepare / a multi-launch call plans inline
+    if (!nodes_dev || !eidx_dev) { set_error("zt_tppr_plan: NULL buffer"); return ZT_ERR_ARG; }
+    const int q = h->next_set;
+    h->next_set ^= 1;
+    h->set[q].valid = false;
+    int rc = plan_chunk(h, q, nodes_dev, reinterpret_cast<const long long *>(eidx_dev), B, (int)B, n_roles, model,
+                        (hipStream_t)stream);
+    if (rc != ZT_OK) return rc;
+    h->set[q].valid = true;
     return ZT_OK;
 }
 
@@ -1079,14 +1147,25 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
     }
     hipStream_t s = (hipStream_t)stream;
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
+    // a prepass made ahead of time by zt_tppr_plan for exactly this call
+    for (int q = 0; q < 2; ++q) {
+        zt_tppr::PlanSet &P = h->set[q];
+        if (P.valid && P.nodes == nodes_dev && P.B == (int)B && P.n_roles == n_roles && P.model == model)
+            return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
+                             out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s);
+    }
     // launches of at most MAX_CHUNK edges: writer ordinals must fit the tag
     for (int64_t c0 = 0; c0 < B; c0 += MAX_CHUNK) {
         const int bc = (int)((B - c0) < MAX_CHUNK ? (B - c0) : MAX_CHUNK);
         const size_t oo = (size_t)c0 * h->k;
-        int rc = stream_chunk(h, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
-                              (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr,
-                              emit ? out_eidx_dev + oo : nullptr, emit ? out_dt_dev + oo : nullptr,
-                              emit ? out_w_dev + oo : nullptr, s);
+        const int q = h->next_set;
+        h->next_set ^= 1;
+        h->set[q].valid = false;
+        int rc = plan_chunk(h, q, nodes_dev + c0, e64 + c0, B, bc, n_roles, model, s);
+        if (rc != ZT_OK) return rc;
+        rc = run_chunk(h, q, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
+                       (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr, emit ? out_eidx_dev + oo : nullptr,
+                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s);
         if (rc != ZT_OK) return rc;
     }
     return ZT_OK;
@@ -1151,13 +1230,19 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
     if (!h) return ZT_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     int c[CTL_WORDS] = {0};
-    ZT_HIP(hipMemcpyAsync(c, h->ctl, sizeof(c), hipMemcpyDeviceToHost, s));
-    ZT_HIP(hipStreamSynchronize(s));
-    const int st = c[2];
-    if (st != 0) {
-        ZT_HIP(hipMemsetAsync(h->ctl + 2, 0, sizeof(int), s));
-        ZT_HIP(hipMemsetAsync(h->ctl + 13, 0, sizeof(int), s));
+    int st = 0;
+    for (int q = 0; q < 2 && st == 0; ++q) {          // the status word of either plan set
+        ZT_HIP(hipMemcpyAsync(c, h->set[q].ctl, sizeof(c), hipMemcpyDeviceToHost, s));
         ZT_HIP(hipStreamSynchronize(s));
+        st = c[2];
+        if (st != 0) {
+            ZT_HIP(hipMemsetAsync(h->set[q].ctl + 2, 0, sizeof(int), s));
+            ZT_HIP(hipMemsetAsync(h->set[q].ctl + 13, 0, sizeof(int), s));
+            ZT_HIP(hipStreamSynchronize(s));
+            use_set(h, q);
+        }
+    }
+    if (st != 0) {
         if (st == ZT_ERR_RANGE) {
             set_error("node or edge id out of range");
         } else {

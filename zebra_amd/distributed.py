@@ -90,7 +90,7 @@ class ShardedTGN:
         self.tgn, self.rank, self.world, self.group = tgn, rank, world, group
 
     @torch.no_grad()
-    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None):
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):
         tgn = self.tgn
         em = tgn.embedding_module
         if not tgn.test_mode:
@@ -98,7 +98,7 @@ class ShardedTGN:
             tgn.test_mode = True
         B = src_d.numel()
         nodes_d, on, oe, od, ow = tgn.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch,
-                                                        check_status)                          # replicated
+                                                        check_status, plan)                    # replicated
         r0, r1 = shard_range(3 * B, self.rank, self.world)
         emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
                               oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),

@@ -105,10 +105,13 @@ class TGN(torch.nn.Module):
         ``tppr_cus`` > 0 pins that stream to the first tppr_cus compute units (CU mask) and the
         caller should run everything else on ``self.main_stream`` (the remaining CUs)."""
         self._pending = None
+        self._planned = {}
+        self._plan_stream = None
         self.main_stream = None
         if not on:
             self._side = None
             return
+        self._plan_stream = torch.cuda.Stream(device=self.device)
         if tppr_cus > 0:
             n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
             hs, hm = C.c_void_p(), C.c_void_p()
@@ -119,13 +122,28 @@ class TGN(torch.nn.Module):
         else:
             self._side = torch.cuda.Stream(device=self.device)
 
+    def plan_batch(self, batch):
+        """Pipeline mode, streaming T-PPR: the dependency prepass of a batch still two steps away, on
+        its own stream (it reads only the ids and overlaps the update kernel of the batch before)."""
+        em = self.embedding_module
+        if getattr(self, "_side", None) is None or em.tppr_strategy != "streaming":
+            return
+        src_d, dst_d, neg_d, _, eidx_d = batch
+        with torch.cuda.stream(self._plan_stream):
+            nodes_d = torch.cat([src_d, dst_d, neg_d])
+            em.tppr_finder.plan_device(nodes_d, eidx_d, 3, -1)
+        nodes_d.record_stream(self._side)
+        self._planned[(eidx_d.data_ptr(), eidx_d.numel())] = nodes_d
+
     def _tppr_launch(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status):
         em = self.embedding_module
-        nodes_d = torch.cat([src_d, dst_d, neg_d])
+        nodes_d = getattr(self, "_planned", {}).pop((eidx_d.data_ptr(), eidx_d.numel()), None)
+        if nodes_d is None:
+            nodes_d = torch.cat([src_d, dst_d, neg_d])
         ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
         return (nodes_d,) + tuple(em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status))
 
-    def tppr_batch_device(self, batch, prefetch=None, check_status=False):
+    def tppr_batch_device(self, batch, prefetch=None, check_status=False, plan=None):
         """T-PPR query of ``batch`` = (src, dst, neg, ts, eidx) -> (nodes, nbr, eidx, dt, w) device
         tensors, valid on the current stream.  With the pipeline enabled, ``prefetch`` (the NEXT
         batch) is enqueued on the side stream before returning."""
@@ -151,21 +169,24 @@ class TGN(torch.nn.Module):
                 ev2 = torch.cuda.Event()
                 ev2.record(side)
             self._pending = ((prefetch[4].data_ptr(), prefetch[4].numel()), nxt, ev2)
+        if plan is not None:
+            self.plan_batch(plan)
         if check_status and self.embedding_module.tppr_strategy == "streaming":
             self.embedding_module.tppr_finder.check_status()
         return outs
 
     @torch.no_grad()
-    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None):
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):
         """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
         int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
         ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings.
-        ``prefetch`` = the next batch's five tensors (pipeline mode only)."""
+        ``prefetch`` = the next batch's five tensors, ``plan`` = the one after it (pipeline mode only)."""
         if not self.test_mode:
             self.update_memory_in_test(self.memory)
             self.test_mode = True
         em = self.embedding_module
-        nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status)
+        nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status,
+                                                        plan)
         emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
         B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
         self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each

@@ -179,6 +179,14 @@ class tppr_finder:
             check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
         return on, oe, od, ow
 
+    def plan_device(self, nodes_d, eidx_d, n_roles=3, model=-1):
+        """Runs the dependency prepass of a coming ``stream_device`` call (same ``nodes_d`` tensor,
+        same batch) on the CURRENT stream; it reads only the ids, so it can overlap the previous
+        call's update kernel.  Optional: a call without a matching plan runs its own prepass."""
+        B = nodes_d.numel() // n_roles
+        check(lib().zt_tppr_plan(self._live.h, ptr(nodes_d), ptr(eidx_d), C.c_int64(B), C.c_int32(n_roles),
+                                 C.c_int32(model), stream_ptr()), "zt_tppr_plan")
+
     def check_status(self):
         check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
 
