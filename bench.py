@@ -147,8 +147,9 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--tppr-cus", type=int, default=0,
-                    help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest")
+    ap.add_argument("--tppr-cus", type=int, default=48,
+                    help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
+                         "(0 = no masks; also the fallback when masked streams cannot be created)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     a = ap.parse_args()
@@ -206,7 +207,12 @@ def main():
 
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
-        tgn.enable_pipeline(tppr_cus=a.tppr_cus)
+        try:
+            tgn.enable_pipeline(tppr_cus=a.tppr_cus)
+        except Exception as exc:                       # no CU-mask support: plain streams
+            sys.stderr.write("[bench] CU-masked streams unavailable (%s); using plain streams\n" % exc)
+            a.tppr_cus = 0
+            tgn.enable_pipeline(tppr_cus=0)
     main_stream = getattr(tgn, "main_stream", None)
 
     def batch(b):

@@ -194,7 +194,7 @@ struct zt_tppr {
 namespace {
 
 constexpr int CAP = 128;          // candidates per merge: 2k+1 <= 127
-constexpr int WAVES_PER_WG = 4;
+constexpr int WAVES_PER_WG = 8;
 constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
 #ifdef ZT_STAMP
@@ -712,7 +712,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS;
     const long long role_stride = A.role_stride;
     STAMP(0);
-    WL(0, 1); WL(1, blockIdx.x * 4 + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
+    WL(0, 1); WL(1, blockIdx.x * WAVES_PER_WG + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
     int wl_fail = 0;
     unsigned wl_seen = 0;
 
@@ -1027,7 +1027,7 @@ static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, i
     long long waves = (long long)B * n_models;
     // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
     // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
-    // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 4 waves).
+    // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 8 waves).
     static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
     const long long max_waves = (long long)(h->n_cu * WAVES_PER_WG * wgs_per_cu);
     if (waves > max_waves) waves = max_waves;
@@ -1287,7 +1287,7 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
                         if (w[0] == 9 && !slow && (w[6] & 255) == 0) continue;
                         ++shown;
                         fprintf(stderr, "[waitlog] m%d edge %d (u %d v %d wo %d %d owner %d): state %d wg %d wave %d start %d rows +%d end +%d prev %d fail 0x%x seen 0x%x\n",
-                                mo, i, nodes[i], nodes[B + i], wo[i], wo[B + i], own[i], w[0], w[1] >> 2, w[1] & 3, w[2] - tmin,
+                                mo, i, nodes[i], nodes[B + i], wo[i], wo[B + i], own[i], w[0], w[1] / WAVES_PER_WG, w[1] % WAVES_PER_WG, w[2] - tmin,
                                 w[3] - w[2], w[4] - w[2], w[5], w[6], w[7]);
                     }
                 }
