@@ -34,6 +34,14 @@ constexpr int LDS_BUDGET = 150 * 1024;
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+#ifdef ZT_AGG_STAMP
+// diagnostic build only: shader-clock time per phase of k_fc1_agg, summed over workgroups
+__device__ unsigned long long g_agg[8];
+#define AGG_STAMP(i) do { if (threadIdx.x == 0) { const long long t__ = clock64(); atomicAdd(&g_agg[i], (unsigned long long)(t__ - t_prev__)); t_prev__ = t__; } } while (0)
+#else
+#define AGG_STAMP(i) do { } while (0)
+#endif
+
 // Zero-padded copy W[rows][cols] -> Wp[rows_p][cols_p].
 __global__ void k_pad_matrix(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wp, int rows_p,
                              int cols_p)
@@ -68,11 +76,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const int rows = nq * k, rows_p = mt_count * 16;
     const int K1 = D + F + T;
     const size_t mb = ((size_t)m * N + q0) * k;                       // first entry of this tile in [M][N][k]
+#ifdef ZT_AGG_STAMP
+    long long t_prev__ = clock64();
+#endif
 
     // per-row gather indices, staged once so that the row loads below are independent
     int *g_nb = reinterpret_cast<int *>(wn + rows_p);                 // [mt*16]
     int *g_ei = g_nb + rows_p;
     float *g_dt = reinterpret_cast<float *>(g_ei + rows_p);
+    float *tw = g_dt + rows_p;                                        // [T] time-encoding frequencies
 
     // ---- stage the per-row scalars (coalesced), then normalise the weights in LDS ----
     for (int g = tid; g < rows_p; g += AGG_THREADS) {
@@ -87,6 +99,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         }
         g_nb[g] = nb; g_ei[g] = ei; g_dt[g] = d; wn[g] = wv;
     }
+    for (int c = tid; c < T; c += AGG_THREADS) tw[c] = time_w[c];
     __syncthreads();
     // w / sum(w), 0 where the sum is 0 (:267-270); sum in entry order like torch.sum(dim=1)
     float my_sum = 0.f;
@@ -100,11 +113,37 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         if (tid % k == 0) S[(size_t)m * N + q0 + tid / k] = (my_sum == 0.f) ? 0.f : 1.f;
     }
 
+    AGG_STAMP(0);
     // ---- gather: flat (row, column) loops, GU loads in flight per thread before any LDS store
     // ---- (a row-at-a-time loop serialises on HBM latency: 20 rows x ~3 us per wave)
     constexpr int GU = 8;
     const unsigned mD = fastdiv_magic((unsigned)D), mF = fastdiv_magic((unsigned)(F > 0 ? F : 1)),
                    mT = fastdiv_magic((unsigned)(T > 0 ? T : 1));
+    // rows are whole float4s, 16-byte aligned in HBM and in the tile
+    const bool vecD = (D & 3) == 0 && ((size_t)memory & 15) == 0;
+    const bool vecF = vecD && F > 0 && (F & 3) == 0 && ((size_t)efeat & 15) == 0;
+    if (vecD) {
+        // one round trip: every thread has all its 16-byte loads in flight before the first LDS store
+        const int D4 = D >> 2;
+        const unsigned mD4 = fastdiv_magic((unsigned)D4);
+        for (int f0 = tid; f0 < rows_p * D4; f0 += AGG_THREADS * GU) {
+            f32x4 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mD4), c = f - g * D4;
+                v[u] = (f < rows_p * D4 && g < rows)
+                           ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mD4), c = f - g * D4;
+                if (f < rows_p * D4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = v[u];
+            }
+        }
+    } else
     for (int f0 = tid; f0 < rows_p * D; f0 += AGG_THREADS * GU) {
         float v[GU];
 #pragma unroll
@@ -120,6 +159,28 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
             if (f < rows_p * D) A[(size_t)g * lda + c] = v[u];
         }
     }
+    AGG_STAMP(1);
+    if (vecF) {
+        const int F4 = F >> 2;
+        const unsigned mF4 = fastdiv_magic((unsigned)(F4 > 0 ? F4 : 1));
+        for (int f0 = tid; f0 < rows_p * F4; f0 += AGG_THREADS * GU) {
+            f32x4 v[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mF4), c = f - g * F4;
+                v[u] = (f < rows_p * F4 && g < rows)
+                           ? *reinterpret_cast<const f32x4 *>(efeat + (size_t)g_ei[g] * F + 4 * c)
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mF4), c = f - g * F4;
+                if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = v[u];
+            }
+        }
+    } else
     for (int f0 = tid; f0 < rows_p * F; f0 += AGG_THREADS * GU) {
         float v[GU];
 #pragma unroll
@@ -135,9 +196,21 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
             if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
         }
     }
-    for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
-        const int g = fastdiv(f, mT), c = f - g * T;
-        A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(g_dt[g] * time_w[c]) : 0.f;   // cos(t*w + 0)
+    AGG_STAMP(2);
+    for (int f0 = tid; f0 < rows_p * T; f0 += AGG_THREADS * 4) {     // frequencies and dt from LDS, 4 at a time
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = fastdiv(f, mT), c = f - g * T;
+            x[u] = (f < rows_p * T) ? g_dt[g] * tw[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + u * AGG_THREADS;
+            const int g = fastdiv(f, mT), c = f - g * T;
+            if (f < rows_p * T) A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(x[u]) : 0.f;   // cos(t*w + 0)
+        }
     }
     const int padw = K1p - K1;
     const unsigned mP = fastdiv_magic((unsigned)(padw > 0 ? padw : 1));
@@ -145,7 +218,9 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         const int g = fastdiv(f, mP), c = f - g * padw;
         A[(size_t)g * lda + K1 + c] = 0.f;
     }
+    AGG_STAMP(3);
     __syncthreads();
+    AGG_STAMP(4);
 
     // ---- fc1 on f32 MFMA: wave handles N-tiles {wave, wave+4}, all M-tiles ----
     const int NT = (D + 15) / 16;
@@ -190,6 +265,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 #pragma unroll
         for (int b = 0; b < NTW; ++b) bcur[b] = bnext[b];
     }
+    AGG_STAMP(5);
     __syncthreads();   // every wave is done reading the A tile: reuse it for the hidden rows
 
     // ---- bias + ReLU + weight, staged as Hs[g][col] in the A region ----
@@ -213,6 +289,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         }
     }
     __syncthreads();
+    AGG_STAMP(6);
     // ---- reduce over the k neighbours of each query row ----
     for (int idx = tid; idx < nq * D; idx += AGG_THREADS) {
         const int q = fastdiv(idx, mD), c = idx - q * D;
@@ -220,6 +297,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         for (int j = 0; j < k; ++j) s += Hs[(size_t)(q * k + j) * ldh + c];
         H[((size_t)m * N + q0 + q) * D + c] = s;
     }
+    AGG_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------
@@ -374,7 +452,7 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     mt = (rq * k + 15) / 16;
     p.mt = mt;
     p.rq = rq;
-    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16;   // A tile + wn, nbr, eix, dt per row
+    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16 + (size_t)T * 4;   // A tile + wn, nbr, eix, dt per row + time_w
     // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
     if ((size_t)mt * 16 * (p.Dp + 1) * 4 > (size_t)mt * 16 * p.lda * 4) return false;
     size_t o = 0;
@@ -390,6 +468,16 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
 }
 
 }  // namespace
+
+#ifdef ZT_AGG_STAMP
+extern "C" int zt_debug_agg(unsigned long long *host, int reset)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_agg), sizeof(unsigned long long) * 8));
+    if (reset) { unsigned long long z[8] = {0}; ZT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_agg), z, sizeof(z))); }
+    return ZT_OK;
+}
+#endif
 
 extern "C" int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
 {

@@ -98,21 +98,36 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// cos(x) for the time encoding: float64 Cody-Waite reduction (k = rint(x*2/pi), two-term pi/2) and
-// float32 polynomials on [-pi/4, pi/4].  |err| <= 1e-7 over |x| <= 3e8 (ocml cosf: 7e-8), at a
-// fraction of the instructions of the Payne-Hanek path large arguments take in ocml.
-__device__ __forceinline__ float time_cosf(float x)
+// cos(x) for the time encoding.  |x| < 4e6: float32 Cody-Waite reduction with three FMA steps
+// (k = rint(x*2/pi), pi/2 split into floats, two FMA steps: each is exact up to one rounding of an O(1)
+// value); larger arguments: the same reduction in float64.  Float32 polynomials on [-pi/4, pi/4].
+// |err| <= 2e-7 over |x| <= 3e8 (ocml cosf: 7e-8), at a fraction of the instructions of the
+// Payne-Hanek path large arguments take in ocml.
+__device__ __forceinline__ float time_cos_poly(float rf, int q)
+{
+    const float s = rf * rf;
+    const float c = fmaf(s, fmaf(s, fmaf(s, fmaf(s, 2.4801587e-5f, -1.3888889e-3f), 4.1666668e-2f), -0.5f), 1.0f);
+    const float sn = rf * fmaf(s, fmaf(s, fmaf(s, fmaf(s, 2.7557319e-6f, -1.9841270e-4f), 8.3333338e-3f), -1.6666667e-1f), 1.0f);
+    const float res = (q & 1) ? sn : c;
+    return ((q + 1) & 2) ? -res : res;
+}
+
+__device__ __noinline__ float time_cosf_large(float x)
 {
     const double xd = (double)x;
     const double kd = rint(xd * 0.63661977236758134308);
     double r = fma(-kd, 1.57079632679489655800e+00, xd);
     r = fma(-kd, 6.12323399573676603587e-17, r);
-    const int q = (int)(long long)kd;
-    const float rf = (float)r, s = rf * rf;
-    const float c = fmaf(s, fmaf(s, fmaf(s, fmaf(s, 2.4801587e-5f, -1.3888889e-3f), 4.1666668e-2f), -0.5f), 1.0f);
-    const float sn = rf * fmaf(s, fmaf(s, fmaf(s, fmaf(s, 2.7557319e-6f, -1.9841270e-4f), 8.3333338e-3f), -1.6666667e-1f), 1.0f);
-    const float res = (q & 1) ? sn : c;
-    return ((q + 1) & 2) ? -res : res;
+    return time_cos_poly((float)r, (int)kd);     // |x| <= 3e8: k fits an int
+}
+
+__device__ __forceinline__ float time_cosf(float x)
+{
+    if (fabsf(x) >= 4.0e6f) return time_cosf_large(x);
+    const float kf = rintf(x * 0.636619772f);
+    float r = fmaf(kf, -1.57079637e+00f, x);            // pi/2 = 1.57079637 - 4.37113883e-08 - 1.7e-15 (floats);
+    r = fmaf(kf, 4.37113883e-08f, r);                   // the third term is < 5e-9 for |k| < 2.6e6
+    return time_cos_poly(r, (int)kf);
 }
 
 // floor(f / d) for small f via a precomputed multiplier m = fastdiv_magic(d); exact for f*d < 2^32.
