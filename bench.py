@@ -207,6 +207,8 @@ def main():
 
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
+        if world > 1 and not rehearsal:
+            a.tppr_cus = 0          # RCCL kernels run on the main stream: keep it an ordinary (unmasked) stream
         try:
             tgn.enable_pipeline(tppr_cus=a.tppr_cus)
         except Exception as exc:                       # no CU-mask support: plain streams

@@ -284,6 +284,29 @@ int zt_temporal_attention(const float *src_dev, const float *src_time_dev,
                           void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* One-node multi-GPU exchange of touched rows.  The reference  */
+/* has no distributed code; this is the data-path step around the one RCCL     */
+/* all-gather per batch.  A row travels as float32                             */
+/*   [ id (int32 bits) | row of table 0 | row of table 1 | ... ],              */
+/* tables being [num_rows][width] float32 arrays (memory, last_update,         */
+/* messages, message timestamps).                                              */
+/* ------------------------------------------------------------------------ */
+typedef struct zt_row_tables {
+    float *ptr[8];       /* device pointers */
+    int32_t width[8];    /* floats per row */
+    int32_t n;           /* tables in use, 1..8 */
+} zt_row_tables;
+
+/* out_dev [cap][1 + sum(width)]: slot r carries ids_dev[r] and its rows for
+ * r < *n_valid_dev, id = -1 and zeros beyond (fixed-size payload). */
+int zt_pack_rows(const zt_row_tables *tables, const int32_t *ids_dev,
+                 const int32_t *n_valid_dev, int64_t cap, float *out_dev,
+                 void *stream);
+/* Every received row with id >= 0 overwrites that row of the local tables. */
+int zt_scatter_rows(const zt_row_tables *tables, const float *recv_dev,
+                    int64_t rows, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* Test hook (not product API): the exact top-k selection primitive on its    */
 /* own.  vals [cases][n] float64; writes np.argsort(vals[c])[-k:] under       */
 /* numba's quicksort semantics into sel_out [cases][k] and the path taken     */

@@ -26,8 +26,12 @@ SYMBOLS = [
     "zt_tppr_export", "zt_tppr_import",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
     "zt_embed_workspace_bytes", "zt_embed",
-    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
+    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
 ]
+
+
+class RowTables(C.Structure):
+    _fields_ = [("ptr", C.c_void_p * 8), ("width", C.c_int32 * 8), ("n", C.c_int32)]
 
 
 class EmbedWeights(C.Structure):

@@ -268,6 +268,65 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.total = o;
 }
 
+
+// ---- one-node multi-GPU exchange (no reference counterpart) ----
+// A touched row travels as float32 [id (int bits) | row of table 0 | row of table 1 | ...].
+struct RowTables {
+    float *ptr[8];
+    int width[8];
+    int n, row_floats;
+};
+
+// one wavefront per slot r < cap: ids[r] (r < *n_valid) or -1, then the id's row of every table (zeros for -1)
+__global__ __launch_bounds__(256) void k_pack_rows(RowTables T, const int *__restrict__ ids, const int *__restrict__ n_valid,
+                                                   long long cap, float *__restrict__ out)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= cap) return;
+    const int id = r < (long long)*n_valid ? ids[r] : -1;
+    float *o = out + r * T.row_floats;
+    if (lane == 0) o[0] = __int_as_float(id);
+    int col = 1;
+    for (int t = 0; t < T.n; ++t) {
+        const int w = T.width[t];
+        const float *src = T.ptr[t] + (size_t)(id < 0 ? 0 : id) * w;
+        for (int c = lane; c < w; c += 64) o[col + c] = id < 0 ? 0.f : src[c];
+        col += w;
+    }
+}
+
+// one wavefront per received row: rows with id >= 0 overwrite the local tables
+__global__ __launch_bounds__(256) void k_scatter_rows(RowTables T, const float *__restrict__ recv, long long rows)
+{
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *in = recv + r * T.row_floats;
+    const int id = __float_as_int(in[0]);
+    if (id < 0) return;
+    int col = 1;
+    for (int t = 0; t < T.n; ++t) {
+        const int w = T.width[t];
+        float *dst = T.ptr[t] + (size_t)id * w;
+        for (int c = lane; c < w; c += 64) dst[c] = in[col + c];
+        col += w;
+    }
+}
+
+static bool make_tables(const zt_row_tables *t, RowTables &T)
+{
+    if (!t || t->n < 1 || t->n > 8) return false;
+    T.n = t->n;
+    T.row_floats = 1;
+    for (int q = 0; q < t->n; ++q) {
+        if (!t->ptr[q] || t->width[q] < 1) return false;
+        T.ptr[q] = t->ptr[q]; T.width[q] = t->width[q];
+        T.row_floats += t->width[q];
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" int zt_store_messages_range(const float *, const float *, const float *, const float *, int64_t, int64_t, int32_t,
@@ -362,6 +421,33 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh);
     ZT_PROF_END(s, P_GRU);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int zt_pack_rows(const zt_row_tables *tables, const int32_t *ids_dev, const int32_t *n_valid_dev, int64_t cap,
+                            float *out_dev, void *stream)
+{
+    RowTables T;
+    if (!make_tables(tables, T) || !ids_dev || !n_valid_dev || cap < 0 || (cap > 0 && !out_dev)) {
+        set_error("zt_pack_rows: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (cap == 0) return ZT_OK;
+    k_pack_rows<<<(unsigned)((cap + 3) / 4), 256, 0, (hipStream_t)stream>>>(T, ids_dev, n_valid_dev, cap, out_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int zt_scatter_rows(const zt_row_tables *tables, const float *recv_dev, int64_t rows, void *stream)
+{
+    RowTables T;
+    if (!make_tables(tables, T) || rows < 0 || (rows > 0 && !recv_dev)) {
+        set_error("zt_scatter_rows: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (rows == 0) return ZT_OK;
+    k_scatter_rows<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(T, recv_dev, rows);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

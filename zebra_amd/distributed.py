@@ -16,9 +16,13 @@ The reference has no distributed code at all; this is new work:
     rows [id | memory | last_update | message | msg timestamp] are exchanged
     with ONE fixed-size all-gather per batch; every replica scatters them.
 
-``exchange_touched_rows`` is pure torch (works on CPU tensors with gloo), so
-the exchange logic is covered by world_size-2 CPU tests.
+``exchange_touched_rows`` has a pure-torch form for CPU tensors (gloo), which the
+world_size-2 CPU tests cover; on the GPU the pack and the scatter are one HIP
+kernel each (``zt_pack_rows`` / ``zt_scatter_rows``, tested against the torch
+form) and the step never synchronises with the host.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -42,8 +46,8 @@ def pack_rows(tables, ids, n_valid, cap):
     safe = torch.where(valid, ids, torch.zeros_like(ids))
     cols = [torch.where(valid, ids, torch.full_like(ids, -1)).to(torch.int32).view(torch.float32).reshape(cap, 1)]
     for t in tables:
-        rows = t.index_select(0, safe)
-        cols.append(rows.reshape(cap, -1).to(torch.float32))
+        rows = t.index_select(0, safe).reshape(cap, -1).to(torch.float32)
+        cols.append(torch.where(valid.reshape(cap, 1), rows, torch.zeros_like(rows)))      # padding slots: zeros
     return torch.cat(cols, dim=1).contiguous()
 
 
@@ -66,20 +70,59 @@ def unpack_rows(tables, recv):
     return int(sel.numel())
 
 
+def _row_tables(tables):
+    from ._capi import RowTables
+    rt = RowTables()
+    rt.n = len(tables)
+    width = 1
+    for q, t in enumerate(tables):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("exchange tables must be contiguous float32")
+        rt.ptr[q] = t.data_ptr()
+        rt.width[q] = t[0].numel() if t.dim() > 1 else 1
+        width += rt.width[q]
+    return rt, width
+
+
+def pack_rows_device(tables, ids, n_valid, cap):
+    """pack_rows on the GPU (one HIP kernel, no host sync)."""
+    from ._capi import lib, check, ptr, stream_ptr
+    rt, width = _row_tables(tables)
+    out = torch.empty((cap, width), dtype=torch.float32, device=ids.device)
+    nv = n_valid.reshape(1).to(device=ids.device, dtype=torch.int32)
+    check(lib().zt_pack_rows(C.byref(rt), ptr(ids), ptr(nv), C.c_int64(cap), ptr(out), stream_ptr()), "zt_pack_rows")
+    return out
+
+
+def unpack_rows_device(tables, recv):
+    """unpack_rows on the GPU (one HIP kernel, no host sync)."""
+    from ._capi import lib, check, ptr, stream_ptr
+    rt, width = _row_tables(tables)
+    assert recv.shape[1] == width and recv.is_contiguous()
+    check(lib().zt_scatter_rows(C.byref(rt), ptr(recv), C.c_int64(recv.shape[0]), stream_ptr()), "zt_scatter_rows")
+
+
 def exchange_touched_rows(tables, ids, n_valid, cap, group=None):
     """All-gather the rows ``ids[:n_valid]`` of every table in ``tables`` from
     all ranks and write them into the local copies.  Fixed-size payload
-    (cap rows per rank), one collective."""
+    (cap rows per rank), one collective.  CUDA tensors: pack and scatter are HIP
+    kernels and nothing synchronises with the host (CPU tensors: torch ops)."""
     world = dist.get_world_size(group)
+    if ids.is_cuda:
+        send = pack_rows_device(tables, ids, n_valid, cap)
+        if dist.get_backend(group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU in tests): gloo has no GPU all-gather
+            recv_h = torch.empty((world * cap, send.shape[1]), dtype=torch.float32)
+            dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
+            recv = recv_h.to(send.device)
+        else:
+            recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
+            dist.all_gather_into_tensor(recv, send, group=group)
+        unpack_rows_device(tables, recv)
+        return None
     send = pack_rows(tables, ids, n_valid, cap)
-    if send.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsal only (several ranks sharing one GPU in tests): gloo has no GPU all-gather
-        recv_h = torch.empty((world * cap, send.shape[1]), dtype=torch.float32)
-        dist.all_gather_into_tensor(recv_h, send.cpu(), group=group)
-        recv = recv_h.to(send.device)
-    else:
-        recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
-        dist.all_gather_into_tensor(recv, send, group=group)
+    recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
     return unpack_rows(tables, recv)
 
 
