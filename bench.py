@@ -258,6 +258,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    torch.cuda.synchronize()
+    if not a.no_pipeline:
+        tgn.enable_pipeline(False)      # give the CU-masked streams back before the runtime shuts down
+
     # ---- per-kernel HIP-event times over the timed region ----
     kern = {}
     if not a.no_profile:

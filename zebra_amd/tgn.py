@@ -108,6 +108,10 @@ class TGN(torch.nn.Module):
         self._planned = {}
         self._plan_stream = None
         self.main_stream = None
+        for hptr in getattr(self, "_masked", []):          # CU-masked streams of an earlier call
+            torch.cuda.synchronize(self.device)
+            check(lib().zt_stream_destroy(C.c_void_p(hptr)))
+        self._masked = []
         if not on:
             self._side = None
             return
@@ -117,6 +121,7 @@ class TGN(torch.nn.Module):
             hs, hm = C.c_void_p(), C.c_void_p()
             check(lib().zt_stream_create_masked(C.byref(hs), C.c_int32(0), C.c_int32(tppr_cus)))
             check(lib().zt_stream_create_masked(C.byref(hm), C.c_int32(tppr_cus), C.c_int32(n_cu)))
+            self._masked = [hs.value, hm.value]
             self._side = torch.cuda.ExternalStream(hs.value, device=self.device)
             self.main_stream = torch.cuda.ExternalStream(hm.value, device=self.device)
         else:
