@@ -123,6 +123,11 @@ int zt_tppr_status(zt_tppr *h, void *stream);
 int zt_tppr_export(zt_tppr *h, int32_t m, int32_t *len_host, double *norm_host,
                    int64_t *eidx_host, int64_t *node_host, double *ts_host,
                    double *w_host);
+/* The same for the n nodes ids_host[0..n) only (outputs [n], [n][k]): what a
+ * checkpoint of a 10^7-node graph wants -- only the nodes the stream has touched. */
+int zt_tppr_export_rows(zt_tppr *h, int32_t m, const int64_t *ids_host, int64_t n,
+                        int32_t *len_host, double *norm_host, int64_t *eidx_host,
+                        int64_t *node_host, double *ts_host, double *w_host);
 int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host,
                    const double *norm_host, const int64_t *eidx_host,
                    const int64_t *node_host, const double *ts_host,

@@ -160,3 +160,65 @@ def test_pipelined_step_matches_sequential(tppr_cus):
     assert np.array_equal(outs["seq"][1], outs["pipe"][1])
     for kk in outs["seq"][2]:
         assert np.array_equal(outs["seq"][2][kk], outs["pipe"][2][kk])
+
+
+def test_full_size_step_properties():
+    """The whole eval step at BASELINE.json's full-size configuration (C5: 10 M nodes, bs=4096, k=20,
+    D=T=100, F=1), checked through size-independent properties: (1) the pipelined schedule (T-PPR one
+    batch ahead on a CU-masked stream, prepass two batches ahead) equals the sequential one bit for bit
+    -- embeddings, touched memory rows, pending messages; (2) rows of a batch are independent given
+    the pre-batch state (modules/embedding_module.py:243-276): embedding a sub-range of the rows gives
+    the same values as the full call; (3) only the batch's endpoints change in the memory."""
+    from zebra_amd import synth
+    wl = synth.WORKLOADS["c5"]
+    N, B, k, D, F, T = wl["n_nodes"], 4096, 20, 100, 1, 100
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    nb = 12
+    src, dst, ts, eidx = synth.power_law_stream(N, nb * B, seed=91)
+    neg = synth.negatives(dst, len(src), seed=92)
+    w = I.model_weights(D, F, T, len(al), 93)
+    efeat = synth.edge_features(nb * B + 1, F, seed=94)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    touched = torch.from_numpy(np.unique(np.concatenate([src, dst])).astype(np.int64)).to(dev)
+    res = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N + 1, nb * B + 1, D, F, T, k, al, be, w, efeat).eval()
+        g = torch.Generator(device="cuda").manual_seed(95)
+        tgn.memory.memory.copy_(torch.randn(tgn.memory.memory.shape, generator=g, device="cuda") * 0.1)
+        if mode == "pipe":
+            tgn.enable_pipeline(tppr_cus=48)
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        before = tgn.memory.memory.clone() if mode == "seq" else None
+        embs = []
+        with torch.cuda.stream(main):
+            for b in range(nb):
+                cur = tuple(x[b * B:(b + 1) * B] for x in t)
+                nxt = tuple(x[(b + 1) * B:(b + 2) * B] for x in t) if (mode == "pipe" and b + 1 < nb) else None
+                nx2 = tuple(x[(b + 2) * B:(b + 3) * B] for x in t) if (mode == "pipe" and b + 2 < nb) else None
+                embs.append(tgn.step_device(*cur, prefetch=nxt, plan=nx2).clone())
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        res[mode] = (torch.stack(embs), tgn.memory.memory.index_select(0, touched),
+                     tgn.memory.messages.index_select(0, touched), tgn.memory.last_update.index_select(0, touched))
+        if mode == "seq":
+            # (3) untouched rows keep their values
+            mask = torch.ones(N + 1, dtype=torch.bool, device=dev)
+            mask[touched] = False
+            assert torch.equal(tgn.memory.memory[mask], before[mask])
+            # (2) a sub-range of rows, embedded on its own from the final state
+            em = tgn.embedding_module
+            b = nb - 1
+            nodes = torch.cat([t[0][b * B:(b + 1) * B], t[1][b * B:(b + 1) * B], t[2][b * B:(b + 1) * B]])
+            on, oe, od, ow = em.tppr_finder.stream_device(nodes, t[3][b * B:(b + 1) * B], t[4][b * B:(b + 1) * B], 3, True, -1)
+            full = em.embed_device(tgn.memory.memory, nodes, on, oe, od, ow)
+            lo, hi = 1000, 1777
+            part = em.embed_device(tgn.memory.memory, nodes[lo:hi].contiguous(), on[:, lo:hi].contiguous(),
+                                   oe[:, lo:hi].contiguous(), od[:, lo:hi].contiguous(), ow[:, lo:hi].contiguous())
+            assert torch.equal(full[lo:hi], part)
+            assert torch.isfinite(full).all()
+        tgn.enable_pipeline(False)
+        del tgn
+        torch.cuda.empty_cache()
+    for a, b in zip(res["seq"], res["pipe"]):
+        assert torch.equal(a, b)

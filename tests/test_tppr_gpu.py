@@ -273,3 +273,73 @@ def test_large_single_call_and_epoch_wrap(zt, oracle):
             assert np.array_equal(np.stack(x), np.stack(y)), "differs after epoch jump at %d" % s
     for m in range(2):
         _cmp_state(f.export_state(m), o.export(m))
+
+
+def test_full_size_properties(zt):
+    """BASELINE.json's full-size configuration (C5: 10 M nodes, bs=4096, k=20, two models) is far beyond
+    what the oracle replays in a test, so the streaming path is checked there through properties that do
+    not depend on the size: (1) batch-split invariance -- the reference applies edges one by one
+    (utils/util.py:499-574), so a batch applied in one call, in two halves or in ragged pieces must
+    leave bit-identical dictionaries, and the rows emitted for an edge only depend on the edges before
+    it; (2) determinism under the scheduler -- two runs of the same stream agree bit for bit although
+    thousands of wavefronts race through the per-node chains; (3) kept weights and norms are positive,
+    keys inside a dictionary are unique, and the newest key of the hub is the last edge that touched it."""
+    import torch
+    from zebra_amd import synth
+    wl = synth.WORKLOADS["c5"]
+    N, B, k = wl["n_nodes"], 4096, 20
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    nb_fill, nb_chk = 60, 4
+    src, dst, ts, eidx = synth.power_law_stream(N, (nb_fill + nb_chk) * B, seed=77)
+    neg = synth.negatives(dst, len(src), seed=78)
+    d = torch.device("cuda")
+    sd, dd, nd = [torch.from_numpy(x).to(d) for x in (src, dst, neg)]
+    td, ed = torch.from_numpy(ts).to(d), torch.from_numpy(eidx).to(d)
+
+    def run(pieces):
+        """pieces(b) -> list of (lo, hi) covering batch b's edges in order"""
+        f = zt.tppr_finder(N + 1, k, 2, al, be)
+        outs = []
+        for b in range(nb_fill + nb_chk):
+            rows = [[], [], [], []]
+            for lo, hi in (pieces(b) if b >= nb_fill else [(b * B, (b + 1) * B)]):
+                o = f.stream_device(torch.cat([sd[lo:hi], dd[lo:hi], nd[lo:hi]]), td[lo:hi], ed[lo:hi], 3, True, -1,
+                                    check_status=False)
+                n = hi - lo
+                for q in range(4):      # [models][3n][k] -> per role [models][n][k]
+                    rows[q].append(o[q].reshape(2, 3, n, k))
+            if b >= nb_fill:
+                outs.append([torch.cat(r, dim=2) for r in rows])
+        f.check_status()
+        return f, outs
+
+    whole = lambda b: [(b * B, (b + 1) * B)]
+    halves = lambda b: [(b * B, b * B + B // 2), (b * B + B // 2, (b + 1) * B)]
+    ragged = lambda b: [(b * B, b * B + 1), (b * B + 1, b * B + 700), (b * B + 700, b * B + 701),
+                        (b * B + 701, (b + 1) * B)]
+    fa, oa = run(whole)
+    for name, pc in (("halves", halves), ("ragged", ragged), ("whole again", whole)):
+        fb, ob = run(pc)
+        for x, y in zip(oa, ob):
+            for q in range(4):
+                assert torch.equal(x[q], y[q]), "%s: emitted rows differ" % name
+        hot = np.unique(np.concatenate([src, dst])).astype(np.int64)
+        for m in range(2):
+            sa, sb = fa.export_rows(m, hot), fb.export_rows(m, hot)
+            for kk in sa:
+                assert np.array_equal(sa[kk], sb[kk]), "%s: state %s of model %d differs" % (name, kk, m)
+        del fb
+    hot = np.unique(np.concatenate([src, dst])).astype(np.int64)
+    hub = int(np.bincount(np.concatenate([src, dst])).argmax())
+    last = int(np.where((src == hub) | (dst == hub))[0].max())
+    for m in range(2):
+        st = fa.export_rows(m, hot)
+        live = np.arange(k)[None, :] < st["len"][:, None]
+        assert (st["len"] >= 1).all() and (st["len"] <= k).all()
+        assert (st["w"][live] > 0).all() and (st["norm"] > 0).all()
+        key = st["eidx"] * (N + 2) + st["node"]
+        key[~live] = -1 - np.arange((~live).sum())            # padding: all different
+        srt = np.sort(key, axis=1)
+        assert (np.diff(srt, axis=1) != 0).all()
+        hrow = fa.export_rows(m, np.array([hub], np.int64))
+        assert eidx[last] in hrow["eidx"][0, : hrow["len"][0]]

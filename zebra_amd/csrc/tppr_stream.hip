@@ -1298,6 +1298,39 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
     return st;
 }
 
+namespace {
+// granules of one row -> the reference's dictionary items in iteration order (zeros beyond len)
+void decode_row(const u64 *r, size_t k, int32_t *len_out, double *norm_out, int64_t *eidx, int64_t *node, double *ts,
+                double *w)
+{
+    auto lo = [](u64 x) { return (u64)(unsigned)x; };
+    *len_out = (int)(unsigned)r[0];
+    const u64 nb = lo(r[1]) | (lo(r[2]) << 32);
+    memcpy(norm_out, &nb, 8);
+    for (size_t j = 0; j < k; ++j) {
+        const u64 *e = r + HDR + j;
+        if ((int)j < *len_out) {
+            node[j] = (int64_t)lo(e[0]);
+            eidx[j] = (int64_t)lo(e[k]);
+            const u64 tb = lo(e[2 * k]) | (lo(e[3 * k]) << 32), wb = lo(e[4 * k]) | (lo(e[5 * k]) << 32);
+            memcpy(&ts[j], &tb, 8);
+            memcpy(&w[j], &wb, 8);
+        } else {
+            eidx[j] = 0; node[j] = 0; ts[j] = 0.0; w[j] = 0.0;
+        }
+    }
+}
+
+__global__ void k_gather_rows(const u64 *__restrict__ rows, const long long *__restrict__ ids, long long n, int rg,
+                              u64 *__restrict__ out)
+{
+    const long long r = blockIdx.x;
+    if (r >= n) return;
+    const u64 *src = rows + ids[r] * rg;
+    for (int c = threadIdx.x; c < rg; c += blockDim.x) out[r * rg + c] = src[c];
+}
+}  // namespace
+
 extern "C" int zt_tppr_export(zt_tppr *h, int32_t m, int32_t *len_host, double *norm_host, int64_t *eidx_host,
                               int64_t *node_host, double *ts_host, double *w_host)
 {
@@ -1306,26 +1339,35 @@ extern "C" int zt_tppr_export(zt_tppr *h, int32_t m, int32_t *len_host, double *
     const size_t N = (size_t)h->N, k = (size_t)h->k, rg = (size_t)h->rg;
     std::vector<u64> g(N * rg);
     ZT_HIP(hipMemcpy(g.data(), h->rows + (size_t)m * N * rg, N * rg * sizeof(u64), hipMemcpyDeviceToHost));
-    auto lo = [](u64 x) { return (u64)(unsigned)x; };
-    for (size_t v = 0; v < N; ++v) {
-        const u64 *r = g.data() + v * rg;
-        len_host[v] = (int)(unsigned)r[0];
-        const u64 nb = lo(r[1]) | (lo(r[2]) << 32);
-        memcpy(&norm_host[v], &nb, 8);
-        for (size_t j = 0; j < k; ++j) {
-            const size_t p = v * k + j;
-            const u64 *e = r + HDR + j;
-            if ((int)j < len_host[v]) {
-                node_host[p] = (int64_t)lo(e[0]);
-                eidx_host[p] = (int64_t)lo(e[k]);
-                const u64 tb = lo(e[2 * k]) | (lo(e[3 * k]) << 32), wb = lo(e[4 * k]) | (lo(e[5 * k]) << 32);
-                memcpy(&ts_host[p], &tb, 8);
-                memcpy(&w_host[p], &wb, 8);
-            } else {
-                eidx_host[p] = 0; node_host[p] = 0; ts_host[p] = 0.0; w_host[p] = 0.0;
-            }
-        }
-    }
+    for (size_t v = 0; v < N; ++v)
+        decode_row(g.data() + v * rg, k, &len_host[v], &norm_host[v], eidx_host + v * k, node_host + v * k,
+                   ts_host + v * k, w_host + v * k);
+    return ZT_OK;
+}
+
+extern "C" int zt_tppr_export_rows(zt_tppr *h, int32_t m, const int64_t *ids_host, int64_t n, int32_t *len_host,
+                                   double *norm_host, int64_t *eidx_host, int64_t *node_host, double *ts_host,
+                                   double *w_host)
+{
+    if (!h || m < 0 || m >= h->M || n < 0 || (n > 0 && !ids_host)) return ZT_ERR_ARG;
+    if (n == 0) return ZT_OK;
+    for (int64_t q = 0; q < n; ++q)
+        if (ids_host[q] < 0 || ids_host[q] >= h->N) { set_error("zt_tppr_export_rows: id out of range"); return ZT_ERR_RANGE; }
+    ZT_HIP(hipDeviceSynchronize());
+    const size_t k = (size_t)h->k, rg = (size_t)h->rg;
+    long long *ids_dev = nullptr;
+    u64 *buf_dev = nullptr;
+    ZT_HIP(hipMalloc(&ids_dev, (size_t)n * sizeof(long long)));
+    ZT_HIP(hipMalloc(&buf_dev, (size_t)n * rg * sizeof(u64)));
+    ZT_HIP(hipMemcpy(ids_dev, ids_host, (size_t)n * sizeof(long long), hipMemcpyHostToDevice));
+    k_gather_rows<<<(unsigned)n, 128>>>(h->rows + (size_t)m * (size_t)h->N * rg, ids_dev, n, (int)rg, buf_dev);
+    std::vector<u64> g((size_t)n * rg);
+    hipError_t e = hipMemcpy(g.data(), buf_dev, (size_t)n * rg * sizeof(u64), hipMemcpyDeviceToHost);
+    (void)hipFree(ids_dev); (void)hipFree(buf_dev);
+    ZT_HIP(e);
+    for (size_t v = 0; v < (size_t)n; ++v)
+        decode_row(g.data() + v * rg, k, &len_host[v], &norm_host[v], eidx_host + v * k, node_host + v * k,
+                   ts_host + v * k, w_host + v * k);
     return ZT_OK;
 }
 

@@ -58,6 +58,19 @@ class _TpprState:
               "zt_tppr_export")
         return dict(len=ln, norm=norm, eidx=e, node=nd, ts=ts, w=w)
 
+    def export_rows(self, m, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        n, k = len(ids), self.shape[1]
+        ln = np.empty(n, np.int32)
+        norm = np.empty(n, np.float64)
+        e = np.empty((n, k), np.int64)
+        nd = np.empty((n, k), np.int64)
+        ts = np.empty((n, k), np.float64)
+        w = np.empty((n, k), np.float64)
+        check(lib().zt_tppr_export_rows(self.h, C.c_int32(m), ptr(ids), C.c_int64(n), ptr(ln), ptr(norm), ptr(e),
+                                        ptr(nd), ptr(ts), ptr(w)), "zt_tppr_export_rows")
+        return dict(len=ln, norm=norm, eidx=e, node=nd, ts=ts, w=w)
+
     def import_(self, m, st):
         check(lib().zt_tppr_import(self.h, C.c_int32(m), ptr(np.ascontiguousarray(st["len"], np.int32)),
                                    ptr(np.ascontiguousarray(st["norm"], np.float64)),
@@ -145,6 +158,10 @@ class tppr_finder:
     def export_state(self, m):
         """Dense view of model m's dictionaries (iteration order)."""
         return self._live.export(m)
+
+    def export_rows(self, m, node_ids):
+        """The same for the given nodes only: arrays [n], [n][k] (large graphs: the touched nodes)."""
+        return self._live.export_rows(m, node_ids)
 
     # ------------------------------------------------------------- streaming
     def _upload(self, source_nodes, timestamps, edge_idxs, n_roles):
