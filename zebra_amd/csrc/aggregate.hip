@@ -76,6 +76,18 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const int rows = nq * k, rows_p = mt_count * 16;
     const int K1 = D + F + T;
     const size_t mb = ((size_t)m * N + q0) * k;                       // first entry of this tile in [M][N][k]
+    // ---- this wave's N-tiles {wave, wave+4}; weight fragments stream from L2 one chunk ahead of their MFMAs
+    // ---- (keeping all of them in registers was measured: no gain, and it halves the occupancy)
+    const int NT = (D + 15) / 16;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const float *bp[NTW];
+    bool live[NTW];
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        const int nt = wave + b * AGG_WAVES;
+        live[b] = nt < NT;
+        bp[b] = W1p + (size_t)((live[b] ? nt : 0) * 16 + r16) * K1p + 4 * g4;
+    }
 #ifdef ZT_AGG_STAMP
     long long t_prev__ = clock64();
 #endif
@@ -122,11 +134,83 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     // rows are whole float4s, 16-byte aligned in HBM and in the tile
     const bool vecD = (D & 3) == 0 && ((size_t)memory & 15) == 0;
     const bool vecF = vecD && F > 0 && (F & 3) == 0 && ((size_t)efeat & 15) == 0;
+    // cos(dt * w_c) for every (row, frequency); reads only LDS
+    auto time_encode = [&]() {
+        for (int f0 = tid; f0 < rows_p * T; f0 += AGG_THREADS * 4) {     // frequencies and dt from LDS, 4 at a time
+            float x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mT), c = f - g * T;
+                x[u] = (f < rows_p * T) ? g_dt[g] * tw[c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mT), c = f - g * T;
+                if (f < rows_p * T) A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(x[u]) : 0.f;   // cos(t*w + 0)
+            }
+        }
+    };
     if (vecD) {
-        // one round trip: every thread has all its 16-byte loads in flight before the first LDS store
-        const int D4 = D >> 2;
-        const unsigned mD4 = fastdiv_magic((unsigned)D4);
-        for (int f0 = tid; f0 < rows_p * D4; f0 += AGG_THREADS * GU) {
+        // One memory round trip for the whole gather, with the time encoding computed underneath it: the
+        // first GU 16-byte loads of every thread (all of them for D = 100, k = 20) and the first batch
+        // of edge-feature loads are issued, then the cosines are evaluated, then the loaded values are
+        // stored to the tile.  (Memory latency under the gather load is ~3-4 us per dependent access.)
+        const int D4 = D >> 2, F4 = F >> 2;
+        const unsigned mD4 = fastdiv_magic((unsigned)D4), mF4 = fastdiv_magic((unsigned)(F4 > 0 ? F4 : 1));
+        f32x4 vm[GU], vf[GU];
+        float sf[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = tid + u * AGG_THREADS;
+            const int g = fastdiv(f, mD4), c = f - g * D4;
+            vm[u] = (f < rows_p * D4 && g < rows) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (vecF) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mF4), c = f - g * F4;
+                vf[u] = (f < rows_p * F4 && g < rows)
+                            ? *reinterpret_cast<const f32x4 *>(efeat + (size_t)g_ei[g] * F + 4 * c)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mF), c = f - g * F;
+                sf[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
+            }
+        }
+        AGG_STAMP(1);
+        time_encode();
+        AGG_STAMP(2);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int f = tid + u * AGG_THREADS;
+            const int g = fastdiv(f, mD4), c = f - g * D4;
+            if (f < rows_p * D4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = vm[u];
+        }
+        if (vecF) {
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mF4), c = f - g * F4;
+                if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = vf[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mF), c = f - g * F;
+                if (f < rows_p * F) A[(size_t)g * lda + D + c] = sf[u];
+            }
+        }
+        // whatever does not fit the first batch
+        for (int f0 = tid + AGG_THREADS * GU; f0 < rows_p * D4; f0 += AGG_THREADS * GU) {
             f32x4 v[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
@@ -143,74 +227,75 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 if (f < rows_p * D4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = v[u];
             }
         }
-    } else
-    for (int f0 = tid; f0 < rows_p * D; f0 += AGG_THREADS * GU) {
-        float v[GU];
+        if (vecF) {
+            for (int f0 = tid + AGG_THREADS * GU; f0 < rows_p * F4; f0 += AGG_THREADS * GU) {
+                f32x4 v[GU];
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mD), c = f - g * D;
-            v[u] = (f < rows_p * D && g < rows) ? memory[(size_t)g_nb[g] * D + c] : 0.f;
-        }
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF4), c = f - g * F4;
+                    v[u] = (f < rows_p * F4 && g < rows)
+                               ? *reinterpret_cast<const f32x4 *>(efeat + (size_t)g_ei[g] * F + 4 * c)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mD), c = f - g * D;
-            if (f < rows_p * D) A[(size_t)g * lda + c] = v[u];
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF4), c = f - g * F4;
+                    if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = v[u];
+                }
+            }
+        } else {
+            for (int f0 = tid + AGG_THREADS * GU; f0 < rows_p * F; f0 += AGG_THREADS * GU) {
+                float v[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF), c = f - g * F;
+                    v[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF), c = f - g * F;
+                    if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+                }
+            }
         }
-    }
-    AGG_STAMP(1);
-    if (vecF) {
-        const int F4 = F >> 2;
-        const unsigned mF4 = fastdiv_magic((unsigned)(F4 > 0 ? F4 : 1));
-        for (int f0 = tid; f0 < rows_p * F4; f0 += AGG_THREADS * GU) {
-            f32x4 v[GU];
+    } else {
+        for (int f0 = tid; f0 < rows_p * D; f0 += AGG_THREADS * GU) {
+            float v[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int f = f0 + u * AGG_THREADS;
-                const int g = fastdiv(f, mF4), c = f - g * F4;
-                v[u] = (f < rows_p * F4 && g < rows)
-                           ? *reinterpret_cast<const f32x4 *>(efeat + (size_t)g_ei[g] * F + 4 * c)
-                           : f32x4{0.f, 0.f, 0.f, 0.f};
+                const int g = fastdiv(f, mD), c = f - g * D;
+                v[u] = (f < rows_p * D && g < rows) ? memory[(size_t)g_nb[g] * D + c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int f = f0 + u * AGG_THREADS;
-                const int g = fastdiv(f, mF4), c = f - g * F4;
-                if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = v[u];
+                const int g = fastdiv(f, mD), c = f - g * D;
+                if (f < rows_p * D) A[(size_t)g * lda + c] = v[u];
             }
         }
-    } else
-    for (int f0 = tid; f0 < rows_p * F; f0 += AGG_THREADS * GU) {
-        float v[GU];
+        AGG_STAMP(1);
+        for (int f0 = tid; f0 < rows_p * F; f0 += AGG_THREADS * GU) {
+            float v[GU];
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mF), c = f - g * F;
-            v[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
-        }
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mF), c = f - g * F;
+                v[u] = (f < rows_p * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
+            }
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mF), c = f - g * F;
-            if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+            for (int u = 0; u < GU; ++u) {
+                const int f = f0 + u * AGG_THREADS;
+                const int g = fastdiv(f, mF), c = f - g * F;
+                if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+            }
         }
-    }
-    AGG_STAMP(2);
-    for (int f0 = tid; f0 < rows_p * T; f0 += AGG_THREADS * 4) {     // frequencies and dt from LDS, 4 at a time
-        float x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mT), c = f - g * T;
-            x[u] = (f < rows_p * T) ? g_dt[g] * tw[c] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f = f0 + u * AGG_THREADS;
-            const int g = fastdiv(f, mT), c = f - g * T;
-            if (f < rows_p * T) A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(x[u]) : 0.f;   // cos(t*w + 0)
-        }
+        AGG_STAMP(2);
+        time_encode();
     }
     const int padw = K1p - K1;
     const unsigned mP = fastdiv_magic((unsigned)(padw > 0 ? padw : 1));
@@ -223,47 +308,38 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     AGG_STAMP(4);
 
     // ---- fc1 on f32 MFMA: wave handles N-tiles {wave, wave+4}, all M-tiles ----
-    const int NT = (D + 15) / 16;
-    const int r16 = lane & 15, g4 = lane >> 4;
     f32x4 acc[MAX_MT][NTW];
 #pragma unroll
     for (int a = 0; a < MAX_MT; ++a)
 #pragma unroll
         for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *bp[NTW];
-    bool live[NTW];
+    {
+        const int nchunk = K1p / 16;
+        f32x4 bcur[NTW], bnext[NTW];
 #pragma unroll
-    for (int b = 0; b < NTW; ++b) {
-        const int nt = wave + b * AGG_WAVES;
-        live[b] = nt < NT;
-        bp[b] = W1p + (size_t)((live[b] ? nt : 0) * 16 + r16) * K1p + 4 * g4;
-    }
-    const int nchunk = K1p / 16;
-    f32x4 bcur[NTW], bnext[NTW];
+        for (int b = 0; b < NTW; ++b) bcur[b] = *reinterpret_cast<const f32x4 *>(bp[b]);
+        for (int kc = 0; kc < nchunk; ++kc) {
+            if (kc + 1 < nchunk) {
 #pragma unroll
-    for (int b = 0; b < NTW; ++b) bcur[b] = *reinterpret_cast<const f32x4 *>(bp[b]);
-    for (int kc = 0; kc < nchunk; ++kc) {
-        if (kc + 1 < nchunk) {
-#pragma unroll
-            for (int b = 0; b < NTW; ++b) bnext[b] = *reinterpret_cast<const f32x4 *>(bp[b] + 16 * (kc + 1));
-        }
-#pragma unroll
-        for (int a = 0; a < MAX_MT; ++a) {
-            if (a < mt_count) {
-                const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4);
-#pragma unroll
-                for (int b = 0; b < NTW; ++b) {
-                    if (live[b]) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bcur[b][0], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bcur[b][1], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bcur[b][2], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bcur[b][3], acc[a][b], 0, 0, 0);
-                    }
-                }
+                for (int b = 0; b < NTW; ++b) bnext[b] = *reinterpret_cast<const f32x4 *>(bp[b] + 16 * (kc + 1));
             }
-        }
+            f32x4 av[MAX_MT];
 #pragma unroll
-        for (int b = 0; b < NTW; ++b) bcur[b] = bnext[b];
+            for (int a = 0; a < MAX_MT; ++a)
+                av[a] = a < mt_count
+                            ? *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < MAX_MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NTW; ++b)
+                        if (a < mt_count && live[b])
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bcur[b][j], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NTW; ++b) bcur[b] = bnext[b];
+        }
     }
     AGG_STAMP(5);
     __syncthreads();   // every wave is done reading the A tile: reuse it for the hidden rows
@@ -440,7 +516,8 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     p.K1p = round_up(K1, 16);
     p.lda = p.K1p + 4;
     // M-tiles per workgroup: as many whole query rows as fit in 5 tiles / the LDS budget
-    int mt = MAX_MT;
+    static const int mt_env = getenv("ZT_AGG_MT") ? atoi(getenv("ZT_AGG_MT")) : 0;
+    int mt = (mt_env >= 1 && mt_env <= MAX_MT) ? mt_env : MAX_MT;
     while (mt > 1 && ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
     int rq = (mt * 16) / k;
     if (rq < 1) {
