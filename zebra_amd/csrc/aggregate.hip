@@ -134,22 +134,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     // rows are whole float4s, 16-byte aligned in HBM and in the tile
     const bool vecD = (D & 3) == 0 && ((size_t)memory & 15) == 0;
     const bool vecF = vecD && F > 0 && (F & 3) == 0 && ((size_t)efeat & 15) == 0;
-    // cos(dt * w_c) for every (row, frequency); reads only LDS
+    // cos(dt * w_c) for every (row, frequency); reads only LDS.  Element f = tid + n*256 -> (row g,
+    // frequency c) is advanced incrementally: no division in the loop.
+    const int step_g = AGG_THREADS / (T > 0 ? T : 1), step_c = AGG_THREADS - step_g * T;
     auto time_encode = [&]() {
-        for (int f0 = tid; f0 < rows_p * T; f0 += AGG_THREADS * 4) {     // frequencies and dt from LDS, 4 at a time
-            float x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u * AGG_THREADS;
-                const int g = fastdiv(f, mT), c = f - g * T;
-                x[u] = (f < rows_p * T) ? g_dt[g] * tw[c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u * AGG_THREADS;
-                const int g = fastdiv(f, mT), c = f - g * T;
-                if (f < rows_p * T) A[(size_t)g * lda + D + F + c] = g < rows ? time_cosf(x[u]) : 0.f;   // cos(t*w + 0)
-            }
+        int g = fastdiv(tid, mT), c = tid - g * T;
+        for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
+            A[g * lda + D + F + c] = g < rows ? time_cosf(g_dt[g] * tw[c]) : 0.f;      // cos(t*w + 0)
+            g += step_g; c += step_c;
+            if (c >= T) { c -= T; ++g; }
         }
     };
     if (vecD) {
