@@ -216,13 +216,21 @@ __device__ int g_wl[2 * MAX_CHUNK * 8];
 #define WL(f, v) do { } while (0)
 #endif
 
+constexpr int HTAB = 1024;        // slots of a wave's key-hash table (all -1 between uses)
+
 struct WaveLds {
     u64 key[CAP];
     double ts[CAP];
     double w[CAP];
     int sel[64];
     SortLds sort;
+    int htab[HTAB];
 };
+
+__device__ __forceinline__ int key_hash(u64 key)
+{
+    return (int)((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA77u)) >> 22);
+}
 
 __host__ __device__ inline u64 granule(unsigned tag, unsigned payload) { return ((u64)tag << 32) | payload; }
 
@@ -494,7 +502,36 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     const bool in2 = lane < len2;
     const double add = r2.w * scale_s2;
     bool matched2 = false;                      // this lane's s2 entry met its key in s1
+    bool matched_done = false;
     if (n1 > 0 && len2 > 0) {
+        // Key matching, fast path: s2's entries enter a hash table in LDS (slot = hash of the key, value =
+        // lane); if no two of them share a slot, an s1 entry can only match the entry in ITS slot, which
+        // it fetches from the lane holding it and compares in full.  Keys are unique inside a
+        // dictionary, so an entry has at most one partner.  Slot collisions (~1 call in 6 for 20
+        // entries in 1024 slots) take the all-pairs path below.
+        int *T = L.htab;
+        const int h1 = key_hash(r1.key), h2 = key_hash(r2.key);
+        if (in2) T[h2] = lane;
+        L.sort.r[lane] = 0;
+        wave_sync();
+        const int back = in2 ? T[h2] : lane;
+        const int cand = in1 ? T[h1] : -1;
+        if (__ballot(in2 && back != lane) == 0ull) {
+            const int src = cand >= 0 ? cand : 0;
+            const u64 kj = __shfl(r2.key, src);
+            const double tj = __shfl(r2.ts, src), aj = __shfl(add, src);
+            const bool hit = in1 && cand >= 0 && kj == r1.key && tj == r1.ts;
+            if (hit) { w1 = w1 + aj; L.sort.r[cand] = 1; }      // t_s1_PPR[key] += value * scale_s2
+            if (in2) T[h2] = -1;
+            wave_sync();
+            matched2 = in2 && L.sort.r[lane] != 0;
+            matched_done = true;
+        } else {
+            if (in2 && back == lane) T[h2] = -1;                // the slot's last writer clears it
+        }
+        wave_sync();
+    }
+    if (n1 > 0 && len2 > 0 && !matched_done) {
         // Key matching through LDS, all pairs at once: the rows are staged (s1 in slots [0,64), s2
         // in [64,128)), lane (c, i) compares s1's entry i with every S-th entry of s2 starting at c.
         // Keys are unique inside a dictionary, so an entry has at most one partner.  Four dependent
@@ -865,6 +902,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) return;   // rejected by k_count: touch nothing
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     if (threadIdx.x == 0) { mail.head = 0; mail.tag = 0; }
+    for (int q = lane; q < HTAB; q += WAVE) L.htab[q] = -1;
     __syncthreads();
     const int n_models = A.n_models;
 
