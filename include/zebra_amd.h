@@ -132,6 +132,13 @@ int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host,
                    const double *norm_host, const int64_t *eidx_host,
                    const int64_t *node_host, const double *ts_host,
                    const double *w_host);
+/* The same for the n nodes ids_host[0..n) only (inputs [n], [n][k]); rows of
+ * other nodes are left as they are.  With zt_tppr_export_rows: a checkpoint
+ * that only holds the nodes the stream has touched. */
+int zt_tppr_import_rows(zt_tppr *h, int32_t m, const int64_t *ids_host, int64_t n,
+                        const int32_t *len_host, const double *norm_host,
+                        const int64_t *eidx_host, const int64_t *node_host,
+                        const double *ts_host, const double *w_host);
 
 /* ------------------------------------------------------------------------ */
 /* Static adjacency + pruning T-PPR -- utils/util.py:90-276                  */

@@ -343,3 +343,38 @@ def test_full_size_properties(zt):
         assert (np.diff(srt, axis=1) != 0).all()
         hrow = fa.export_rows(m, np.array([hub], np.int64))
         assert eidx[last] in hrow["eidx"][0, : hrow["len"][0]]
+
+
+def test_checkpoint_round_trip(zt, oracle, tmp_path):
+    """a run interrupted after some batches, checkpointed through ``state_dict`` (only
+    the touched nodes, written with np.savez), restored into a NEW finder and continued must equal the
+    uninterrupted run and the oracle bit for bit."""
+    N, E, k, bs = 3000, 12000, 20, 600
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, 811)
+    o = oracle.TpprOracle(N, k, 2, al, be)
+    a = zt.tppr_finder(N, k, 2, al, be)
+    half = (E // bs // 2) * bs
+
+    def feed(f, s, e):
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        return f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+
+    for s in range(0, half, bs):
+        feed(a, s, s + bs)
+        feed(o, s, s + bs)
+    touched = np.unique(np.concatenate([src[:half], dst[:half]]))
+    path = tmp_path / "tppr.npz"
+    np.savez(path, **a.state_dict(touched))
+    b = zt.tppr_finder(N, k, 2, al, be)
+    b.load_state_dict(dict(np.load(path)))
+    for m in range(2):
+        _cmp_state(b.export_state(m), a.export_state(m), "restored model %d" % m)
+    for s in range(half, E, bs):
+        ra, rb, ro = feed(a, s, s + bs), feed(b, s, s + bs), feed(o, s, s + bs)
+        for x, y, z in zip(ra, rb, ro):
+            assert np.array_equal(np.stack(x), np.stack(y)) and np.array_equal(np.stack(y), np.stack(z))
+    for m in range(2):
+        _cmp_state(b.export_state(m), o.export(m), "continued model %d" % m)
+    with pytest.raises(Exception):
+        zt.tppr_finder(N, 10, 2, al, be).load_state_dict(dict(np.load(path)))

@@ -23,7 +23,7 @@ ZT_ERR_ARG, ZT_ERR_RANGE, ZT_ERR_HIP, ZT_ERR_UNSUPPORTED, ZT_ERR_TIMEOUT = -1, -
 SYMBOLS = [
     "zt_last_error", "zt_version", "zt_profile_enable", "zt_profile_reset", "zt_profile_read", "zt_stream_create_masked", "zt_stream_destroy",
     "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
-    "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import",
+    "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
     "zt_embed_workspace_bytes", "zt_embed",
     "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",

@@ -1409,6 +1409,42 @@ extern "C" int zt_tppr_export_rows(zt_tppr *h, int32_t m, const int64_t *ids_hos
     return ZT_OK;
 }
 
+namespace {
+// the reference's dictionary items (iteration order) -> granules of one row, tag 0
+int encode_row(const zt_tppr *h, u64 *r, int32_t len, double norm, const int64_t *eidx, const int64_t *node,
+               const double *ts, const double *w)
+{
+    const size_t k = (size_t)h->k;
+    if (len < 0 || len > (int)k) { set_error("zt_tppr_import: bad length"); return ZT_ERR_ARG; }
+    u64 nb;
+    memcpy(&nb, &norm, 8);
+    r[0] = (u64)(unsigned)len; r[1] = (u64)(unsigned)nb; r[2] = nb >> 32;
+    for (size_t j = 0; j < (size_t)len; ++j) {
+        if (eidx[j] < 0 || eidx[j] > 0x7fffffffll || node[j] < 0 || node[j] >= h->N) {
+            set_error("zt_tppr_import: id out of range");
+            return ZT_ERR_RANGE;
+        }
+        u64 tb, wb;
+        memcpy(&tb, &ts[j], 8);
+        memcpy(&wb, &w[j], 8);
+        u64 *e = r + HDR + j;
+        e[0] = (u64)node[j]; e[k] = (u64)eidx[j];
+        e[2 * k] = (u64)(unsigned)tb; e[3 * k] = tb >> 32;
+        e[4 * k] = (u64)(unsigned)wb; e[5 * k] = wb >> 32;
+    }
+    return ZT_OK;
+}
+
+__global__ void k_scatter_tppr_rows(u64 *__restrict__ rows, const long long *__restrict__ ids, long long n, int rg,
+                                    const u64 *__restrict__ in)
+{
+    const long long r = blockIdx.x;
+    if (r >= n) return;
+    u64 *dst = rows + ids[r] * rg;
+    for (int c = threadIdx.x; c < rg; c += blockDim.x) dst[c] = in[r * rg + c];
+}
+}  // namespace
+
 extern "C" int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host, const double *norm_host,
                               const int64_t *eidx_host, const int64_t *node_host, const double *ts_host,
                               const double *w_host)
@@ -1417,27 +1453,41 @@ extern "C" int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host, co
     const size_t N = (size_t)h->N, k = (size_t)h->k, rg = (size_t)h->rg;
     std::vector<u64> g(N * rg, 0ull);
     for (size_t v = 0; v < N; ++v) {
-        if (len_host[v] < 0 || len_host[v] > (int)k) { set_error("zt_tppr_import: bad length"); return ZT_ERR_ARG; }
-        u64 *r = g.data() + v * rg;
-        u64 nb;
-        memcpy(&nb, &norm_host[v], 8);
-        r[0] = (u64)(unsigned)len_host[v]; r[1] = (u64)(unsigned)nb; r[2] = nb >> 32;
-        for (size_t j = 0; j < (size_t)len_host[v]; ++j) {
-            const size_t p = v * k + j;
-            if (eidx_host[p] < 0 || eidx_host[p] > 0x7fffffffll || node_host[p] < 0 || node_host[p] >= h->N) {
-                set_error("zt_tppr_import: id out of range");
-                return ZT_ERR_RANGE;
-            }
-            u64 tb, wb;
-            memcpy(&tb, &ts_host[p], 8);
-            memcpy(&wb, &w_host[p], 8);
-            u64 *e = r + HDR + j;
-            e[0] = (u64)node_host[p]; e[k] = (u64)eidx_host[p];
-            e[2 * k] = (u64)(unsigned)tb; e[3 * k] = tb >> 32;
-            e[4 * k] = (u64)(unsigned)wb; e[5 * k] = wb >> 32;
-        }
+        int rc = encode_row(h, g.data() + v * rg, len_host[v], norm_host[v], eidx_host + v * k, node_host + v * k,
+                            ts_host + v * k, w_host + v * k);
+        if (rc != ZT_OK) return rc;
     }
     ZT_HIP(hipDeviceSynchronize());
     ZT_HIP(hipMemcpy(h->rows + (size_t)m * N * rg, g.data(), N * rg * sizeof(u64), hipMemcpyHostToDevice));
+    return ZT_OK;
+}
+
+extern "C" int zt_tppr_import_rows(zt_tppr *h, int32_t m, const int64_t *ids_host, int64_t n, const int32_t *len_host,
+                                   const double *norm_host, const int64_t *eidx_host, const int64_t *node_host,
+                                   const double *ts_host, const double *w_host)
+{
+    if (!h || m < 0 || m >= h->M || n < 0 || (n > 0 && !ids_host)) return ZT_ERR_ARG;
+    if (n == 0) return ZT_OK;
+    const size_t k = (size_t)h->k, rg = (size_t)h->rg;
+    std::vector<u64> g((size_t)n * rg, 0ull);
+    for (size_t v = 0; v < (size_t)n; ++v) {
+        if (ids_host[v] < 0 || ids_host[v] >= h->N) { set_error("zt_tppr_import_rows: id out of range"); return ZT_ERR_RANGE; }
+        int rc = encode_row(h, g.data() + v * rg, len_host[v], norm_host[v], eidx_host + v * k, node_host + v * k,
+                            ts_host + v * k, w_host + v * k);
+        if (rc != ZT_OK) return rc;
+    }
+    ZT_HIP(hipDeviceSynchronize());
+    long long *ids_dev = nullptr;
+    u64 *buf_dev = nullptr;
+    ZT_HIP(hipMalloc(&ids_dev, (size_t)n * sizeof(long long)));
+    ZT_HIP(hipMalloc(&buf_dev, (size_t)n * rg * sizeof(u64)));
+    hipError_t e = hipMemcpy(ids_dev, ids_host, (size_t)n * sizeof(long long), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(buf_dev, g.data(), (size_t)n * rg * sizeof(u64), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_scatter_tppr_rows<<<(unsigned)n, 128>>>(h->rows + (size_t)m * (size_t)h->N * rg, ids_dev, n, (int)rg, buf_dev);
+        e = hipDeviceSynchronize();
+    }
+    (void)hipFree(ids_dev); (void)hipFree(buf_dev);
+    ZT_HIP(e);
     return ZT_OK;
 }

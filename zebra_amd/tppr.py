@@ -80,6 +80,17 @@ class _TpprState:
                                    ptr(np.ascontiguousarray(st["w"], np.float64))), "zt_tppr_import")
 
 
+    def import_rows(self, m, ids, st):
+        ids = np.ascontiguousarray(ids, np.int64)
+        check(lib().zt_tppr_import_rows(self.h, C.c_int32(m), ptr(ids), C.c_int64(len(ids)),
+                                        ptr(np.ascontiguousarray(st["len"], np.int32)),
+                                        ptr(np.ascontiguousarray(st["norm"], np.float64)),
+                                        ptr(np.ascontiguousarray(st["eidx"], np.int64)),
+                                        ptr(np.ascontiguousarray(st["node"], np.int64)),
+                                        ptr(np.ascontiguousarray(st["ts"], np.float64)),
+                                        ptr(np.ascontiguousarray(st["w"], np.float64))), "zt_tppr_import_rows")
+
+
 class tppr_finder:
     """Drop-in for the reference's ``tppr_finder`` jitclass (utils/util.py:391).
 
@@ -162,6 +173,28 @@ class tppr_finder:
     def export_rows(self, m, node_ids):
         """The same for the given nodes only: arrays [n], [n][k] (large graphs: the touched nodes)."""
         return self._live.export_rows(m, node_ids)
+
+    # ------------------------------------------------------------- checkpoint (SURVEY.md 8f-2)
+    def state_dict(self, node_ids):
+        """The T-PPR state of ``node_ids`` (the nodes the stream has touched so far) for every model, as
+        plain numpy arrays: what the reference leaves out of its checkpoint (train.py:291), so that a
+        resumed run continues bit for bit instead of replaying the stream (fill_tppr)."""
+        ids = np.ascontiguousarray(node_ids, np.int64)
+        out = {"node_ids": ids, "k": np.int32(self.k), "n_tppr": np.int32(self.n_tppr)}
+        for m in range(self.n_tppr):
+            for key, val in self._live.export_rows(m, ids).items():
+                out["m%d_%s" % (m, key)] = val
+        return out
+
+    def load_state_dict(self, sd, reset=True):
+        """Inverse of ``state_dict`` (``reset``: every other node's dictionary is emptied first)."""
+        if int(sd["k"]) != self.k or int(sd["n_tppr"]) != self.n_tppr:
+            raise ValueError("checkpoint was written for k=%d, n_tppr=%d" % (int(sd["k"]), int(sd["n_tppr"])))
+        if reset:
+            self.reset_tppr()
+        ids = np.ascontiguousarray(sd["node_ids"], np.int64)
+        for m in range(self.n_tppr):
+            self._live.import_rows(m, ids, {key: sd["m%d_%s" % (m, key)] for key in ("len", "norm", "eidx", "node", "ts", "w")})
 
     # ------------------------------------------------------------- streaming
     def _upload(self, source_nodes, timestamps, edge_idxs, n_roles):
