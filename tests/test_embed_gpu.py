@@ -222,3 +222,52 @@ def test_full_size_step_properties():
         torch.cuda.empty_cache()
     for a, b in zip(res["seq"], res["pipe"]):
         assert torch.equal(a, b)
+
+
+def test_device_side_evaluation_matches_reference_protocol():
+    """zebra_amd.evaluation.eval_edge_prediction (probabilities and AP / AUC / accuracy
+    stay on the device) against the reference's protocol restated with scikit-learn on the host
+    (evaluation/evaluation.py:7-48) -- same model, same sampler seed."""
+    import math
+    import types
+    sk = pytest.importorskip("sklearn.metrics")
+    from zebra_amd import evaluation as ev
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    data = types.SimpleNamespace(sources=src, destinations=dst, timestamps=ts, edge_idxs=eidx, n_interactions=len(src))
+
+    class Sampler:                       # RandEdgeSampler's interface (utils/util.py:54-84)
+        def __init__(self, dsts, seed):
+            self.seed, self.dst_list = seed, np.unique(dsts)
+            self.random_state = np.random.RandomState(seed)
+
+        def reset_random_state(self):
+            self.random_state = np.random.RandomState(self.seed)
+
+        def sample(self, size):
+            i = self.random_state.randint(0, len(self.dst_list), size)
+            return self.dst_list[i], self.dst_list[self.random_state.randint(0, len(self.dst_list), size)]
+
+    batch = 150
+    got = ev.eval_edge_prediction(build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat), Sampler(dst, 7), data, 10, batch)
+    # the reference's loop, on the host
+    model = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    smp = Sampler(dst, 7)
+    smp.reset_random_state()
+    aps, aucs, accs = [], [], []
+    with torch.no_grad():
+        for b in range(math.ceil(len(src) / batch)):
+            s, e = b * batch, min(len(src), (b + 1) * batch)
+            _, negs = smp.sample(e - s)
+            pos, ng = model.compute_edge_probabilities(src[s:e], dst[s:e], negs, ts[s:e], eidx[s:e], 10, train=False)
+            pos, ng = pos.cpu().numpy(), ng.cpu().numpy()
+            y = np.concatenate([np.ones(e - s), np.zeros(e - s)])
+            sc = np.concatenate([pos, ng])
+            aps.append(sk.average_precision_score(y, sc))
+            aucs.append(sk.roc_auc_score(y, sc))
+            accs.append(sk.accuracy_score(np.zeros(e - s), np.argmax(np.hstack([pos, ng]), axis=1)))
+    want = (np.mean(aps), np.mean(aucs), np.mean(accs))
+    assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)
