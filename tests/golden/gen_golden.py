@@ -246,6 +246,34 @@ def gen_embed():
     save("g6_timeencode", time_w=te.w.weight.detach().numpy().ravel().copy(), dts=dts, enc=enc)
 
 
+# ---------------------------------------------------------------------------
+# G7 ingest: the reference's get_data / compute_time_statistics on a synthetic ml_*.csv
+# ---------------------------------------------------------------------------
+def gen_ingest():
+    import tempfile
+    import utils.data_processing as DP  # noqa: E402  (reference)
+    u, i, ts, label, idx = I.make_ml_table()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "data", "synth"))
+        os.makedirs(os.path.join(tmp, "run"))
+        I.write_ml_csv(os.path.join(tmp, "data", "synth", "ml_synth.csv"), u, i, ts, label, idx)
+        cwd = os.getcwd()
+        os.chdir(os.path.join(tmp, "run"))          # the reference reads '../data/{name}/ml_{name}.csv'
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                full, train, val, test, nn_val, nn_test, n_nodes, n_edges = DP.get_data("synth")
+        finally:
+            os.chdir(cwd)
+    out = dict(u=u, i=i, ts=ts, label=label, idx=idx, n_nodes=np.int64(n_nodes), n_edges=np.int64(n_edges))
+    for nm, d in (("full", full), ("train", train), ("val", val), ("test", test), ("nn_val", nn_val), ("nn_test", nn_test)):
+        out[nm + "_idx"] = np.asarray(d.edge_idxs)
+        out[nm + "_n_unique"] = np.int64(d.n_unique_nodes)
+    out["time_stats"] = np.asarray(DP.compute_time_statistics(full.sources, full.destinations, full.timestamps), np.float64)
+    save("g7_ingest", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -253,6 +281,7 @@ def main():
     gen_stream()
     gen_prune()
     gen_embed()
+    gen_ingest()
     bad = 0
     for name, arrays in OUT.items():
         path = os.path.join(HERE, name + ".npz")

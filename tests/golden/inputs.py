@@ -155,3 +155,25 @@ def digest(arrays):
     for a in arrays:
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+# ---------------------------------------------------------------------------
+# ingest (g7): a small bipartite table in the reference's ml_{name}.csv format
+# ---------------------------------------------------------------------------
+def make_ml_table(n_users=60, n_items=40, n_edges=1500, seed=4242):
+    """u (1..U), i (U+1..U+I), ts (sorted, with repeats), label, idx (1..E) like utils/preprocess_data.py."""
+    rng = np.random.RandomState(seed)
+    u = 1 + np.minimum((rng.pareto(1.2, n_edges) * 3).astype(np.int64), n_users - 1)
+    i = 1 + n_users + np.minimum((rng.pareto(1.5, n_edges) * 2).astype(np.int64), n_items - 1)
+    ts = np.sort(np.round(rng.exponential(50.0, n_edges).cumsum(), 0)).astype(np.float64)
+    label = (rng.random_sample(n_edges) < 0.03).astype(np.float64)
+    idx = np.arange(1, n_edges + 1, dtype=np.int64)
+    return u, i, ts, label, idx
+
+
+def write_ml_csv(path, u, i, ts, label, idx):
+    """Same layout as the reference's preprocessing output (unnamed index column first)."""
+    with open(path, "w") as f:
+        f.write(",u,i,ts,label,idx\n")
+        for r in range(len(u)):
+            f.write("%d,%d,%d,%r,%r,%d\n" % (r, u[r], i[r], float(ts[r]), float(label[r]), idx[r]))
