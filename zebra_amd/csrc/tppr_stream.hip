@@ -29,6 +29,18 @@
 //     the number of chain hops still ahead), publishes "reads done", merges in
 //     LDS, prunes with the exact numba argsort semantics, and stores the new
 //     rows as write-through (sc1) granules, fire and forget.
+//   * The kernel's time is the longest chain of edges through one node times
+//     the time of one hop.  The most-touched nodes of a launch (hubs) get a
+//     workgroup of their own whose waves take the hub's edges in order and pass
+//     the hub's row through an LDS mailbox; a hub row goes to memory only when
+//     its next accessor reads it from there (process_edge: hub_to_memory).
+//   * The prepass reads only node / edge ids.  The handle keeps two sets of its
+//     buffers, so zt_tppr_plan can run it for a later call on another stream
+//     while k_stream still works on the previous set.
+//   * A merge matches keys through a per-wave hash table in LDS (all pairs on
+//     slot collisions); the top-k prune is rank counting in registers, a
+//     quicksort replay on the ranks when ties decide, LDS / sequential replays
+//     for more than 64 candidates (numba_sort.hpp).
 #include "numba_sort.hpp"
 
 #include <cstdarg>
