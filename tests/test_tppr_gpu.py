@@ -378,3 +378,57 @@ def test_checkpoint_round_trip(zt, oracle, tmp_path):
         _cmp_state(b.export_state(m), o.export(m), "continued model %d" % m)
     with pytest.raises(Exception):
         zt.tppr_finder(N, 10, 2, al, be).load_state_dict(dict(np.load(path)))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_dense_hub_graph_vs_oracle(zt, oracle, seed):
+    """Every node is a hub: 40 nodes, 4096-edge launches, so all 16 chain workgroups are in use,
+    chains own edges whose other endpoint is another chain's hub (foreign writers between mailbox
+    hand-offs), negatives hit hubs (readers between hand-offs: the row must go to memory, the next
+    writer must wait for the reads-done flag), plus self-loops and negative == endpoint.  Bit-exact
+    against the oracle, outputs and final state."""
+    rng = np.random.RandomState(900 + seed)
+    N, E, k, bs = 41, 3 * 4096, 20, 4096
+    p = 1.0 / np.arange(1, N) ** 0.7
+    p /= p.sum()
+    src = (1 + rng.choice(N - 1, E, p=p)).astype(np.int32)
+    dst = (1 + rng.choice(N - 1, E, p=p)).astype(np.int32)
+    loops = rng.random_sample(E) < 0.03
+    dst[loops] = src[loops]
+    neg = (1 + rng.choice(N - 1, E, p=p)).astype(np.int32)
+    same = rng.random_sample(E) < 0.05
+    neg[same] = src[same]
+    ts = np.cumsum(rng.randint(0, 3, E)).astype(np.float64)          # repeated timestamps too
+    eidx = np.arange(1, E + 1, dtype=np.int64)
+    al, be = [0.1, 0.2], [0.5, 0.95]
+    f = zt.tppr_finder(N, k, 2, al, be)
+    o = oracle.TpprOracle(N, k, 2, al, be)
+    for s in range(0, E, bs):
+        e = s + bs
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        a = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        b = o.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        for x, y, nm in zip(a, b, ("nodes", "eidx", "dt", "w")):
+            assert np.array_equal(np.stack(x), np.stack(y)), "%s differs in batch at %d" % (nm, s)
+    for m in range(2):
+        _cmp_state(f.export_state(m), o.export(m), "model %d" % m)
+
+
+def test_chain_overflow_vs_oracle(zt, oracle):
+    """Six nodes, one 8192-edge launch: every hub is touched by more edges than a chain holds
+    (CH_MAX = 2048), so chains hand the rest to the general queue in the middle of their order."""
+    rng = np.random.RandomState(77)
+    N, E, k = 7, 8192, 5
+    src = rng.randint(1, N, E).astype(np.int32)
+    dst = rng.randint(1, N, E).astype(np.int32)
+    neg = rng.randint(1, N, E).astype(np.int32)
+    ts = np.arange(E, dtype=np.float64)
+    eidx = np.arange(1, E + 1, dtype=np.int64)
+    al, be = [0.15], [0.9]
+    f = zt.tppr_finder(N, k, 1, al, be)
+    o = oracle.TpprOracle(N, k, 1, al, be)
+    nodes = np.concatenate([src, dst, neg])
+    a, b = f.streaming_topk(nodes, ts, eidx), o.streaming_topk(nodes, ts, eidx)
+    for x, y in zip(a, b):
+        assert np.array_equal(np.stack(x), np.stack(y))
+    _cmp_state(f.export_state(0), o.export(0))
