@@ -184,6 +184,7 @@ struct zt_tppr {
     int *ctl;
     unsigned epoch;
     int n_cu;
+    int run_cus;     // CUs of the stream the last k_stream ran on (0: not known yet)
     // Two sets of the prepass buffers above (the fields above point into the set in use): the prepass of
     // the next call can run on another stream while k_stream still reads the previous call's set.
     struct PlanSet {
@@ -1072,6 +1073,16 @@ extern "C" int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream)
 }
 
 // grid of k_stream and the number of hub chains for a launch of B edges
+// CUs a stream may use (CU-masked streams: the size of the mask)
+static int stream_cus(const zt_tppr *h, hipStream_t s)
+{
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) { (void)hipGetLastError(); return h->n_cu; }
+    int c = 0;
+    for (int q = 0; q < 32; ++q) c += __builtin_popcount(mask[q]);
+    return (c > 0 && c < h->n_cu) ? c : h->n_cu;
+}
+
 static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, int *max_chains_out)
 {
     long long waves = (long long)B * n_models;
@@ -1079,12 +1090,21 @@ static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, i
     // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
     // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 8 waves).
     static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
-    const long long max_waves = (long long)(h->n_cu * WAVES_PER_WG * wgs_per_cu);
+    // Every workgroup of the grid must be resident at once (chain workgroups wait on each other's rows):
+    // the CUs of the stream that runs k_stream (run_cus: learnt from the last launch, a CU-masked stream
+    // offers fewer) times the workgroups one CU can hold (LDS).
+    constexpr size_t wg_lds = sizeof(WaveLds) * WAVES_PER_WG + sizeof(Mail);
+    constexpr int per_cu = (int)((160 * 1024) / wg_lds) < 1 ? 1 : (int)((160 * 1024) / wg_lds);
+    const int cus = h->run_cus > 0 ? h->run_cus : h->n_cu;
+    long long max_waves = (long long)(cus * WAVES_PER_WG * wgs_per_cu);
+    const long long resident = (long long)cus * per_cu * WAVES_PER_WG;
+    if (max_waves > resident) max_waves = resident;
+    if (max_waves < WAVES_PER_WG) max_waves = WAVES_PER_WG;
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    // hub chains: at most a quarter of the (co-resident) grid, so the general queue always keeps waves
+    // hub chains: at most two thirds of the grid, so the general queue always keeps waves
     static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
-    int max_chains = grid / (4 * n_models);
+    int max_chains = (2 * grid) / (3 * n_models);
     if (max_chains > chains_env) max_chains = chains_env;
     if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
     *grid_out = grid;
@@ -1140,6 +1160,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     h->epoch += 1;
     ZT_HIP(hipStreamWaitEvent(s, P.planned, 0));
     use_set(h, q);
+    h->run_cus = stream_cus(h, s);
     StreamArgs sa;
     sa.nodes = nodes; sa.tsv = ts; sa.eidx = eidx; sa.role_stride = role_stride; sa.B = B; sa.n_roles = n_roles;
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
@@ -1204,6 +1225,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
             return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
                              out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s);
     }
+    h->run_cus = stream_cus(h, s);             // plan and run on the same stream here
     // launches of at most MAX_CHUNK edges: writer ordinals must fit the tag
     for (int64_t c0 = 0; c0 < B; c0 += MAX_CHUNK) {
         const int bc = (int)((B - c0) < MAX_CHUNK ? (B - c0) : MAX_CHUNK);
