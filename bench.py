@@ -166,6 +166,9 @@ def main():
     rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        # several ranks on ONE GPU: their k_stream grids would compete for the same CUs, and hub-chain
+        # workgroups need their whole grid resident -> no chains in the rehearsal
+        os.environ.setdefault("ZT_STREAM_CHAINS", "0")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -34,6 +34,8 @@ def _run(rank, world, port, cfg, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
+        os.environ["ZT_STREAM_CHAINS"] = "0"     # ranks share one GPU here: hub chains need a whole grid resident
+    if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         N, E, D, F, T, k, al, be, seed, bs = cfg
