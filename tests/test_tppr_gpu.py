@@ -432,3 +432,36 @@ def test_chain_overflow_vs_oracle(zt, oracle):
     for x, y in zip(a, b):
         assert np.array_equal(np.stack(x), np.stack(y))
     _cmp_state(f.export_state(0), o.export(0))
+
+
+def test_long_power_law_stream_vs_oracle(zt, oracle):
+    """A bench-shaped stream (power-law endpoints, bs=4096, k=20, alpha=[.1,.1], beta=[.5,.95]) long enough
+    for the dictionaries of the hubs to be full and tie-laden (beta = 0.5 scales exactly): 300 launches of
+    4096 edges on 100,000 nodes, checked against the oracle every 20th batch (all four output arrays) and on
+    the final state of every touched node."""
+    from zebra_amd import synth
+    N, B, k, nb = 100_000, 4096, 20, 300
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    src, dst, ts, eidx = synth.power_law_stream(N, nb * B, seed=515)
+    neg = synth.negatives(dst, len(src), seed=516)
+    f = zt.tppr_finder(N + 1, k, 2, al, be)
+    o = oracle.TpprOracle(N + 1, k, 2, al, be)
+    for b in range(nb):
+        s, e = b * B, (b + 1) * B
+        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
+        ob = o.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        if b % 20 == 19 or b == nb - 1:
+            a = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
+            for x, y, nm in zip(a, ob, ("nodes", "eidx", "dt", "w")):
+                assert np.array_equal(np.stack(x), np.stack(y)), "%s differs in batch %d" % (nm, b)
+        else:
+            import torch
+            d = torch.device("cuda")
+            f.stream_device(torch.from_numpy(nodes).to(d), torch.from_numpy(ts[s:e]).to(d),
+                            torch.from_numpy(eidx[s:e]).to(d), 3, True, -1, check_status=False)
+    f.check_status()
+    touched = np.unique(np.concatenate([src, dst])).astype(np.int64)
+    for m in range(2):
+        got, want = f.export_rows(m, touched), o.export(m)
+        for kk in got:
+            assert np.array_equal(got[kk], want[kk][touched]), "state %s of model %d" % (kk, m)
