@@ -247,6 +247,34 @@ def gen_embed():
 
 
 # ---------------------------------------------------------------------------
+# G8 training step: loss and parameter gradients of train.py:205-215 (no optimizer step)
+# ---------------------------------------------------------------------------
+def gen_train_grads():
+    torch.set_num_threads(1)
+    name = "d20_f7"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+    tgn.train(True)
+    crit = torch.nn.BCELoss()
+    out = {}
+    for b in range(nb):
+        s, e_ = b * bs, (b + 1) * bs
+        tgn.zero_grad()
+        pos, negp = tgn.compute_edge_probabilities(src[s:e_], dst[s:e_], neg[s:e_], ts[s:e_], eidx[s:e_], 10, True)
+        loss = crit(pos.squeeze(), torch.ones(bs)) + crit(negp.squeeze(), torch.zeros(bs))
+        loss.backward()
+        out["b%d_loss" % b] = np.float64(loss.item())
+        for pn, p in tgn.named_parameters():
+            if p.requires_grad and p.grad is not None:
+                out["b%d_grad_%s" % (b, pn)] = p.grad.detach().numpy().copy()
+        tgn.memory.detach_memory()
+    save("g8_train_grads", **out)
+
+
+# ---------------------------------------------------------------------------
 # G7 ingest: the reference's get_data / compute_time_statistics on a synthetic ml_*.csv
 # ---------------------------------------------------------------------------
 def gen_ingest():
@@ -282,6 +310,7 @@ def main():
     gen_prune()
     gen_embed()
     gen_ingest()
+    gen_train_grads()
     bad = 0
     for name, arrays in OUT.items():
         path = os.path.join(HERE, name + ".npz")

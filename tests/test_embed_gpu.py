@@ -271,3 +271,38 @@ def test_device_side_evaluation_matches_reference_protocol():
             accs.append(sk.accuracy_score(np.zeros(e - s), np.argmax(np.hstack([pos, ng]), axis=1)))
     want = (np.mean(aps), np.mean(aucs), np.mean(accs))
     assert np.allclose(got, want, rtol=0, atol=1e-9), (got, want)
+
+
+def test_training_step_gradients_match_reference():
+    """SURVEY.md 8f-1 (first half): an unmodified training step in the reference's style
+    (train.py:205-215: BCE on positive / negative probabilities, loss.backward()) through the drop-in
+    gives the reference's loss and parameter gradients (fixture g8_train_grads, generated from the
+    reference): T-PPR and memory kernels in HIP, the aggregation differentiable through torch device ops."""
+    name = "d20_f7"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g8_train_grads")
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+    tgn.train(True)
+    crit = torch.nn.BCELoss()
+    dev = torch.device("cuda")
+    seen = 0
+    for b in range(nb):
+        s, e = b * bs, (b + 1) * bs
+        tgn.zero_grad()
+        pos, negp = tgn.compute_edge_probabilities(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, True)
+        loss = crit(pos.squeeze(), torch.ones(bs, device=dev)) + crit(negp.squeeze(), torch.zeros(bs, device=dev))
+        loss.backward()
+        assert abs(float(loss.item()) - float(g["b%d_loss" % b])) <= 1e-5, "loss of batch %d" % b
+        for pn, p in tgn.named_parameters():
+            key = "b%d_grad_%s" % (b, pn)
+            if key in g.files:
+                assert p.grad is not None, pn
+                want = g[key]
+                err = np.abs(p.grad.detach().cpu().numpy() - want).max()
+                assert err <= 1e-5 + 1e-4 * np.abs(want).max(), "%s in batch %d: %g" % (pn, b, err)
+                seen += 1
+        tgn.memory.detach_memory()
+    assert seen >= 12 * nb
