@@ -147,9 +147,10 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--tppr-cus", type=int, default=48,
+    ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
-                         "(0 = no masks; also the fallback when masked streams cannot be created)")
+                         "(0 = no masks; default: 48 for the streaming strategy, whose update kernel is latency-bound, "
+                         "0 for the pruning strategy, whose query kernel wants the whole chip)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     a = ap.parse_args()
@@ -210,6 +211,8 @@ def main():
 
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
+        if a.tppr_cus < 0:
+            a.tppr_cus = 48 if wl["strategy"] == "streaming" else 0
         if world > 1 and not rehearsal:
             a.tppr_cus = 0          # RCCL kernels run on the main stream: keep it an ordinary (unmasked) stream
         try:
