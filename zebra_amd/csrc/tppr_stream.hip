@@ -491,7 +491,7 @@ __device__ __forceinline__ u64 readlane_u64(u64 x, int src /* wave-uniform */)
 
 __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
                                  const Row &r2, u64 newkey, double newts, u64 &ok, double &ot, double &ow,
-                                 int g_stamp_i = -1)
+                                 int pre = 0, int g_stamp_i = -1)
 {
     STAMP2(0);
     // A lone wave is bound by dependent-instruction latency, so this routine is written for the
@@ -522,14 +522,20 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
         // it fetches from the lane holding it and compares in full.  Keys are unique inside a
         // dictionary, so an entry has at most one partner.  Slot collisions (~1 call in 6 for 20
         // entries in 1024 slots) take the all-pairs path below.
+        // (pre != 0: s2 was entered into the table by the caller while it waited for r1 -- hub chains)
         int *T = L.htab;
         const int h1 = key_hash(r1.key), h2 = key_hash(r2.key);
-        if (in2) T[h2] = lane;
-        L.sort.r[lane] = 0;
-        wave_sync();
-        const int back = in2 ? T[h2] : lane;
-        const int cand = in1 ? T[h1] : -1;
-        if (__ballot(in2 && back != lane) == 0ull) {
+        bool clash = pre == 2;
+        if (pre == 0) {
+            if (in2) T[h2] = lane;
+            L.sort.r[lane] = 0;
+            wave_sync();
+            const int back = in2 ? T[h2] : lane;
+            clash = __ballot(in2 && back != lane) != 0ull;
+            if (clash && in2 && back == lane) T[h2] = -1;       // the slot's last writer clears it
+        }
+        const int cand = (in1 && !clash) ? T[h1] : -1;
+        if (!clash) {
             const int src = cand >= 0 ? cand : 0;
             const u64 kj = __shfl(r2.key, src);
             const double tj = __shfl(r2.ts, src), aj = __shfl(add, src);
@@ -539,11 +545,10 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
             wave_sync();
             matched2 = in2 && L.sort.r[lane] != 0;
             matched_done = true;
-        } else {
-            if (in2 && back == lane) T[h2] = -1;                // the slot's last writer clears it
         }
         wave_sync();
     }
+    if (pre == 1 && !(n1 > 0 && len2 > 0) && lane < r2.len) L.htab[key_hash(r2.key)] = -1;   // (cannot happen on a chain)
     if (n1 > 0 && len2 > 0 && !matched_done) {
         // Key matching through LDS, all pairs at once: the rows are staged (s1 in slots [0,64), s2
         // in [64,128)), lane (c, i) compares s1's entry i with every S-th entry of s2 starting at c.
@@ -821,10 +826,29 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     WL(0, 5);
     if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
         if (!load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2, &wl_seen)) wl_fail |= 8;
+    int pre_hash = 0;                           // 1: partner entered into this wave's hash table, 2: with a clash
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
         const unsigned want = tag_base | (unsigned)((u == hub) ? wo_u : wo_v);
         WL(0, 6);
+        // while waiting: the partner of the first merge goes into the hash table already (merge_pair, pre)
+        {
+            const bool sw0 = v_first && u != v;
+            const long long x1_0 = sw0 ? v : u;
+            const Row &rp = sw0 ? ru : rv;
+            const int lenp = (rp.norm != 0.0) ? rp.len : 0;
+            if (x1_0 == hub && u != v && lenp > 0) {
+                const int h2 = key_hash(rp.key);
+                if (lane < lenp) L.htab[h2] = lane;
+                L.sort.r[lane] = 0;
+                wave_sync();
+                const int back = lane < lenp ? L.htab[h2] : lane;
+                const bool clash = __ballot(lane < lenp && back != lane) != 0ull;
+                if (clash && lane < lenp && back == lane) L.htab[h2] = -1;
+                pre_hash = clash ? 2 : 1;
+                wave_sync();
+            }
+        }
         unsigned spins = 0;
         long long t0 = 0;
         while (lds_load_tag(&mail->tag) != want) {
@@ -862,7 +886,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         double nt = 0, nw = 0;
         // (edge_idx, s2, ts) is the key entering s1's dictionary
         int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
-                           nt, nw, mo == 0 ? i : -1);
+                           nt, nw, pre_hash, mo == 0 ? i : -1);
         if (mail != nullptr && x1 == hub) {     // mailbox first: the chain's next edge is spinning on it
             mail->key[lane] = nk; mail->ts[lane] = nt; mail->w[lane] = nw;
             if (lane == 0) { mail->len = n; mail->norm = r1.norm * beta + beta; }
