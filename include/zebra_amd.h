@@ -93,27 +93,40 @@ int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream);
  *   model     : -1 = all models, else only that one
  *   out_*_dev : [n_emitted_models][n_roles*B][k] int32/int32/float32/float32;
  *               every row is written (zeros when the dictionary is empty).
+ *   plan_token: 0, or the token zt_tppr_plan returned for exactly this call.
  * Edges are applied in batch order, each seeing the state left by the edges
- * before it, exactly as the reference's sequential loop. */
+ * before it, exactly as the reference's sequential loop.
+ * Errors: a batch with an out-of-range id is NOT applied, its output rows read
+ * as empty dictionaries (zeros), and ZT_ERR_RANGE is latched in the handle:
+ * every later zt_tppr_stream / zt_tppr_plan call returns it (as soon as the
+ * device's write is visible to the host; no synchronisation is added) until
+ * zt_tppr_status has reported and cleared it.  ZT_ERR_TIMEOUT likewise. */
 int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev,
                    const int64_t *eidx_dev, int64_t B, int32_t n_roles,
                    int32_t emit, int32_t model, int32_t *out_nodes_dev,
                    int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
-                   void *stream);
+                   uint64_t plan_token, void *stream);
 
 /* Optional, no reference counterpart: run the dependency prepass of a coming
  * zt_tppr_stream call ahead of time on another stream.  The prepass (which
  * edges of the batch touch the same node, in which order) reads only the ids,
  * never the T-PPR state, so it can overlap the previous call's update kernel.
- * The next zt_tppr_stream call with the same nodes_dev, B, n_roles and model
- * picks the plan up (ordering between the two streams is handled inside);
- * any other call simply runs its own prepass.  Two plans can be outstanding.
- * A no-op for B == 0 or B > 8192 (multi-launch calls plan inline). */
+ * *token_out identifies the plan: the zt_tppr_stream call it was made for
+ * passes it back (same nodes_dev, B, n_roles, model; ordering between the two
+ * streams is handled inside).  A call with token 0, or with a token whose plan
+ * has been dropped (zt_tppr_reset / copy / import, or two newer plans), runs
+ * its own prepass.  Two plans can be outstanding.  *token_out = 0 and a no-op
+ * for B == 0 or B > 8192 (multi-launch calls plan inline).
+ * The k_stream grid is sized for the compute units of the stream that RUNS it
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs of that stream's mask);
+ * if that stream turns out to offer fewer CUs than the plan assumed, the grid
+ * shrinks and hub chains are dropped for that launch (in-order queue only). */
 int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev,
-                 int64_t B, int32_t n_roles, int32_t model, void *stream);
+                 int64_t B, int32_t n_roles, int32_t model, uint64_t *token_out,
+                 void *stream);
 
-/* Synchronises `stream` and returns the latched device status (ZT_OK,
- * ZT_ERR_RANGE or ZT_ERR_TIMEOUT), clearing it. */
+/* Synchronises `stream` and returns the latched status (ZT_OK, ZT_ERR_RANGE
+ * or ZT_ERR_TIMEOUT) of the launches so far, clearing it. */
 int zt_tppr_status(zt_tppr *h, void *stream);
 
 /* State of model m to / from host arrays, dictionary items in iteration

@@ -252,3 +252,84 @@ def affinity(x1, x2, w):
     lib().zo_affinity(_p(x1), _p(x2), C.c_int64(x1.shape[0]), C.c_int32(x1.shape[1]), _p(ws["fc1_w"]),
                       _p(ws["fc1_b"]), _p(ws["fc2_w"]), _p(ws["fc2_b"]), _p(out))
     return out
+
+
+class ProtocolOracle:
+    """The per-batch protocol of TGN.compute_temporal_embeddings / compute_edge_probabilities
+    (model/tgn_model.py:124-188) composed from the oracle's pieces, eval AND train mode
+    (train: lazily updated memory for the selected neighbours, modules/embedding_module.py:227-230,
+    modules/memory_updater.py:61-90; eager update + clear BEFORE the messages, tgn_model.py:155-157).
+    ``finder`` is a TpprOracle (streaming) or a CsrOracle (pruning; swap with set_neighbor_finder)."""
+
+    def __init__(self, n_nodes, D, F, T, k, alpha, beta, weights, efeat, time_w, strategy="streaming", finder=None,
+                 width=10, depth=2, n_threads=1):
+        self.N, self.D, self.F, self.T, self.k = n_nodes, D, F, T, k
+        self.alpha, self.beta = list(alpha), list(beta)
+        self.w, self.efeat, self.tw = weights, _c(efeat, np.float32), _c(time_w, np.float32)
+        self.strategy, self.width, self.depth, self.n_threads = strategy, width, depth, n_threads
+        self.gru = {kk: weights[kk] for kk in ("w_ih", "w_hh", "b_ih", "b_hh")}
+        self.aff = dict(fc1_w=weights["aff1_w"], fc1_b=weights["aff1_b"], fc2_w=weights["aff2_w"],
+                        fc2_b=weights["aff2_b"])
+        self.tppr = TpprOracle(n_nodes, k, len(alpha), alpha, beta) if strategy == "streaming" else None
+        self.finder = finder
+        self.init_memory()
+        self.test_mode = False
+
+    def init_memory(self):                       # Memory.__init_memory__ (modules/memory.py:19-25)
+        self.mem = MemoryOracle(self.N, self.D, 2 * self.D + self.F + self.T)
+
+    def set_neighbor_finder(self, finder):       # tgn_model.py:230-232
+        self.finder = finder
+
+    def topk(self, nodes, ts, eidx):
+        if self.strategy == "streaming":
+            return self.tppr.streaming_topk(nodes, ts, eidx)
+        n = len(nodes)
+        t3 = np.concatenate([ts] * (n // len(ts)))
+        outs = ([], [], [], [])
+        for a, b in zip(self.alpha, self.beta):   # modules/embedding_module.py:280-297
+            arr = (np.zeros((n, self.k), np.int32), np.zeros((n, self.k), np.int32),
+                   np.zeros((n, self.k), np.float32), np.zeros((n, self.k), np.float32))
+            self.finder.get_pruned_topk(nodes, t3, self.width, self.depth, a, b, self.k, *arr)
+            for o, x in zip(outs, arr):
+                o.append(x)
+        return outs
+
+    def batch(self, src, dst, neg, ts, eidx, train):
+        """-> (embeddings [3B, D*(M+1)], probabilities [2B])."""
+        mem, B = self.mem, len(src)
+        nodes = np.concatenate([src, dst, neg]).astype(np.int32)
+        positives = np.unique(np.concatenate([src, dst]))
+        if train:
+            self.test_mode = False
+        elif not self.test_mode:
+            mem.gru_update(self.gru, None, n_threads=self.n_threads)          # update_memory_in_test (:142-146)
+            self.test_mode = True
+        on, oe, od, ow = self.topk(nodes, ts, eidx)
+        table = mem.memory
+        if train:                                                            # get_updated_memory(memory, index)
+            index = np.unique(np.concatenate([a.ravel() for a in on]))
+            lazy = MemoryOracle(self.N, self.D, mem.msg_dim)
+            lazy.memory, lazy.last_update = mem.memory.copy(), mem.last_update.copy()
+            lazy.messages, lazy.timestamps, lazy.flags = mem.messages, mem.timestamps, mem.flags.copy()
+            lazy.gru_update(self.gru, index, n_threads=self.n_threads)
+            table = lazy.memory
+        emb = embed(table, self.efeat, self.tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow),
+                    self.w, n_threads=self.n_threads)
+        if train:
+            mem.gru_update(self.gru, positives, n_threads=self.n_threads)     # :155-157
+        mem.store_messages(self.efeat, self.tw, src, dst, ts, eidx)           # :159-168
+        if not train:
+            mem.gru_update(self.gru, positives, n_threads=self.n_threads)     # :170-172
+        prob = affinity(np.concatenate([emb[:B], emb[:B]]), np.concatenate([emb[B:2 * B], emb[2 * B:]]), self.aff)
+        self.average_topk = float(np.mean(np.sum(ow[0][:2 * B], axis=1)))
+        return emb, prob
+
+    def backup_memory(self):                     # modules/memory.py:49-50 (flags aliased, as in the reference)
+        m = self.mem
+        return m.memory.copy(), m.last_update.copy(), m.messages.copy(), m.flags, m.timestamps.copy()
+
+    def restore_memory(self, b):                 # modules/memory.py:52-53
+        m = self.mem
+        m.memory, m.last_update, m.messages, m.flags, m.timestamps = b[0].copy(), b[1].copy(), b[2].copy(), b[3], \
+            b[4].copy()

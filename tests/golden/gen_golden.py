@@ -302,6 +302,148 @@ def gen_ingest():
     save("g7_ingest", **out)
 
 
+# ---------------------------------------------------------------------------
+# G9 attention: the reference's own TemporalAttentionLayer (model/temporal_attention.py:7-68)
+# ---------------------------------------------------------------------------
+def gen_attention():
+    from model.temporal_attention import TemporalAttentionLayer  # noqa: E402  (reference)
+    torch.set_num_threads(1)
+    for name, (D, F, T, k, N, heads, seed) in I.ATTENTION_CASES.items():
+        w = I.attention_weights(D, F, T, seed)
+        layer = TemporalAttentionLayer(D, D, F, T, output_dimension=D, n_head=heads, dropout=0.1).eval()
+        mha = layer.multi_head_target
+        with torch.no_grad():
+            mha.q_proj_weight.copy_(torch.from_numpy(w["q_w"]))
+            mha.k_proj_weight.copy_(torch.from_numpy(w["k_w"]))
+            mha.v_proj_weight.copy_(torch.from_numpy(w["v_w"]))
+            mha.in_proj_bias.copy_(torch.from_numpy(w["in_b"]))
+            mha.out_proj.weight.copy_(torch.from_numpy(w["out_w"]))
+            mha.out_proj.bias.copy_(torch.from_numpy(w["out_b"]))
+            layer.merger.fc1.weight.copy_(torch.from_numpy(w["m1_w"]))
+            layer.merger.fc1.bias.copy_(torch.from_numpy(w["m1_b"]))
+            layer.merger.fc2.weight.copy_(torch.from_numpy(w["m2_w"]))
+            layer.merger.fc2.bias.copy_(torch.from_numpy(w["m2_b"]))
+        src, src_t, nbr, nbr_t, edge, mask = I.attention_inputs(D, F, T, k, N, seed)
+        with torch.no_grad():
+            out, aw = layer(torch.from_numpy(src), torch.from_numpy(src_t), torch.from_numpy(nbr),
+                            torch.from_numpy(nbr_t), torch.from_numpy(edge), torch.from_numpy(mask.copy()))
+        save("g9_attention_" + name, out=out.numpy().copy(), attn_w=aw.numpy().copy())
+
+
+# ---------------------------------------------------------------------------
+# G4/G5 with tppr_strategy='pruning' (modules/embedding_module.py:221-224,280-297; config C4's shape)
+# ---------------------------------------------------------------------------
+def gen_prune_embed():
+    torch.set_num_threads(1)
+    for name, (kind, N, E, D, F, T, k, al, be, width, depth, seed, bs, nb, first, n_train) in I.PRUNE_EMBED_CASES.items():
+        src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+        w = I.model_weights(D, F, T, len(al), seed)
+        mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+        full = types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts)
+        part = types.SimpleNamespace(sources=src[:n_train], destinations=dst[:n_train], edge_idxs=eidx[:n_train],
+                                     timestamps=ts[:n_train])
+        out = {}
+        for mode, train in (("eval", False), ("train", True)):
+            nf_full, nf_part = U.get_neighbor_finder(full), U.get_neighbor_finder(part)
+            tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy="pruning", nf=nf_part, width=width,
+                            depth=depth)
+            tgn.train(train)
+            with torch.no_grad():
+                tgn.memory.memory.copy_(torch.from_numpy(mem0))
+            for b in range(nb):
+                if b == nb // 2:
+                    tgn.set_neighbor_finder(nf_full)            # the finder swap of train.py:191,245
+                s, e_ = first + b * bs, first + (b + 1) * bs
+                ctx = torch.enable_grad() if train else torch.no_grad()
+                with ctx:
+                    se, de, ne = tgn.compute_temporal_embeddings(src[s:e_], dst[s:e_], neg[s:e_], ts[s:e_],
+                                                                 eidx[s:e_], width, train)
+                    score = tgn.affinity_score(torch.cat([se, se], dim=0), torch.cat([de, ne])).squeeze(dim=0)
+                    prob = score.sigmoid()
+                out["%s_b%d_emb" % (mode, b)] = torch.cat([se, de, ne]).detach().numpy().copy()
+                out["%s_b%d_prob" % (mode, b)] = prob.detach().numpy().copy().ravel()
+                if train:
+                    tgn.memory.detach_memory()
+                if b == nb - 1:
+                    out.update(mem_state(tgn, "%s_b%d_" % (mode, b)))
+            out["%s_average_topk" % mode] = np.array(tgn.embedding_module.average_topk)
+        save("g45_prune_" + name, **out)
+
+
+# ---------------------------------------------------------------------------
+# G10 epoch protocol (train.py:188-191,241-269,296-306), streaming strategy
+# ---------------------------------------------------------------------------
+def tppr_state(tgn, pre):
+    f = tgn.embedding_module.tppr_finder
+    st = {}
+    for m in range(f.n_tppr):
+        for kk, v in ref_state(f, m).items():
+            st["%sm%d_%s" % (pre, m, kk)] = v
+    return st
+
+
+def gen_epoch():
+    torch.set_num_threads(1)
+    for name, (N, E, D, F, T, k, al, be, seed, bs, n_train, n_val, n_nn) in I.EPOCH_CASES.items():
+        src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+        w = I.model_weights(D, F, T, len(al), seed)
+        _, efeat = I.random_tables(N, E + 1, D, F, seed)
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+        em = tgn.embedding_module
+        out = {}
+        tr = slice(0, n_train)
+        va = np.arange(n_train, n_train + n_val)
+        nn_va = va[1::2][:n_nn]                      # a time-ordered subset, like new_node_val_data
+        te = np.arange(n_train + n_val, E)
+
+        def run(tag, idx, train):
+            probs = []
+            for s in range(0, len(idx), bs):
+                ii = idx[s:s + bs]
+                tgn.train(train)
+                ctx = torch.enable_grad() if train else torch.no_grad()
+                with ctx:
+                    pos, negp = tgn.compute_edge_probabilities(src[ii], dst[ii], neg[ii], ts[ii], eidx[ii], 10, train)
+                probs.append(torch.cat([pos, negp]).detach().numpy().ravel().copy())
+            out[tag + "_prob"] = np.concatenate(probs)
+
+        tppr_filled = False
+        for epoch in range(2):
+            ep = "e%d_" % epoch
+            tgn.memory.__init_memory__()
+            em.reset_tppr()
+            tgn.set_neighbor_finder(None)
+            run(ep + "train", np.arange(n_train), True)
+            out.update(mem_state(tgn, ep + "train_end_"))
+            em.reset_tppr()
+            em.fill_tppr(src[tr].astype(np.int64), dst[tr].astype(np.int64), ts[tr], eidx[tr], tppr_filled)
+            tppr_filled = True
+            out.update(tppr_state(tgn, ep + "filled_"))
+            train_memory_backup = tgn.memory.backup_memory()
+            train_tppr_backup = em.backup_tppr()
+            run(ep + "val", va, False)
+            val_memory_backup = tgn.memory.backup_memory()
+            val_tppr_backup = em.backup_tppr()
+            tgn.memory.restore_memory(train_memory_backup)
+            em.restore_tppr(train_tppr_backup)
+            out[ep + "flags_after_restore_train"] = tgn.memory.nodes.astype(np.uint8).copy()
+            out.update(tppr_state(tgn, ep + "after_restore_train_"))
+            run(ep + "nn_val", nn_va, False)
+            tgn.memory.restore_memory(val_memory_backup)
+            em.restore_tppr(val_tppr_backup)
+            out.update(mem_state(tgn, ep + "end_"))
+            out.update(tppr_state(tgn, ep + "end_"))
+        # test pass (train.py:296-306)
+        val_memory_backup = tgn.memory.backup_memory()
+        val_tppr_backup = em.backup_tppr()
+        run("test", te, False)
+        tgn.memory.restore_memory(val_memory_backup)
+        em.restore_tppr(val_tppr_backup)
+        out.update(mem_state(tgn, "final_"))
+        out.update(tppr_state(tgn, "final_"))
+        save("g10_epoch_" + name, **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -311,6 +453,9 @@ def main():
     gen_embed()
     gen_ingest()
     gen_train_grads()
+    gen_attention()
+    gen_prune_embed()
+    gen_epoch()
     bad = 0
     for name, arrays in OUT.items():
         path = os.path.join(HERE, name + ".npz")

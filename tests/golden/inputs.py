@@ -177,3 +177,66 @@ def write_ml_csv(path, u, i, ts, label, idx):
         f.write(",u,i,ts,label,idx\n")
         for r in range(len(u)):
             f.write("%d,%d,%d,%r,%r,%d\n" % (r, u[r], i[r], float(ts[r]), float(label[r]), idx[r]))
+
+
+# ---------------------------------------------------------------------------
+# attention (g9): seeded weights + inputs of model/temporal_attention.py's layer
+# ---------------------------------------------------------------------------
+# name -> (D, F, T, k, N, heads, seed)
+ATTENTION_CASES = {
+    "d100_f172_k20": (100, 172, 100, 20, 96, 2, 51),
+    "d100_f1_k10": (100, 1, 100, 10, 65, 2, 52),
+    "d20_f4_k5_h4": (20, 4, 12, 5, 70, 4, 53),
+}
+
+
+def attention_weights(D, F, T, seed):
+    """Parameters of TemporalAttentionLayer(n_node=D, n_nbr=D, n_edge=F, time=T, out=D) in torch layout."""
+    rng = np.random.RandomState(seed)
+    E, K = D + T, D + T + F
+
+    def mat(o, i, s=None):
+        s = np.sqrt(2.0 / (o + i)) if s is None else s
+        return (rng.standard_normal((o, i)) * s).astype(np.float32)
+
+    def vec(n, s=0.1):
+        return (rng.uniform(-s, s, n)).astype(np.float32)
+
+    return dict(q_w=mat(E, E), k_w=mat(E, K), v_w=mat(E, K), in_b=vec(3 * E), out_w=mat(E, E), out_b=vec(E),
+                m1_w=mat(D, E + D), m1_b=vec(D), m2_w=mat(D, D), m2_b=vec(D))
+
+
+def attention_inputs(D, F, T, k, N, seed):
+    """src [N,D], src_time [N,1,T], nbr [N,k,D], nbr_time [N,k,T], edge [N,k,F], mask bool [N,k]
+    (True = no neighbour); row 3 has no neighbour at all, row 5 all of them."""
+    rng = np.random.RandomState(seed + 500)
+    src = rng.standard_normal((N, D)).astype(np.float32)
+    src_t = np.ones((N, 1, T), np.float32)                                    # cos(0)
+    nbr = rng.standard_normal((N, k, D)).astype(np.float32)
+    nbr_t = np.cos(rng.standard_normal((N, k, T)) * 5).astype(np.float32)
+    edge = rng.standard_normal((N, k, F)).astype(np.float32)
+    mask = rng.random_sample((N, k)) < 0.4
+    mask[3] = True
+    mask[5] = False
+    mask[7, 1:] = True                                                        # exactly one neighbour
+    return src, src_t, nbr, nbr_t, edge, mask
+
+
+# ---------------------------------------------------------------------------
+# pruning-strategy protocol (g45_prune_*): config C4's shape in small
+# name -> (stream kind, n_nodes, n_edges, D, F, T, k, alpha, beta, width, depth, seed, bs, n_batches, first_edge,
+#          train_finder_edges)
+# ---------------------------------------------------------------------------
+PRUNE_EMBED_CASES = {
+    "d100_f1_k40": ("general", 150, 1200, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 10, 2, 61, 16, 4, 900, 800),
+    "d20_f7_k10": ("hub", 80, 800, 20, 7, 20, 10, [0.2], [0.8], 5, 3, 62, 12, 4, 500, 450),
+}
+
+
+# ---------------------------------------------------------------------------
+# epoch protocol (g10): train.py:188-191,241-269,296-306 in small
+# name -> (n_nodes, n_edges, D, F, T, k, alpha, beta, seed, bs, n_train, n_val, n_nn_val)
+# ---------------------------------------------------------------------------
+EPOCH_CASES = {
+    "stream_d20_f7": (60, 520, 20, 7, 20, 5, [0.2, 0.1], [0.8, 0.5], 71, 16, 320, 96, 48),
+}

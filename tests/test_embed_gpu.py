@@ -306,3 +306,252 @@ def test_training_step_gradients_match_reference():
                 seen += 1
         tgn.memory.detach_memory()
     assert seen >= 12 * nb
+
+
+# ---------------------------------------------------------------------------------------------------------
+# TimeEncode on the device (model/time_encoding.py:18-28), incl. the large-argument branch of time_cosf
+# ---------------------------------------------------------------------------------------------------------
+def _time_identity_tgn(N, E1, k=4):
+    """A TGN whose aggregation returns cos(dt * w) itself: fc1 = [0 | 0 | I_T] with bias +1 (so the ReLU is
+    the identity on cos + 1), fc2 = I with bias -1, one neighbour of weight 1 per row."""
+    D = T = 100
+    F = 1
+    w = I.model_weights(D, F, T, 1, 5)
+    w["fc1_w"] = np.concatenate([np.zeros((D, D + F), np.float32), np.eye(T, dtype=np.float32)], axis=1)
+    w["fc1_b"] = np.ones(D, np.float32)
+    w["fc2_w"] = np.eye(D, dtype=np.float32)
+    w["fc2_b"] = -np.ones(D, np.float32)
+    efeat = np.zeros((E1, F), np.float32)
+    return build_tgn(N, E1, D, F, T, k, [0.1], [0.5], w, efeat).eval()
+
+
+def test_time_encode_through_embed_kernel():
+    """g6_timeencode (the reference TimeEncode's outputs for dt = 0 ... 3e8, 16777217, ...) through zt_embed."""
+    g = golden("g6_timeencode")
+    dts = g["dts"].ravel()
+    # add the padding-slot value f32(t_now) for t_now as large as SuperUser / the bench stream have
+    extra = np.array([6.2e7, 2.4e8, 2.9e8, 4.0e6, 3.99e6, 1.0e7], np.float32)
+    tw = g["time_w"]
+    all_dt = np.concatenate([dts, extra])
+    want = np.concatenate([g["enc"].reshape(-1, 100), np.cos(extra[:, None] * tw[None, :]).astype(np.float32)])
+    n, k = len(all_dt), 4
+    tgn = _time_identity_tgn(50, 10, k)
+    dev = tgn.device
+    nodes = torch.ones(n, dtype=torch.int32, device=dev)
+    on = torch.zeros((1, n, k), dtype=torch.int32, device=dev)
+    on[0, :, 2] = 3
+    oe = torch.zeros_like(on)
+    od = torch.zeros((1, n, k), dtype=torch.float32, device=dev)
+    od[0, :, 2] = torch.from_numpy(all_dt).to(dev)
+    ow = torch.zeros_like(od)
+    ow[0, :, 2] = 1.0
+    out = tgn.embedding_module.embed_device(tgn.memory.memory, nodes, on, oe, od, ow).cpu().numpy()
+    got = out[:, 100:]
+    assert np.abs(got[: len(dts)] - want[: len(dts)]).max() <= 2e-6          # vs the reference's own outputs
+    # vs float64 cos of the float32 product (what torch.cos approximates); the ocml cos has its own 1e-7
+    x = (all_dt[:, None].astype(np.float32) * tw[None, :]).astype(np.float32).astype(np.float64)
+    assert np.abs(got - np.cos(x)).max() <= 2e-6
+
+
+def test_time_encode_through_message_kernel():
+    """The same dt set as message time features: cos((f32(t) - last_update) * w) in zt_store_messages."""
+    g = golden("g6_timeencode")
+    dts = np.concatenate([g["dts"].ravel(), np.array([6.2e7, 2.4e8, 2.9e8, 4.0e6], np.float32)])
+    B = len(dts)
+    tgn = _time_identity_tgn(2 * B + 2, B + 2)
+    dev = tgn.device
+    src = torch.arange(1, B + 1, dtype=torch.int32, device=dev)
+    dst = torch.arange(B + 1, 2 * B + 1, dtype=torch.int32, device=dev)
+    ts = torch.from_numpy(dts.astype(np.float64)).to(dev)
+    eidx = torch.arange(1, B + 1, dtype=torch.int64, device=dev)
+    tgn.store_messages_device(src, dst, ts, eidx)
+    msg = tgn.memory.messages.cpu().numpy()
+    tw = g["time_w"]
+    x = (dts[:, None] * tw[None, :]).astype(np.float32).astype(np.float64)
+    for rows in (np.arange(1, B + 1), np.arange(B + 1, 2 * B + 1)):
+        got = msg[rows, -100:]
+        assert np.abs(got - np.cos(x)).max() <= 2e-6
+        assert np.abs(got[: g["dts"].size] - g["enc"].reshape(-1, 100)).max() <= 2e-6
+    assert np.array_equal(tgn.memory.timestamps.cpu().numpy()[1: B + 1], dts)
+
+
+def test_protocol_vs_oracle_large_timestamps(oracle):
+    """A stream whose clock runs to 3e8 s (SuperUser spans 2.4e8): every padding slot carries dt = f32(t_now)
+    and most neighbours dt > 4e6, so the embeddings and messages run on the large-argument cosine."""
+    D = T = 100
+    N, E, F, bs, k, al, be, seed = 2000, 3600, 1, 300, 20, [0.1, 0.1], [0.5, 0.95], 207
+    src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+    ts = ts * (3.0e8 / ts[-1])
+    w = I.model_weights(D, F, T, 2, seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T), n_threads=8)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    for s in range(0, E, bs):
+        e = s + bs
+        with torch.no_grad():
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, False)
+        emb, _ = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        assert np.abs(torch.cat([se, de, ne]).cpu().numpy() - emb).max() <= TOL, "edge %d" % s
+    assert np.abs(tgn.memory.memory.cpu().numpy() - p.mem.memory).max() <= TOL
+    assert np.abs(tgn.memory.messages.cpu().numpy() - p.mem.messages).max() <= TOL
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), p.mem.last_update)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# tppr_strategy='pruning' end to end (config C4's shape): modules/embedding_module.py:221-224,280-297
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("name", list(I.PRUNE_EMBED_CASES))
+def test_pruning_protocol_golden(name, mode):
+    import types
+    from zebra_amd.tppr import get_neighbor_finder
+    kind, N, E, D, F, T, k, al, be, width, depth, seed, bs, nb, first, n_train = I.PRUNE_EMBED_CASES[name]
+    g = golden("g45_prune_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+    data = lambda n: types.SimpleNamespace(sources=src[:n], destinations=dst[:n], edge_idxs=eidx[:n], timestamps=ts[:n])
+    nf_full, nf_part = get_neighbor_finder(data(E)), get_neighbor_finder(data(n_train))
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy="pruning", nf=nf_part, width=width, depth=depth)
+    train = mode == "train"
+    tgn.train(train)
+    with torch.no_grad():
+        tgn.memory.memory.copy_(torch.from_numpy(mem0))
+    for b in range(nb):
+        if b == nb // 2:
+            tgn.set_neighbor_finder(nf_full)
+        s, e = first + b * bs, first + (b + 1) * bs
+        ctx = torch.enable_grad() if train else torch.no_grad()
+        with ctx:
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], width, train)
+            score = tgn.affinity_score(torch.cat([se, se], dim=0), torch.cat([de, ne])).squeeze(dim=0)
+        emb = torch.cat([se, de, ne]).detach().cpu().numpy()
+        assert np.abs(emb - g["%s_b%d_emb" % (mode, b)]).max() <= TOL, "batch %d" % b
+        assert np.abs(score.sigmoid().detach().cpu().numpy().ravel() - g["%s_b%d_prob" % (mode, b)]).max() <= TOL
+        if train:
+            tgn.memory.detach_memory()
+    assert abs(tgn.embedding_module.average_topk - float(g["%s_average_topk" % mode])) < 1e-6
+    m = tgn.memory
+    pre = "%s_b%d_" % (mode, nb - 1)
+    assert np.abs(m.memory.cpu().numpy() - g[pre + "memory"]).max() <= TOL
+    assert np.array_equal(m.last_update.cpu().numpy(), g[pre + "last_update"])
+    assert np.abs(m.messages.cpu().numpy() - g[pre + "messages"]).max() <= TOL
+    assert np.array_equal(m.timestamps.cpu().numpy(), g[pre + "timestamps"])
+    assert np.array_equal(m.nodes.astype(np.uint8), g[pre + "flags"])
+
+
+def test_pruning_protocol_vs_oracle_c4_shape(oracle):
+    """C4's shape (SuperUser: non-bipartite, F=1, k=40, width 10, depth 2, bs=1000) on a smaller graph,
+    step_device (the path bench.py times) against the oracle protocol."""
+    D = T = 100
+    N, E, F, bs, k, al, be, seed = 6000, 14000, 1, 1000, 40, [0.1, 0.1], [0.5, 0.95], 208
+    import types
+    from zebra_amd.tppr import get_neighbor_finder
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, 2, seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+    ref_nf = oracle.CsrOracle(src, dst, eidx, ts, N)
+    p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T), "pruning", ref_nf, 10, 2,
+                              n_threads=8)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy="pruning", nf=nf).eval()
+    dev = tgn.device
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    for s in range(8000, E, bs):
+        e = s + bs
+        got = tgn.step_device(*[x[s:e] for x in t], check_status=True).cpu().numpy()
+        emb, _ = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        assert np.abs(got - emb).max() <= TOL, "edge %d" % s
+    assert np.abs(tgn.memory.memory.cpu().numpy() - p.mem.memory).max() <= TOL
+    assert np.array_equal(tgn.memory.nodes.astype(np.uint8), p.mem.flags)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the epoch protocol through the drop-in (train.py:188-191,241-269,296-306)
+# ---------------------------------------------------------------------------------------------------------
+class _TgnEpochAdapter:
+    def __init__(self, tgn):
+        self.tgn, self.em = tgn, tgn.embedding_module
+
+    def init_memory(self):
+        self.tgn.memory.__init_memory__()
+
+    def reset_tppr(self):
+        self.em.reset_tppr()
+        self.tgn.set_neighbor_finder(None)
+
+    def fill_tppr(self, src, dst, ts, eidx, filled):
+        self.em.fill_tppr(src, dst, ts, eidx, filled)
+
+    def backup_tppr(self):
+        return self.em.backup_tppr()
+
+    def restore_tppr(self, b):
+        self.em.restore_tppr(b)
+
+    def backup_memory(self):
+        return self.tgn.memory.backup_memory()
+
+    def restore_memory(self, b):
+        self.tgn.memory.restore_memory(b)
+
+    def batch(self, src, dst, neg, ts, eidx, train):
+        self.tgn.train(train)
+        with (torch.enable_grad() if train else torch.no_grad()):
+            pos, negp = self.tgn.compute_edge_probabilities(src, dst, neg, ts, eidx, 10, train)
+        return torch.cat([pos, negp]).detach().cpu().numpy().ravel()
+
+    def memory_state(self):
+        m = self.tgn.memory
+        return dict(memory=m.memory.detach().cpu().numpy(), last_update=m.last_update.cpu().numpy(),
+                    messages=m.messages.detach().cpu().numpy(), timestamps=m.timestamps.cpu().numpy(),
+                    flags=m.nodes.astype(np.uint8))
+
+    def tppr_state(self):
+        f = self.em.tppr_finder
+        return {"m%d_%s" % (m, kk): v for m in range(f.n_tppr) for kk, v in f.export_state(m).items()}
+
+
+@pytest.mark.parametrize("aliasing", [True, False])
+@pytest.mark.parametrize("name", list(I.EPOCH_CASES))
+def test_epoch_protocol_golden(name, aliasing):
+    """Two epochs of the reference's driver against its own run (g10_epoch).  With
+    reference_compat_aliasing the whole protocol must reproduce, including the reference's quirks
+    (restore_tppr is a no-op, flags are shared between backups); with deep snapshots (the default)
+    everything up to the first restore must."""
+    from helpers import epoch_protocol, make_checker
+    case = I.EPOCH_CASES[name]
+    N, E, D, F, T, k, al, be, seed = case[:9]
+    g = golden("g10_epoch_" + name)
+    streams = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, compat=aliasing)
+    assert tgn.memory.reference_compat_aliasing == aliasing
+    epoch_protocol(_TgnEpochAdapter(tgn), g, case, streams, make_checker(g, TOL), aliasing=aliasing)
+
+
+def test_deep_snapshots_restore_what_was_backed_up():
+    """Default (deep) snapshots: after backup -> eval batches -> restore, memory, flags and T-PPR state are
+    exactly what was backed up (the reference's aliasing loses both, g10 records that)."""
+    name = "stream_d20_f7"
+    N, E, D, F, T, k, al, be, seed, bs, n_train = I.EPOCH_CASES[name][:11]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+    a = _TgnEpochAdapter(tgn)
+    for s in range(0, 64, bs):
+        a.batch(src[s:s + bs], dst[s:s + bs], neg[s:s + bs], ts[s:s + bs], eidx[s:s + bs], True)
+    mem0, tp0 = a.memory_state(), a.tppr_state()
+    assert mem0["flags"].sum() > 0
+    mb, tb = a.backup_memory(), a.backup_tppr()
+    for s in range(64, 128, bs):
+        a.batch(src[s:s + bs], dst[s:s + bs], neg[s:s + bs], ts[s:s + bs], eidx[s:s + bs], False)
+    assert not np.array_equal(a.memory_state()["memory"], mem0["memory"])
+    a.restore_memory(mb)
+    a.restore_tppr(tb)
+    for kk, v in a.memory_state().items():
+        assert np.array_equal(v, mem0[kk]), kk
+    for kk, v in a.tppr_state().items():
+        assert np.array_equal(v, tp0[kk]), kk

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import inputs as I
+from helpers import epoch_protocol, make_checker
 from conftest import golden
 
 EMB_TOL = 1e-4
@@ -166,3 +167,111 @@ def test_time_encode(oracle):
     assert np.array_equal(I.time_encode_weights(100), g["time_w"])
     enc = np.cos(g["dts"][..., None] * g["time_w"][None, None, :]).astype(np.float32)
     assert np.abs(enc - g["enc"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", list(I.ATTENTION_CASES))
+def test_attention_restatement_matches_reference_layer(name):
+    """oracle/attention_np.py vs the outputs of the reference's own TemporalAttentionLayer (g9)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import attention_np
+    D, F, T, k, N, heads, seed = I.ATTENTION_CASES[name]
+    g = golden("g9_attention_" + name)
+    out, aw = attention_np.temporal_attention(*I.attention_inputs(D, F, T, k, N, seed), I.attention_weights(D, F, T, seed),
+                                              heads)
+    assert np.abs(out - g["out"]).max() <= 1e-5
+    assert np.abs(aw - g["attn_w"]).max() <= 1e-6
+    assert np.abs(g["attn_w"][3]).max() == 0 and np.abs(aw[3]).max() == 0       # the row without neighbours
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("name", list(I.PRUNE_EMBED_CASES))
+def test_pruning_protocol(oracle, name, mode):
+    """tppr_strategy='pruning' through the whole per-batch protocol (config C4's shape), with the
+    neighbour-finder swap of train.py:191,245 half-way."""
+    kind, N, E, D, F, T, k, al, be, width, depth, seed, bs, nb, first, n_train = I.PRUNE_EMBED_CASES[name]
+    g = golden("g45_prune_" + name)
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+    nf_full = oracle.CsrOracle(src, dst, eidx, ts, N)
+    nf_part = oracle.CsrOracle(src[:n_train], dst[:n_train], eidx[:n_train], ts[:n_train], N)
+    p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T), "pruning", nf_part, width, depth)
+    p.mem.memory[...] = mem0
+    train = mode == "train"
+    for b in range(nb):
+        if b == nb // 2:
+            p.set_neighbor_finder(nf_full)
+        s, e = first + b * bs, first + (b + 1) * bs
+        emb, prob = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], train)
+        assert np.abs(emb - g["%s_b%d_emb" % (mode, b)]).max() <= EMB_TOL, "batch %d" % b
+        assert np.abs(prob - g["%s_b%d_prob" % (mode, b)]).max() <= EMB_TOL
+    assert abs(p.average_topk - float(g["%s_average_topk" % mode])) < 1e-6
+    pre = "%s_b%d_" % (mode, nb - 1)
+    assert np.abs(p.mem.memory - g[pre + "memory"]).max() <= EMB_TOL
+    assert np.array_equal(p.mem.last_update, g[pre + "last_update"])
+    assert np.abs(p.mem.messages - g[pre + "messages"]).max() <= EMB_TOL
+    assert np.array_equal(p.mem.timestamps, g[pre + "timestamps"])
+    assert np.array_equal(p.mem.flags, g[pre + "flags"])
+
+
+class _OracleEpochAdapter:
+    """The oracle under the epoch protocol, with the reference's aliasing: backups of the
+    T-PPR state are the live object, restore_val_tppr makes the val state live."""
+
+    def __init__(self, oracle, case, w, efeat):
+        N, E, D, F, T, k, al, be = case[:8]
+        self.o = oracle
+        self.p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T))
+        self.val = None
+        self.M = len(al)
+
+    def init_memory(self):
+        self.p.init_memory()
+
+    def reset_tppr(self):                           # new objects; the old ones live on in val / backups
+        p = self.p
+        p.tppr = self.o.TpprOracle(p.N, p.k, self.M, p.alpha, p.beta)
+
+    def fill_tppr(self, src, dst, ts, eidx, filled):
+        if filled:
+            self.p.tppr = self.val                  # restore_val_tppr: shallow copy == alias
+        else:
+            self.p.tppr.update_only(src, dst, ts, eidx)
+            self.val = self.p.tppr
+
+    def backup_tppr(self):
+        return self.p.tppr
+
+    def restore_tppr(self, b):
+        self.p.tppr = b
+
+    def backup_memory(self):
+        return self.p.backup_memory()
+
+    def restore_memory(self, b):
+        self.p.restore_memory(b)
+
+    def batch(self, src, dst, neg, ts, eidx, train):
+        return self.p.batch(src, dst, neg, ts, eidx, train)[1]
+
+    def memory_state(self):
+        m = self.p.mem
+        return dict(memory=m.memory, last_update=m.last_update, messages=m.messages, timestamps=m.timestamps,
+                    flags=m.flags)
+
+    def tppr_state(self):
+        return {"m%d_%s" % (m, kk): v for m in range(self.M) for kk, v in self.p.tppr.export(m).items()}
+
+
+@pytest.mark.parametrize("name", list(I.EPOCH_CASES))
+def test_epoch_protocol(oracle, name):
+    """Two epochs of train -> fill_tppr -> val -> backup/restore -> inductive val, then test
+    (train.py:188-191,241-269,296-306) against the reference's own run (g10)."""
+    case = I.EPOCH_CASES[name]
+    N, E, D, F, T, k, al, be, seed = case[:9]
+    g = golden("g10_epoch_" + name)
+    streams = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    epoch_protocol(_OracleEpochAdapter(oracle, case, w, efeat), g, case, streams, make_checker(g, EMB_TOL))

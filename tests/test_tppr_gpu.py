@@ -465,3 +465,120 @@ def test_long_power_law_stream_vs_oracle(zt, oracle):
         got, want = f.export_rows(m, touched), o.export(m)
         for kk in got:
             assert np.array_equal(got[kk], want[kk][touched]), "state %s of model %d" % (kk, m)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# failure latch, plan tokens, grids that do not fit the stream (round-1 advisor findings)
+# ---------------------------------------------------------------------------------------------------------
+def _dev_batch(torch, src, dst, neg, ts, eidx, s, e):
+    d = torch.device("cuda")
+    return (torch.from_numpy(np.concatenate([src[s:e], dst[s:e], neg[s:e]])).to(d), torch.from_numpy(ts[s:e]).to(d),
+            torch.from_numpy(eidx[s:e]).to(d))
+
+
+def test_unchecked_bad_batch_is_dropped_and_latched(zt, oracle):
+    """A batch with an out-of-range id run WITHOUT a status check: its rows read as empty dictionaries, the state
+    is untouched, every valid batch that still gets through matches the oracle, and a later call raises."""
+    import torch
+    N, E, bs, k = 400, 4000, 200, 20
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, 111)
+    f = zt.tppr_finder(N, k, 2, al, be)
+    o = oracle.TpprOracle(N, k, 2, al, be)
+    raised = False
+    for b, s in enumerate(range(0, E, bs)):
+        e = s + bs
+        nodes_d, ts_d, eidx_d = _dev_batch(torch, src, dst, neg, ts, eidx, s, e)
+        bad = b == 3
+        if bad:
+            nodes_d = nodes_d.clone()
+            nodes_d[17] = N + 5
+        try:
+            outs = f.stream_device(nodes_d, ts_d, eidx_d, 3, True, -1, check_status=False)
+        except IndexError:
+            raised = True
+            assert b > 3
+            break
+        got = [x.cpu().numpy() for x in outs]
+        if bad:
+            for x in got:
+                assert not x.any(), "rows of a rejected batch must be zero"
+            continue
+        want = o.streaming_topk(np.concatenate([src[s:e], dst[s:e], neg[s:e]]), ts[s:e], eidx[s:e])
+        for x, y in zip(got, want):
+            assert np.array_equal(x, np.stack(y)), "batch %d after the rejected one" % b
+    if not raised:
+        with pytest.raises(IndexError):
+            f.check_status()
+    # reported once; the handle works again and still equals the oracle (which never saw the bad batch)
+    f.check_status()
+    nodes = np.concatenate([src[:50], dst[:50], neg[:50]])
+    a, w = f.streaming_topk(nodes, ts[:50] + ts[-1], eidx[:50]), o.streaming_topk(nodes, ts[:50] + ts[-1], eidx[:50])
+    for x, y in zip(a, w):
+        assert np.array_equal(np.stack(x), np.stack(y))
+    for m in range(2):
+        _cmp_state(f.export_state(m), o.export(m))
+
+
+def test_plan_tokens(zt, oracle):
+    """A plan is used only by the call that presents its token; a token whose plan has been dropped
+    (reset) falls back to an inline prepass; a token presented with other arguments is an error."""
+    import torch
+    N, E, bs, k = 300, 1200, 300, 20
+    src, dst, neg, ts, eidx = I.make_stream("hub", N, E, 112)
+    f = zt.tppr_finder(N, k, 1, [0.1], [0.5])
+    o = oracle.TpprOracle(N, k, 1, [0.1], [0.5])
+    b0, b1 = _dev_batch(torch, src, dst, neg, ts, eidx, 0, bs), _dev_batch(torch, src, dst, neg, ts, eidx, bs, 2 * bs)
+    tok0 = f.plan_device(b0[0], b0[2], 3, -1)
+    tok1 = f.plan_device(b1[0], b1[2], 3, -1)
+    assert tok0 != 0 and tok1 != 0 and tok0 != tok1
+    with pytest.raises(ValueError):                       # batch 1's ids with batch 0's token
+        f.stream_device(b1[0], b1[1], b1[2], 3, True, -1, plan_token=tok0)
+    for (n_d, t_d, e_d), tok, s in ((b0, tok0, 0), (b1, tok1, bs)):
+        got = f.stream_device(n_d, t_d, e_d, 3, True, -1, plan_token=tok)
+        want = o.streaming_topk(np.concatenate([src[s:s + bs], dst[s:s + bs], neg[s:s + bs]]), ts[s:s + bs], eidx[s:s + bs])
+        for x, y in zip(got, want):
+            assert np.array_equal(x.cpu().numpy(), np.stack(y))
+    # a plan made before reset_tppr must not be applied after it; same address, different ids
+    tok = f.plan_device(b0[0], b0[2], 3, -1)
+    f.reset_tppr()
+    o.reset_tppr()
+    b0[0].copy_(b1[0])
+    got = f.stream_device(b0[0], b1[1], b1[2], 3, True, -1, plan_token=tok)
+    want = o.streaming_topk(np.concatenate([src[bs:2 * bs], dst[bs:2 * bs], neg[bs:2 * bs]]), ts[bs:2 * bs], eidx[bs:2 * bs])
+    for x, y in zip(got, want):
+        assert np.array_equal(x.cpu().numpy(), np.stack(y))
+    _cmp_state(f.export_state(0), o.export(0))
+
+
+def test_grid_larger_than_the_run_stream(zt, oracle):
+    """Planned for the whole chip, run on a CU-masked stream of 8 CUs: the grid must shrink to what is resident
+    there and the hub chains must give way to the in-order queue -- same results, no time-out."""
+    import ctypes as C
+    import torch
+    from zebra_amd._capi import lib, check
+    N, E, bs, k = 500, 8192, 4096, 20
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    src, dst, neg, ts, eidx = I.make_stream("hub", N, E, 113)
+    f = zt.tppr_finder(N, k, 2, al, be)
+    o = oracle.TpprOracle(N, k, 2, al, be)
+    hs = C.c_void_p()
+    check(lib().zt_stream_create_masked(C.byref(hs), C.c_int32(0), C.c_int32(8)))
+    small = torch.cuda.ExternalStream(hs.value)
+    try:
+        for s in range(0, E, bs):
+            e = s + bs
+            n_d, t_d, e_d = _dev_batch(torch, src, dst, neg, ts, eidx, s, e)
+            tok = f.plan_device(n_d, e_d, 3, -1)            # on the default stream: plans a 256-CU grid
+            torch.cuda.synchronize()
+            with torch.cuda.stream(small):
+                got = f.stream_device(n_d, t_d, e_d, 3, True, -1, plan_token=tok)
+            small.synchronize()
+            want = o.streaming_topk(np.concatenate([src[s:e], dst[s:e], neg[s:e]]), ts[s:e], eidx[s:e])
+            for x, y in zip(got, want):
+                assert np.array_equal(x.cpu().numpy(), np.stack(y))
+        for m in range(2):
+            _cmp_state(f.export_state(m), o.export(m))
+    finally:
+        torch.cuda.synchronize()
+        check(lib().zt_stream_destroy(hs))

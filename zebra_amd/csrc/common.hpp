@@ -114,11 +114,14 @@ __device__ __forceinline__ float time_cos_poly(float rf, int q)
 
 __device__ __noinline__ float time_cosf_large(float x)
 {
+    // beyond 1e15 the quotient k no longer fits the float64 reduction below (k * pi/2 must stay exact to
+    // ~1e-17 * k): take the library's Payne-Hanek path; such arguments (dt > 3e7 years) are not data
+    if (!(fabsf(x) < 1.0e15f)) return cosf(x);
     const double xd = (double)x;
     const double kd = rint(xd * 0.63661977236758134308);
     double r = fma(-kd, 1.57079632679489655800e+00, xd);
     r = fma(-kd, 6.12323399573676603587e-17, r);
-    return time_cos_poly((float)r, (int)kd);     // |x| <= 3e8: k fits an int
+    return time_cos_poly((float)r, (int)((long long)kd & 3ll));   // |k| < 6.4e14: the quadrant from 64 bits
 }
 
 __device__ __forceinline__ float time_cosf(float x)

@@ -185,6 +185,12 @@ struct zt_tppr {
     unsigned epoch;
     int n_cu;
     int run_cus;     // CUs of the stream the last k_stream ran on (0: not known yet)
+    int wg_per_cu;   // k_stream workgroups one CU can hold (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+    // Failure latch in host-mapped memory: the first ZT_ERR_RANGE / ZT_ERR_TIMEOUT of any launch is written
+    // here by the device (system scope), so the NEXT host call on the handle fails without a synchronisation
+    // even when the caller never polls zt_tppr_status.  Cleared by zt_tppr_status.
+    int *latch_host, *latch_dev;
+    unsigned long long plan_serial;   // tokens handed out by zt_tppr_plan
     // Two sets of the prepass buffers above (the fields above point into the set in use): the prepass of
     // the next call can run on another stream while k_stream still reads the previous call's set.
     struct PlanSet {
@@ -195,7 +201,8 @@ struct zt_tppr {
         // what the set was planned for (valid == a zt_tppr_plan result not consumed yet)
         bool valid;
         const int32_t *nodes;
-        int B, n_roles, model, grid;
+        int B, n_roles, model, grid, max_chains;
+        unsigned long long token;
     } set[2];
     int next_set;
     // last launch (diagnostics)
@@ -253,8 +260,16 @@ __host__ __device__ inline u64 granule(unsigned tag, unsigned payload) { return 
 // edge's second access to the same node (self-loop, negative == endpoint) is a
 // SHADOW: it is not entered into the node's group.
 // K1: validate ids; count accesses per node; remember each access' slot.
+__device__ __forceinline__ void latch_failure(int *latch, int code)
+{
+    __hip_atomic_store(latch, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// K0: a set is planned afresh: the status of the launch it last served is history (the handle's latch keeps it)
+__global__ void k_plan_begin(int *ctl) { if (threadIdx.x == 0) { ctl[2] = 0; ctl[13] = 0; } }
+
 __global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
-                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl)
+                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl, int *latch)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
@@ -267,6 +282,7 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
     }
     if (!ok) {
         atomicExch(&ctl[2], ZT_ERR_RANGE);
+        latch_failure(latch, ZT_ERR_RANGE);
         slot[a] = -1;
         return;
     }
@@ -670,6 +686,7 @@ __device__ __noinline__ void note_timeout(int *status, int kind, int a, int b, i
     }
     __threadfence();
     atomicExch(status, ZT_ERR_TIMEOUT);
+    latch_failure(*reinterpret_cast<int **>(ctl + 14), ZT_ERR_TIMEOUT);    // ctl[14..15]: address of the handle's latch
 }
 
 // One wait of the launch has already timed out: the others stop waiting too (their results are void).
@@ -744,6 +761,7 @@ struct StreamArgs {
     const long long *eidx;
     long long role_stride;
     int B, n_roles, emit, m_lo, n_models;
+    int use_chains;    // 0: the grid cannot be guaranteed resident -> every edge goes through the in-order queue
     long long out_rows;
     int *out_nodes, *out_eidx;
     float *out_dt, *out_w;
@@ -873,7 +891,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     STAMP(1);
     WL(0, 7); WL(3, wall_clock64() >> 7); WL(6, wl_fail | (hub_by_mail ? 256 : 0)); if (wl_fail & 14) WL(7, wl_seen);
     // ---- all reads done: later writers of these rows may go ahead ----
-    st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
+    // release: the row loads above must have returned before a later writer may see the flag (the loads
+    // of a negative sample's row are not consumed until emission, so nothing else orders them)
+    __hip_atomic_store(done + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // every lane, same word (no lane-0 branch, see the dequeue)
 
     // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
     // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
@@ -936,7 +956,19 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
     __shared__ Mail mail;
     WaveLds &L = lds[threadIdx.x / WAVE];
     const int lane = lane_id();
-    if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) return;   // rejected by k_count: touch nothing
+    if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) {         // rejected by k_count: the state is not touched,
+        if (A.emit) {                                  // the output rows read as empty dictionaries
+            const int k = h.k;
+            for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+                 q < (long long)A.n_models * A.n_roles * A.B * k; q += (long long)gridDim.x * blockDim.x) {
+                const long long c = q % k, row = q / k;
+                const long long i = row % A.B, role = (row / A.B) % A.n_roles, mo = row / ((long long)A.B * A.n_roles);
+                const long long o = (mo * A.out_rows + role * A.role_stride + i) * k + c;
+                A.out_nodes[o] = 0; A.out_eidx[o] = 0; A.out_dt[o] = 0.f; A.out_w[o] = 0.f;
+            }
+        }
+        return;
+    }
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     if (threadIdx.x == 0) { mail.head = 0; mail.tag = 0; }
     for (int q = lane; q < HTAB; q += WAVE) L.htab[q] = -1;
@@ -944,7 +976,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
     const int n_models = A.n_models;
 
     // ---- chain workgroups: blocks [0, chains * models) each own one hub of one model ----
-    const int n_chain_wg = h.ctl[4] * n_models;
+    const int n_chain_wg = A.use_chains ? h.ctl[4] * n_models : 0;
     if ((int)blockIdx.x < n_chain_wg) {
         const int c = blockIdx.x / n_models, mo = blockIdx.x % n_models;
         const long long hub = h.chain_node[c];
@@ -971,7 +1003,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= total) return;
         const int i = idx / n_models;
-        if (h.owner_of[i] >= 0) continue;              // a chain workgroup applies this edge
+        if (A.use_chains && h.owner_of[i] >= 0) continue;   // a chain workgroup applies this edge
         process_edge(h, A, L, lane, i, idx % n_models, nullptr, -1, -1, -1);
     }
 }
@@ -1040,6 +1072,12 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         P.used = false;
         P.valid = false;
     }
+    ZT_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->latch_host), sizeof(int), hipHostMallocMapped));
+    *h->latch_host = 0;
+    ZT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->latch_dev), h->latch_host, 0));
+    for (int q = 0; q < 2; ++q)                        // note_timeout finds the latch through ctl[14..15]
+        ZT_HIP(hipMemcpy(h->set[q].ctl + 14, &h->latch_dev, sizeof(int *), hipMemcpyHostToDevice));
+    h->plan_serial = 0;
     h->next_set = 0;
     use_set(h, 0);
     hipDeviceProp_t prop;
@@ -1047,6 +1085,11 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     ZT_HIP(hipGetDevice(&dev));
     ZT_HIP(hipGetDeviceProperties(&prop, dev));
     h->n_cu = prop.multiProcessorCount;
+    // every workgroup of a k_stream grid that runs hub chains must be resident: ask the runtime how many
+    // fit on a CU (LDS, registers) rather than estimating it
+    int per_cu = 0;
+    ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, WAVE * WAVES_PER_WG, 0));
+    h->wg_per_cu = per_cu;
     h->epoch = 0;
     int rc = zt_tppr_reset(h, nullptr);
     if (rc != ZT_OK) return rc;
@@ -1060,6 +1103,7 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
     if (!h) return ZT_OK;
     (void)hipDeviceSynchronize();
     (void)hipFree(h->rows); (void)hipFree(h->done);
+    if (h->latch_host) (void)hipHostFree(h->latch_host);
     for (int q = 0; q < 2; ++q) {
         zt_tppr::PlanSet &P = h->set[q];
         (void)hipFree(P.cnt); (void)hipFree(P.off); (void)hipFree(P.ctl); (void)hipFree(P.slot); (void)hipFree(P.list);
@@ -1077,6 +1121,7 @@ extern "C" int zt_tppr_reset(zt_tppr *h, void *stream)
     if (!h) return ZT_ERR_ARG;
     const size_t rows = (size_t)h->M * (size_t)h->N;
     ZT_HIP(hipMemsetAsync(h->rows, 0, rows * h->rg * sizeof(u64), (hipStream_t)stream));
+    h->set[0].valid = h->set[1].valid = false;       // plans made for the old state's stream are void
     return ZT_OK;
 }
 
@@ -1093,10 +1138,10 @@ extern "C" int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream)
     // tags are relative to the owner's launch epoch: strip them in the copy
     k_retag<<<2048, 256, 0, s>>>(dst->rows, (long long)n);
     ZT_LAUNCH_CHECK();
+    dst->set[0].valid = dst->set[1].valid = false;
     return ZT_OK;
 }
 
-// grid of k_stream and the number of hub chains for a launch of B edges
 // CUs a stream may use (CU-masked streams: the size of the mask)
 static int stream_cus(const zt_tppr *h, hipStream_t s)
 {
@@ -1107,7 +1152,18 @@ static int stream_cus(const zt_tppr *h, hipStream_t s)
     return (c > 0 && c < h->n_cu) ? c : h->n_cu;
 }
 
-static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, int *max_chains_out)
+// hub chains a grid can carry: at most two thirds of its workgroups, so the general queue always keeps waves
+static int chains_for_grid(int grid, int n_models)
+{
+    static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
+    int max_chains = (2 * grid) / (3 * n_models);
+    if (max_chains > chains_env) max_chains = chains_env;
+    if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
+    return max_chains < 0 ? 0 : max_chains;
+}
+
+// grid of k_stream and the number of hub chains for a launch of B edges on a stream of `cus` CUs
+static void launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *grid_out, int *max_chains_out)
 {
     long long waves = (long long)B * n_models;
     // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
@@ -1115,24 +1171,16 @@ static void launch_shape(const zt_tppr *h, int B, int n_models, int *grid_out, i
     // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 8 waves).
     static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
     // Every workgroup of the grid must be resident at once (chain workgroups wait on each other's rows):
-    // the CUs of the stream that runs k_stream (run_cus: learnt from the last launch, a CU-masked stream
-    // offers fewer) times the workgroups one CU can hold (LDS).
-    constexpr size_t wg_lds = sizeof(WaveLds) * WAVES_PER_WG + sizeof(Mail);
-    constexpr int per_cu = (int)((160 * 1024) / wg_lds) < 1 ? 1 : (int)((160 * 1024) / wg_lds);
-    const int cus = h->run_cus > 0 ? h->run_cus : h->n_cu;
+    // the CUs of the stream that runs k_stream (a CU-masked stream offers fewer) times the workgroups one
+    // CU holds (asked from the runtime at create time).
     long long max_waves = (long long)(cus * WAVES_PER_WG * wgs_per_cu);
-    const long long resident = (long long)cus * per_cu * WAVES_PER_WG;
+    const long long resident = (long long)cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1) * WAVES_PER_WG;
     if (max_waves > resident) max_waves = resident;
     if (max_waves < WAVES_PER_WG) max_waves = WAVES_PER_WG;
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
-    // hub chains: at most two thirds of the grid, so the general queue always keeps waves
-    static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
-    int max_chains = (2 * grid) / (3 * n_models);
-    if (max_chains > chains_env) max_chains = chains_env;
-    if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
     *grid_out = grid;
-    *max_chains_out = max_chains;
+    *max_chains_out = chains_for_grid(grid, n_models);
 }
 
 // The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
@@ -1147,9 +1195,10 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
     const int tb = 256, gb = (A + tb - 1) / tb;
     const int n_models = model < 0 ? h->M : 1;
     int grid, max_chains;
-    launch_shape(h, B, n_models, &grid, &max_chains);
+    launch_shape(h, h->run_cus > 0 ? h->run_cus : h->n_cu, B, n_models, &grid, &max_chains);
     ZT_PROF_BEGIN(s, P_PREPASS);
-    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl);
+    k_plan_begin<<<1, 64, 0, s>>>(h->ctl);
+    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl, h->latch_dev);
     k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
     k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
     k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
@@ -1166,7 +1215,7 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
     ZT_PROF_END(s, P_CLEANUP);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.planned, s));
-    P.nodes = nodes; P.B = B; P.n_roles = n_roles; P.model = model; P.grid = grid;
+    P.nodes = nodes; P.B = B; P.n_roles = n_roles; P.model = model; P.grid = grid; P.max_chains = max_chains;
     return ZT_OK;
 }
 
@@ -1185,7 +1234,18 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     ZT_HIP(hipStreamWaitEvent(s, P.planned, 0));
     use_set(h, q);
     h->run_cus = stream_cus(h, s);
+    // The plan sized the grid for the CUs it expected.  If THIS stream offers fewer (a CU mask the plan did
+    // not know about), shrink the grid to what is resident here; hub chains only run when their workgroups
+    // plus a general queue fit, otherwise every edge goes through the in-order queue, which needs no
+    // residency (a task only waits on tasks already dequeued by resident waves).
+    int grid = P.grid, use_chains = 1;
+    const int resident = h->run_cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1);
+    if (grid > resident) {
+        grid = resident;
+        use_chains = P.max_chains <= chains_for_grid(grid, model < 0 ? h->M : 1) ? 1 : 0;
+    }
     StreamArgs sa;
+    sa.use_chains = use_chains;
     sa.nodes = nodes; sa.tsv = ts; sa.eidx = eidx; sa.role_stride = role_stride; sa.B = B; sa.n_roles = n_roles;
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
@@ -1198,7 +1258,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     }
 #endif
     ZT_PROF_BEGIN(s, P_STREAM);
-    k_stream<<<P.grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.consumed, s));
@@ -1207,13 +1267,25 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     return ZT_OK;
 }
 
-extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev, int64_t B, int32_t n_roles,
-                            int32_t model, void *stream)
+// a failure latched by an earlier launch makes every later call fail until zt_tppr_status has reported it
+static int latched(const zt_tppr *h, const char *who)
 {
-    if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M) {
+    const int st = *reinterpret_cast<volatile int *>(h->latch_host);
+    if (st == 0) return ZT_OK;
+    set_error("%s: an earlier launch on this handle failed (%s); zt_tppr_status reports and clears it", who,
+              st == ZT_ERR_RANGE ? "node or edge id out of range, that batch was not applied" : "dependency wait timed out");
+    return st;
+}
+
+extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev, int64_t B, int32_t n_roles,
+                            int32_t model, uint64_t *token_out, void *stream)
+{
+    if (token_out) *token_out = 0;
+    if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M || !token_out) {
         set_error("zt_tppr_plan: bad argument");
         return ZT_ERR_ARG;
     }
+    if (int st = latched(h, "zt_tppr_plan")) return st;
     if (B == 0 || B > MAX_CHUNK) return ZT_OK;      // nothing to prepare / a multi-launch call plans inline
     if (!nodes_dev || !eidx_dev) { set_error("zt_tppr_plan: NULL buffer"); return ZT_ERR_ARG; }
     const int q = h->next_set;
@@ -1223,17 +1295,21 @@ extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t 
                         (hipStream_t)stream);
     if (rc != ZT_OK) return rc;
     h->set[q].valid = true;
+    h->set[q].token = ++h->plan_serial;
+    *token_out = h->set[q].token;
     return ZT_OK;
 }
 
 extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev,
                               int64_t B, int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev,
-                              int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev, void *stream)
+                              int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev, uint64_t plan_token,
+                              void *stream)
 {
     if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M) {
         set_error("zt_tppr_stream: bad argument");
         return ZT_ERR_ARG;
     }
+    if (int st = latched(h, "zt_tppr_stream")) return st;
     if (B == 0) return ZT_OK;
     if (!nodes_dev || !ts_dev || !eidx_dev ||
         (emit && (!out_nodes_dev || !out_eidx_dev || !out_dt_dev || !out_w_dev))) {
@@ -1242,12 +1318,21 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
     }
     hipStream_t s = (hipStream_t)stream;
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
-    // a prepass made ahead of time by zt_tppr_plan for exactly this call
-    for (int q = 0; q < 2; ++q) {
-        zt_tppr::PlanSet &P = h->set[q];
-        if (P.valid && P.nodes == nodes_dev && P.B == (int)B && P.n_roles == n_roles && P.model == model)
-            return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
-                             out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s);
+    // a prepass made ahead of time by zt_tppr_plan for exactly this call: the caller hands back the token
+    // that plan returned (a recycled device address alone must never select a stale plan)
+    if (plan_token != 0) {
+        for (int q = 0; q < 2; ++q) {
+            zt_tppr::PlanSet &P = h->set[q];
+            if (P.valid && P.token == plan_token) {
+                if (P.nodes != nodes_dev || P.B != (int)B || P.n_roles != n_roles || P.model != model) {
+                    set_error("zt_tppr_stream: plan token %llu was made for another call", (unsigned long long)plan_token);
+                    return ZT_ERR_ARG;
+                }
+                return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
+                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s);
+            }
+        }
+        // the plan is gone (reset / copy / import, or two newer plans): fall through to an inline prepass
     }
     h->run_cus = stream_cus(h, s);             // plan and run on the same stream here
     // launches of at most MAX_CHUNK edges: writer ordinals must fit the tag
@@ -1327,7 +1412,10 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
     hipStream_t s = (hipStream_t)stream;
     int c[CTL_WORDS] = {0};
     int st = 0;
-    for (int q = 0; q < 2 && st == 0; ++q) {          // the status word of either plan set
+    ZT_HIP(hipStreamSynchronize(s));
+    const int latch = *reinterpret_cast<volatile int *>(h->latch_host);
+    *reinterpret_cast<volatile int *>(h->latch_host) = 0;
+    for (int q = 0; q < 2 && st == 0; ++q) {          // the status word of either plan set (details of a time-out)
         ZT_HIP(hipMemcpyAsync(c, h->set[q].ctl, sizeof(c), hipMemcpyDeviceToHost, s));
         ZT_HIP(hipStreamSynchronize(s));
         st = c[2];
@@ -1337,6 +1425,10 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
             ZT_HIP(hipStreamSynchronize(s));
             use_set(h, q);
         }
+    }
+    if (st == 0 && latch != 0) {                      // the failing set has been re-planned since: the latch remembers
+        st = latch;
+        c[13] = 0;
     }
     if (st != 0) {
         if (st == ZT_ERR_RANGE) {
@@ -1517,6 +1609,7 @@ extern "C" int zt_tppr_import(zt_tppr *h, int32_t m, const int32_t *len_host, co
     }
     ZT_HIP(hipDeviceSynchronize());
     ZT_HIP(hipMemcpy(h->rows + (size_t)m * N * rg, g.data(), N * rg * sizeof(u64), hipMemcpyHostToDevice));
+    h->set[0].valid = h->set[1].valid = false;
     return ZT_OK;
 }
 
@@ -1547,5 +1640,6 @@ extern "C" int zt_tppr_import_rows(zt_tppr *h, int32_t m, const int64_t *ids_hos
     }
     (void)hipFree(ids_dev); (void)hipFree(buf_dev);
     ZT_HIP(e);
+    h->set[0].valid = h->set[1].valid = false;
     return ZT_OK;
 }

@@ -68,8 +68,12 @@ class Memory(nn.Module):
     for code that inspects them."""
 
     def __init__(self, n_nodes, memory_dimension, input_dimension, message_dimension=None, device="cuda",
-                 combination_method="sum"):
+                 combination_method="sum", reference_compat_aliasing=False):
         super().__init__()
+        # True: backup_memory hands out the live flag buffer itself, as the reference does with its host
+        # array (modules/memory.py:50,53) -- a restore then keeps whatever the flags have become since.
+        # False (default): the flags are part of the snapshot.  Fixture g10_epoch records the reference.
+        self.reference_compat_aliasing = bool(reference_compat_aliasing)
         self.n_nodes = n_nodes
         self.memory_dimension = memory_dimension
         self.input_dimension = input_dimension
@@ -114,14 +118,14 @@ class Memory(nn.Module):
     def get_last_update(self, node_idxs):
         return self.last_update[self._ids(node_idxs)]
 
-    def backup_memory(self):
-        return (self.memory.clone(), self.last_update.clone(), self.messages.clone(), self._flag_buf.clone(),
-                self.timestamps.clone())
+    def backup_memory(self):                                    # modules/memory.py:49-50
+        flags = self._flag_buf if self.reference_compat_aliasing else self._flag_buf.clone()
+        return (self.memory.clone(), self.last_update.clone(), self.messages.clone(), flags, self.timestamps.clone())
 
-    def restore_memory(self, memory_backup):
+    def restore_memory(self, memory_backup):                    # modules/memory.py:52-53
         self.memory, self.last_update, self.messages = (memory_backup[0].clone(), memory_backup[1].clone(),
                                                         memory_backup[2].clone())
-        self._flag_buf = memory_backup[3].clone()
+        self._flag_buf = memory_backup[3] if self.reference_compat_aliasing else memory_backup[3].clone()
         self.timestamps = memory_backup[4].clone()
 
     def detach_memory(self):
@@ -311,12 +315,12 @@ class GraphDiffusionEmbedding(nn.Module):
                                       p(self.fc2_source.bias), p(self.time_encoder.w.weight))
         return self._ew
 
-    def topk_device(self, nodes_d, ts_d, eidx_d, check_status=True):
+    def topk_device(self, nodes_d, ts_d, eidx_d, check_status=True, plan_token=0):
         """T-PPR query for one batch, device tensors in and out."""
         if self.tppr_strategy == "streaming":
             B = eidx_d.numel()
             return self.tppr_finder.stream_device(nodes_d, ts_d[:B].contiguous(), eidx_d, 3 if nodes_d.numel() == 3 * B
-                                                  else 2, True, -1, check_status=check_status)
+                                                  else 2, True, -1, check_status=check_status, plan_token=plan_token)
         if self.tppr_strategy == "pruning":
             return self.pruning_topk_device(nodes_d, ts_d, check_status=check_status)
         raise ValueError("tppr_strategy must be 'streaming' or 'pruning'")

@@ -56,7 +56,8 @@ class TGN(torch.nn.Module):
         message_dimension = raw_message_dimension
         self.memory = Memory(n_nodes=self.n_nodes, memory_dimension=self.memory_dimension,
                              input_dimension=message_dimension, message_dimension=message_dimension,
-                             device=self.device)
+                             device=self.device,
+                             reference_compat_aliasing=getattr(args, "reference_compat_aliasing", False))
         self.memory_updater = get_memory_updater(module_type=memory_updater_type, message_dimension=message_dimension,
                                                  memory_dimension=self.memory_dimension, device=self.device)
         self.embedding_module = get_embedding_module(
@@ -136,17 +137,17 @@ class TGN(torch.nn.Module):
         src_d, dst_d, neg_d, _, eidx_d = batch
         with torch.cuda.stream(self._plan_stream):
             nodes_d = torch.cat([src_d, dst_d, neg_d])
-            em.tppr_finder.plan_device(nodes_d, eidx_d, 3, -1)
+            token = em.tppr_finder.plan_device(nodes_d, eidx_d, 3, -1)
         nodes_d.record_stream(self._side)
-        self._planned[(eidx_d.data_ptr(), eidx_d.numel())] = nodes_d
+        self._planned[(eidx_d.data_ptr(), eidx_d.numel())] = (nodes_d, token)
 
     def _tppr_launch(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status):
         em = self.embedding_module
-        nodes_d = getattr(self, "_planned", {}).pop((eidx_d.data_ptr(), eidx_d.numel()), None)
+        nodes_d, token = getattr(self, "_planned", {}).pop((eidx_d.data_ptr(), eidx_d.numel()), (None, 0))
         if nodes_d is None:
             nodes_d = torch.cat([src_d, dst_d, neg_d])
         ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
-        return (nodes_d,) + tuple(em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status))
+        return (nodes_d,) + tuple(em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status, plan_token=token))
 
     def tppr_batch_device(self, batch, prefetch=None, check_status=False, plan=None):
         """T-PPR query of ``batch`` = (src, dst, neg, ts, eidx) -> (nodes, nbr, eidx, dt, w) device

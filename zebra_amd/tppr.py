@@ -209,9 +209,10 @@ class tppr_finder:
         d = self._dev
         return (torch.from_numpy(nodes).to(d), torch.from_numpy(ts).to(d), torch.from_numpy(eidx).to(d), B)
 
-    def stream_device(self, nodes_d, ts_d, eidx_d, n_roles=3, emit=True, model=-1, check_status=True):
+    def stream_device(self, nodes_d, ts_d, eidx_d, n_roles=3, emit=True, model=-1, check_status=True, plan_token=0):
         """Device-resident form: int32[n_roles*B], float64[B], int64[B] CUDA
-        tensors in, four [n_models][n_roles*B][k] CUDA tensors out."""
+        tensors in, four [n_models][n_roles*B][k] CUDA tensors out.  ``plan_token``: what
+        ``plan_device`` returned for this very call (same ``nodes_d``), or 0."""
         B = nodes_d.numel() // n_roles
         nm = self.n_tppr if model < 0 else 1
         d = nodes_d.device
@@ -222,9 +223,10 @@ class tppr_finder:
             ow = torch.empty_like(od)
         else:
             on = oe = od = ow = None
-        check(lib().zt_tppr_stream(self._live.h, ptr(nodes_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B),
-                                   C.c_int32(n_roles), C.c_int32(1 if emit else 0), C.c_int32(model), ptr(on),
-                                   ptr(oe), ptr(od), ptr(ow), stream_ptr()), "zt_tppr_stream")
+        rc = lib().zt_tppr_stream(self._live.h, ptr(nodes_d), ptr(ts_d), ptr(eidx_d), C.c_int64(B),
+                                  C.c_int32(n_roles), C.c_int32(1 if emit else 0), C.c_int32(model), ptr(on),
+                                  ptr(oe), ptr(od), ptr(ow), C.c_uint64(plan_token), stream_ptr())
+        self._raise_latched(rc, "zt_tppr_stream")
         if check_status:
             check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
         return on, oe, od, ow
@@ -232,10 +234,21 @@ class tppr_finder:
     def plan_device(self, nodes_d, eidx_d, n_roles=3, model=-1):
         """Runs the dependency prepass of a coming ``stream_device`` call (same ``nodes_d`` tensor,
         same batch) on the CURRENT stream; it reads only the ids, so it can overlap the previous
-        call's update kernel.  Optional: a call without a matching plan runs its own prepass."""
+        call's update kernel.  Returns the plan's token for ``stream_device(plan_token=...)``
+        (0: nothing was planned).  Optional: a call without a token runs its own prepass."""
         B = nodes_d.numel() // n_roles
-        check(lib().zt_tppr_plan(self._live.h, ptr(nodes_d), ptr(eidx_d), C.c_int64(B), C.c_int32(n_roles),
-                                 C.c_int32(model), stream_ptr()), "zt_tppr_plan")
+        tok = C.c_uint64(0)
+        rc = lib().zt_tppr_plan(self._live.h, ptr(nodes_d), ptr(eidx_d), C.c_int64(B), C.c_int32(n_roles),
+                                C.c_int32(model), C.byref(tok), stream_ptr())
+        self._raise_latched(rc, "zt_tppr_plan")
+        return int(tok.value)
+
+    def _raise_latched(self, rc, what):
+        """A failure latched by an EARLIER launch (bad id in a batch run with check_status=False, or a
+        dependency time-out) surfaces at the next call: report it once (zt_tppr_status also clears it)."""
+        if rc in (_capi.ZT_ERR_RANGE, _capi.ZT_ERR_TIMEOUT):
+            check(lib().zt_tppr_status(self._live.h, stream_ptr()) or rc, what)
+        check(rc, what)
 
     def check_status(self):
         check(lib().zt_tppr_status(self._live.h, stream_ptr()), "zt_tppr_stream")
