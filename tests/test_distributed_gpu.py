@@ -38,11 +38,17 @@ def _run(rank, world, port, cfg, out):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        N, E, D, F, T, k, al, be, seed, bs = cfg
-        src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+        N, E, D, F, T, k, al, be, seed, bs = cfg[:10]
+        strategy = cfg[10] if len(cfg) > 10 else "streaming"
+        src, dst, neg, ts, eidx = I.make_stream("bipartite" if strategy == "streaming" else "general", N, E, seed)
         w = I.model_weights(D, F, T, len(al), seed)
         _, efeat = I.random_tables(N, E + 1, D, F, seed)
-        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        nf = None
+        if strategy == "pruning":
+            import types
+            from zebra_amd.tppr import get_neighbor_finder
+            nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf).eval()
         runner = ShardedTGN(tgn, rank, world) if world > 1 else tgn
         dev = torch.device("cuda")
         t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
@@ -51,20 +57,29 @@ def _run(rank, world, port, cfg, out):
             cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
             embs.append(runner.step_device(*cur).cpu().numpy())
         torch.cuda.synchronize()
-        tgn.embedding_module.tppr_finder.check_status()
+        state = {}
+        if strategy == "streaming":
+            tgn.embedding_module.tppr_finder.check_status()
+            state = tgn.embedding_module.tppr_finder.export_state(0)
         m = tgn.memory
         out[rank] = dict(emb=embs, memory=m.memory.cpu().numpy(), last_update=m.last_update.cpu().numpy(),
                          messages=m.messages.cpu().numpy(), ts=m.timestamps.cpu().numpy(), flags=m.nodes.copy(),
-                         state=tgn.embedding_module.tppr_finder.export_state(0),
-                         shard=shard_range(3 * bs, rank, world))
+                         state=state, shard=shard_range(3 * bs, rank, world))
     finally:
         if world > 1:
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(world):
-    cfg = (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200)
+CFGS = {
+    "streaming": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200),
+    # config C4's shape (SuperUser: pruning T-PPR, k=40, F=1, width 10, depth 2), 4-GPU config in BASELINE.json
+    "pruning_c4": (900, 3000, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 302, 500, "pruning"),
+}
+
+
+@pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4")])
+def test_sharded_equals_single(world, cfg_name):
+    cfg = CFGS[cfg_name]
     mgr = mp.Manager()
     ref = mgr.dict()
     mp.spawn(_run, args=(1, _free_port(), cfg, ref), nprocs=1, join=True)

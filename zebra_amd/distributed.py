@@ -5,9 +5,10 @@ The reference has no distributed code at all; this is new work:
 
   * T-PPR state, node memory, pending messages and the edge-feature table are
     replicated (C5: ~26 GB of 288 GB per GPU);
-  * P1 (T-PPR update + row emission) is applied to the WHOLE batch on every
-    rank: the stream is sequential by construction, so replicas stay
-    bit-identical with zero communication;
+  * P1, streaming strategy (T-PPR update + row emission) is applied to the
+    WHOLE batch on every rank: the stream is sequential by construction, so
+    replicas stay bit-identical with zero communication; P1, pruning strategy
+    (a query of the static adjacency, rows independent) is sharded with P2;
   * P2 (gather + aggregate) is sharded over contiguous slices of the 3B rows;
   * P3 (last-message store + GRU update) is sharded by batch POSITION: the
     last occurrence of every endpoint is resolved over the whole batch, rank r
@@ -140,12 +141,20 @@ class ShardedTGN:
             tgn.update_memory_in_test(tgn.memory)
             tgn.test_mode = True
         B = src_d.numel()
-        nodes_d, on, oe, od, ow = tgn.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch,
-                                                        check_status, plan)                    # replicated
         r0, r1 = shard_range(3 * B, self.rank, self.world)
-        emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
-                              oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),
-                              check_status=check_status)
+        if em.tppr_strategy == "pruning":
+            # the pruning query reads only the static adjacency: rows are independent, so P1 shards with P2
+            nodes_d = torch.cat([src_d, dst_d, neg_d])
+            ts3 = torch.cat([ts_d, ts_d, ts_d])
+            mine = nodes_d[r0:r1].contiguous()
+            on, oe, od, ow = em.pruning_topk_device(mine, ts3[r0:r1].contiguous(), check_status=check_status)
+            emb = em.embed_device(tgn.memory.memory, mine, on, oe, od, ow, check_status=check_status)
+        else:
+            nodes_d, on, oe, od, ow = tgn.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch,
+                                                            check_status, plan)                    # replicated
+            emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
+                                  oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),
+                                  check_status=check_status)
         p0, p1 = shard_range(2 * B, self.rank, self.world)
         tgn.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=(p0, p1))
         # only this rank's winners are flagged: the GRU compacts them out of the endpoint list

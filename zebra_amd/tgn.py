@@ -182,7 +182,8 @@ class TGN(torch.nn.Module):
         return outs
 
     @torch.no_grad()
-    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None,
+                    stats=False):
         """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
         int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
         ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings.
@@ -193,6 +194,8 @@ class TGN(torch.nn.Module):
         em = self.embedding_module
         nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status,
                                                         plan)
+        if stats:                                    # average_topk (modules/embedding_module.py:232-233)
+            em._avg_topk_t = ow[0, : 2 * src_d.numel()].sum(dim=1).mean()
         emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
         B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
         self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each
@@ -221,7 +224,7 @@ class TGN(torch.nn.Module):
             if negative_nodes is None:
                 raise ValueError("the accelerated eval path expects negatives (tgn_model.py:132)")
             neg_d = torch.as_tensor(np.ascontiguousarray(negative_nodes, np.int32), device=d)
-            node_embedding = self.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=True)
+            node_embedding = self.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=True, stats=True)
         else:
             self.test_mode = False
             nodes = np.concatenate([source_nodes, destination_nodes, negative_nodes])
