@@ -37,10 +37,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # dense f32 MFMA
 
 
-def algorithmic_bytes(k, F, M, D=100, T=100):
+def algorithmic_bytes(k, F, M, D=100, T=100, strategy="streaming", width=10, depth=2):
     """logical bytes per edge, no cache credit."""
     msg = 2 * D + F + T
-    p1 = 5 * (24 * k + 8) + 48 * k                    # per model
+    if strategy == "streaming":
+        p1 = 5 * (24 * k + 8) + 48 * k                # per model: 3 rows read, 2 written, 3 output rows
+    else:                                             # pruning: CSR tails of width + width^2 + ... entries x 16 B
+        states = sum(width ** d for d in range(1, depth + 1))
+        p1 = 3 * states * 16 + 48 * k                 # per model (3 query rows per edge)
     p2 = 3 * k * (4 * D + 4 * F) + 3 * k * 16         # per model
     p2_once = 3 * 4 * D + 3 * 4 * D * (M + 1)
     p3 = 2 * (4 * msg + 4 * D + 4 * D + 4) + 2 * (4 * msg + 4)
@@ -48,9 +52,20 @@ def algorithmic_bytes(k, F, M, D=100, T=100):
 
 
 def algorithmic_flops(k, F, M, D=100, T=100):
+    """FLOPs per edge as the reference computes them (fc2 per neighbour), scorer included."""
     msg = 2 * D + F + T
+    H = D * (M + 1)
     p2 = 3 * k * (2 * (D + F + T) * D + 2 * D * D)    # per model (reference formulation)
-    return dict(p2=p2, src=3 * 4 * D * D, gru=2 * 2 * 3 * D * (msg + D), total=M * p2 + 3 * 4 * D * D + 2 * 2 * 3 * D * (msg + D))
+    src = 3 * 4 * D * D
+    gru = 2 * 2 * 3 * D * (msg + D)
+    scorer = 2 * (2 * (2 * H) * H + 2 * H)
+    return dict(p2=p2, src=src, gru=gru, scorer=scorer, total=M * p2 + src + gru + scorer)
+
+
+def executed_flops(k, F, M, D=100, T=100):
+    """FLOPs the HIP kernels execute per edge: fc2 is hoisted behind the k-reduction (aggregate.hip), so
+    k_fc1_agg runs fc1 only and k_embed_out runs fc2 once per row and model plus the source transform."""
+    return dict(fc1_agg=M * 3 * k * 2 * (D + F + T) * D, embed_out=M * 3 * 2 * D * D + 3 * 4 * D * D)
 
 
 def make_stream(wl, n_edges, seed=2020):
@@ -84,57 +99,90 @@ def build_model(wl, device, n_edge_rows):
     return tgn
 
 
-def cpu_baseline(wl, n_edges, n_threads):
-    """Oracle ("port") on the host cores: same protocol, same stream shape,
-    a bounded prefix of the stream; the second half is timed."""
+def snapshot_state(tgn, wl, touched):
+    """Host copy of the warm state (T-PPR rows, memory tables) of the nodes the stream has touched so far:
+    what the CPU baseline starts from, so that both legs see the same warm-up."""
+    import torch
+    ids = np.ascontiguousarray(touched, np.int64)
+    snap = {"ids": ids}
+    if wl["strategy"] == "streaming":
+        f = tgn.embedding_module.tppr_finder
+        snap["tppr"] = [f.export_rows(m, ids) for m in range(f.n_tppr)]
+    ids_d = torch.from_numpy(ids).to(tgn.device)
+    m = tgn.memory
+    for name in ("memory", "last_update", "messages", "timestamps"):
+        snap[name] = getattr(m, name).index_select(0, ids_d).cpu().numpy()
+    snap["flags"] = m.flags.index_select(0, ids_d).cpu().numpy()
+    return snap
+
+
+def model_weights(tgn):
+    em, g = tgn.embedding_module, tgn.memory_updater.memory_updater
+    c = lambda t: t.detach().cpu().numpy().copy()
+    w = dict(fc1_w=c(em.fc1.weight), fc1_b=c(em.fc1.bias), fc2_w=c(em.fc2.weight), fc2_b=c(em.fc2.bias),
+             fc1s_w=c(em.fc1_source.weight), fc1s_b=c(em.fc1_source.bias), fc2s_w=c(em.fc2_source.weight),
+             fc2s_b=c(em.fc2_source.bias), w_ih=c(g.weight_ih), w_hh=c(g.weight_hh), b_ih=c(g.bias_ih),
+             b_hh=c(g.bias_hh), aff1_w=c(tgn.affinity_score.fc1.weight), aff1_b=c(tgn.affinity_score.fc1.bias),
+             aff2_w=c(tgn.affinity_score.fc2.weight), aff2_b=c(tgn.affinity_score.fc2.bias))
+    return w, c(tgn.time_encoder.w.weight).ravel()
+
+
+def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
+    """Oracle ("port") on the host cores: the eval-mode protocol on the first timed batches of the same
+    stream, started from the GPU run's warm state.  The T-PPR loop runs single-threaded like the
+    reference's Numba loop for the first half of the sample and with one thread per T-PPR model for
+    the second half (the N-thread P1 variant, N = n_tppr); aggregation / GRU on n_threads OpenMP threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
-    import torch
-    from zebra_amd.modules import TimeEncode
-    if wl["strategy"] != "streaming":
-        return None
     bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
     D = T = 100
-    n_edges = max(2 * bs, n_edges // bs * bs)
-    src, dst, neg, ts, eidx = make_stream(wl, n_edges)
     N = wl["n_nodes"] + 1
-    torch.manual_seed(0)
-    rng = np.random.RandomState(0)
-
-    def lin(o, i):
-        return (rng.standard_normal((o, i)) * np.sqrt(2.0 / (o + i))).astype(np.float32), np.zeros(o, np.float32)
-    w = {}
-    w["fc1_w"], w["fc1_b"] = lin(D, D + F + T)
-    w["fc2_w"], w["fc2_b"] = lin(D, D)
-    w["fc1s_w"], w["fc1s_b"] = lin(D, D)
-    w["fc2s_w"], w["fc2s_b"] = lin(D, D)
-    gru = dict(w_ih=lin(3 * D, 2 * D + F + T)[0], w_hh=lin(3 * D, D)[0], b_ih=np.zeros(3 * D, np.float32),
-               b_hh=np.zeros(3 * D, np.float32))
-    tw = TimeEncode(T).w.weight.detach().numpy().ravel().copy()
-    efeat = np.zeros((n_edges + 1, F), np.float32) if F == 1 else \
-        np.random.RandomState(1).standard_normal((n_edges + 1, F)).astype(np.float32)
-    f = pyoracle.TpprOracle(N, k, M, wl["alpha"], wl["beta"])
-    mem = pyoracle.MemoryOracle(N, D, 2 * D + F + T)
-    nb = n_edges // bs
-    t0 = None
-    timed = 0
-    for b in range(nb):
-        if b == nb // 2:
-            t0 = time.perf_counter()
-        s, e = b * bs, (b + 1) * bs
-        nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
-        on, oe, od, ow = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
-        pyoracle.embed(mem.memory, efeat, tw, nodes, np.stack(on), np.stack(oe), np.stack(od), np.stack(ow), w,
-                       n_threads=n_threads)
-        mem.store_messages(efeat, tw, src[s:e], dst[s:e], ts[s:e], eidx[s:e])
-        mem.gru_update(gru, np.unique(np.concatenate([src[s:e], dst[s:e]])), n_threads=n_threads)
-        if t0 is not None:
-            timed += e - s
-    dt = time.perf_counter() - t0
-    return dict(value=timed / dt, unit="edges/s", cores=n_threads, kind="port",
-                sample="first %d edges of the same synthetic stream from an empty state, second half (%d edges) "
-                       "timed; T-PPR loop single-threaded as in the reference, aggregation/GRU on %d OpenMP "
-                       "threads" % (n_edges, timed, n_threads))
+    efeat = np.zeros((wl["n_edges"] + 1, 1), np.float32) if F == 1 else csr_arrays["efeat"]
+    finder = None
+    if wl["strategy"] == "pruning":
+        finder = pyoracle.CsrOracle(csr_arrays["src"], csr_arrays["dst"], csr_arrays["eidx"], csr_arrays["ts"], N)
+    p = pyoracle.ProtocolOracle(N, D, F, T, k, wl["alpha"], wl["beta"], weights, efeat, time_w, wl["strategy"], finder,
+                                wl.get("width", 10), wl.get("depth", 2), n_threads=n_threads)
+    ids = snap["ids"]
+    if wl["strategy"] == "streaming":
+        for m in range(M):
+            p.tppr.import_rows(m, ids, snap["tppr"][m])
+    p.mem.memory[ids] = snap["memory"]
+    p.mem.last_update[ids] = snap["last_update"]
+    p.mem.messages[ids] = snap["messages"]
+    p.mem.timestamps[ids] = snap["timestamps"]
+    p.mem.flags[ids] = snap["flags"]
+    p.test_mode = True                              # the GPU leg flushed pending messages before its warm-up
+    half = max(1, len(batches) // 2)
+    t_p1 = [0.0, 0.0]
+    t_all = [0.0, 0.0]
+    n_e = [0, 0]
+    single = p.tppr.streaming_topk if p.tppr is not None else None
+    for b, (src, dst, neg, ts, eidx) in enumerate(batches):
+        part = 0 if b < half else 1
+        if p.tppr is not None:
+            p.tppr.streaming_topk = single if part == 0 else p.tppr.streaming_topk_threads
+        t0 = time.perf_counter()
+        nodes = np.concatenate([src, dst, neg]).astype(np.int32)
+        on = p.topk(nodes, ts, eidx)
+        t1 = time.perf_counter()
+        p.batch(src, dst, neg, ts, eidx, False, topk_out=on)
+        t2 = time.perf_counter()
+        t_p1[part] += t1 - t0
+        t_all[part] += t2 - t0
+        n_e[part] += len(src)
+    if p.tppr is not None:
+        p.tppr.streaming_topk = single
+    out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=n_threads, kind="port",
+               p1_edges_per_s_1thread=n_e[0] / max(t_p1[0], 1e-9),
+               sample="%d timed batches (%d edges) of the same stream from the GPU run's warm state; value = first "
+                      "%d batches with the T-PPR loop on 1 thread (as the reference's Numba loop); aggregation / "
+                      "GRU / scorer on %d OpenMP threads" % (len(batches), n_e[0] + n_e[1], half, n_threads))
+    if n_e[1]:
+        out["value_p1_threads"] = n_e[1] / t_all[1]
+        out["p1_threads"] = M if wl["strategy"] == "streaming" else 1
+        out["p1_edges_per_s_threads"] = n_e[1] / max(t_p1[1], 1e-9)
+    return out
 
 
 def main():
@@ -181,7 +229,8 @@ def main():
 
     wl = dict(synth.WORKLOADS[a.workload])
     bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
-    prefill = a.prefill_steps if a.prefill_steps >= 0 else {"c5": 480, "c3": 300, "c2": 250, "c4": 0}[a.workload]
+    # the first 10 % of the stream is the untimed warm-up, so that T-PPR rows are full
+    prefill = a.prefill_steps if a.prefill_steps >= 0 else (wl["n_edges"] // 10) // bs
     n_steps_total = prefill + a.warmup + a.steps
     n_edges = n_steps_total * bs
     stream_edges = min(wl["n_edges"], max(n_edges, 1))
@@ -241,6 +290,22 @@ def main():
     run(prefill, a.warmup)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
     torch.cuda.synchronize()
+    # ---- warm state for the CPU leg (same warm-up as the GPU leg) and row-fill statistics ----
+    e0 = (prefill + a.warmup) * bs
+    cpu_nb = 0
+    if world == 1 and a.cpu_edges != 0:
+        ce = a.cpu_edges if a.cpu_edges > 0 else {"c5": 48 * bs, "c3": 40 * bs, "c2": 60 * bs, "c4": 20 * bs}[a.workload]
+        cpu_nb = max(2, min(a.steps, ce // bs))
+    snap, fill = None, None
+    if cpu_nb:
+        touched = np.unique(np.concatenate([src[:e0], dst[:e0]])) if e0 else np.zeros(0, np.int64)
+        snap = snapshot_state(tgn, wl, touched)
+        if wl["strategy"] == "streaming" and len(touched):
+            ends = np.concatenate([src[e0:e0 + bs], dst[e0:e0 + bs], neg[e0:e0 + bs]])
+            pos = np.searchsorted(touched, ends)
+            seen = (pos < len(touched)) & (touched[np.minimum(pos, len(touched) - 1)] == ends)
+            ln = np.where(seen, snap["tppr"][0]["len"][np.minimum(pos, len(touched) - 1)], 0)
+            fill = dict(mean_row_len=float(ln.mean()), frac_empty=float((ln == 0).mean()), frac_full=float((ln == k).mean()))
     if not a.no_profile:
         lib.zt_profile_reset()
         lib.zt_profile_enable(1)
@@ -293,49 +358,58 @@ def main():
             if os.path.isfile(pj):
                 pmc = json.load(open(pj)).get("kernels", {})
                 break
-    ab = algorithmic_bytes(k, F, M)
+    ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
     af = algorithmic_flops(k, F, M)
+    ex = executed_flops(k, F, M)
+
+    def kernel_roofline(name):
+        """achieved = ALGORITHMIC bytes (or EXECUTED flops) of one launch / its average HIP-event time."""
+        us = kern[name]["avg_us"] * 1e-6
+        shard = world if name in ("fc1_agg", "embed_out", "pruned_topk") and world > 1 else 1
+        tr = pmc.get(name, {}).get("traffic")
+        if name in ("fc1_agg", "embed_out"):
+            ach = ex[name] * bs / shard / us / 1e12
+            return dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr,
+                        note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out); the reference "
+                             "formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
+        if name == "tppr_stream":
+            byts = ab["p1"] * M * bs                       # one k_stream launch covers all M models
+            note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
+                    "per-node chains; the binding resource is hops x hop latency, not HBM")
+        elif name == "pruned_topk":
+            byts = ab["p1"] * bs / shard                   # one launch per model
+            note = "CSR tail reads + output rows per query (binary-search probes not counted)"
+        elif name == "gru_update":
+            byts = 2 * (4 * (2 * 100 + F + 100) + 8 * 100 + 4) * bs / shard
+            note = None
+        else:
+            byts = ab["p3"] * bs / shard
+            note = None
+        ach = byts / us / 1e9
+        return dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                    traffic=tr, note=note)
+
     # dominant kernel = the one with the largest total time in the timed region
-    roof = None
+    roof = roof2 = None
     if kern:
         dom = max(kern, key=lambda n: kern[n]["avg_us"] * kern[n]["launches"])
-        per_launch_edges = bs / (world if dom in ("fc1_agg", "embed_out") and world > 1 else 1)
-        if dom in ("tppr_stream", "pruned_topk"):
-            per_model = dom == "pruned_topk"
-            byts = (ab["p1"] * (1 if per_model else M)) * bs      # one k_stream launch covers all M models
-            if a.workload == "c4":
-                byts = (3 * 110 * 16 + 48 * k) * bs
-            ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=pmc.get(dom, {}).get("traffic"),
-                        note="dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in "
-                             "order along per-node chains")
-        elif dom == "fc1_agg":
-            fl = af["p2"] * per_launch_edges               # one launch covers all M models via grid.y
-            fl = fl * M
-            ach = fl / (kern[dom]["avg_us"] * 1e-6) / 1e12
-            roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=pmc.get(dom, {}).get("traffic"))
-        else:
-            byts = ab["p3"] * bs
-            ach = byts / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=pmc.get(dom, {}).get("traffic"))
-
-    # the largest THROUGHPUT kernel as well, when the dominant one is the latency-bound T-PPR chain
-    roof2 = None
-    if kern and roof is not None and roof["kernel"] != "fc1_agg" and "fc1_agg" in kern:
-        fl = af["p2"] * (bs / world) * M
-        ach = fl / (kern["fc1_agg"]["avg_us"] * 1e-6) / 1e12
-        roof2 = dict(kernel="fc1_agg", bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                     frac=ach / MFMA_F32_PEAK_TF, traffic=pmc.get("fc1_agg", {}).get("traffic"))
+        roof = kernel_roofline(dom)
+        # the largest THROUGHPUT kernel as well, when the dominant one is the latency-bound T-PPR chain
+        if dom != "fc1_agg" and "fc1_agg" in kern:
+            roof2 = kernel_roofline("fc1_agg")
 
     cpu = None
-    if world == 1 and a.cpu_edges != 0:
+    if cpu_nb:
         n_threads = min(16, os.cpu_count() or 1)
-        ce = a.cpu_edges if a.cpu_edges > 0 else {"c5": 16 * bs, "c3": 40 * bs, "c2": 60 * bs, "c4": 0}[a.workload]
-        if ce:
-            cpu = cpu_baseline(wl, ce, n_threads)
+        weights, time_w = model_weights(tgn)
+        b0 = prefill + a.warmup
+        batches = [(src[b * bs:(b + 1) * bs], dst[b * bs:(b + 1) * bs], neg[b * bs:(b + 1) * bs], ts[b * bs:(b + 1) * bs],
+                    eidx[b * bs:(b + 1) * bs]) for b in range(b0, b0 + cpu_nb)]
+        extra = dict(src=src, dst=dst, eidx=eidx, ts=ts)
+        if F != 1:
+            extra["efeat"] = tgn.edge_raw_features.cpu().numpy()
+        cpu = cpu_baseline(wl, snap, weights, time_w, batches, extra, n_threads)
 
     value = edges / dt
     out = {
@@ -352,7 +426,9 @@ def main():
         "roofline": roof,
         "roofline_throughput_kernel": roof2,
         "cpu_baseline": cpu,
+        "row_fill": fill,
         "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
+                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + af["gru"] + af["scorer"],
                         "hbm_gbs_at_value": ab["total"] * value / 1e9,
                         "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
                         "mfma_tflops_at_value": af["total"] * value / 1e12,

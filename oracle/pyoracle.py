@@ -115,6 +115,24 @@ class TpprOracle:
         on, oe, od, ow = self._stream(source_nodes, timestamps, edge_idxs, 3, True, int(tppr_id))
         return on[0], oe[0], od[0], ow[0]
 
+    def streaming_topk_threads(self, source_nodes, timestamps, edge_idxs):
+        """The same with one host thread per T-PPR model (the models are independent; inside a model the
+        reference's loop is sequential).  bench.py's N-thread P1 variant; N = n_tppr."""
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(self.n_tppr) as ex:
+            res = list(ex.map(lambda m: self._stream(source_nodes, timestamps, edge_idxs, 3, True, m),
+                              range(self.n_tppr)))
+        return tuple([r[q][0] for r in res] for q in range(4))
+
+    def import_rows(self, m, ids, st):
+        ids = _c(ids, np.int64)
+        rc = lib().zo_tppr_import_rows(self._h, C.c_int32(m), _p(ids), C.c_int64(len(ids)), _p(_c(st["len"], np.int32)),
+                                       _p(_c(st["norm"], np.float64)), _p(_c(st["eidx"], np.int64)),
+                                       _p(_c(st["node"], np.int64)), _p(_c(st["ts"], np.float64)),
+                                       _p(_c(st["w"], np.float64)))
+        if rc != 0:
+            raise IndexError("zo_tppr_import_rows rc=%d" % rc)
+
     def update_only(self, sources, targets, timestamps, edge_idxs):
         nodes = np.concatenate([_c(sources, np.int32), _c(targets, np.int32)])
         self._stream(nodes, timestamps, edge_idxs, 2, False, -1)
@@ -295,8 +313,9 @@ class ProtocolOracle:
                 o.append(x)
         return outs
 
-    def batch(self, src, dst, neg, ts, eidx, train):
-        """-> (embeddings [3B, D*(M+1)], probabilities [2B])."""
+    def batch(self, src, dst, neg, ts, eidx, train, topk_out=None):
+        """-> (embeddings [3B, D*(M+1)], probabilities [2B]).  ``topk_out``: this batch's T-PPR query if the
+        caller has run (and timed) it already."""
         mem, B = self.mem, len(src)
         nodes = np.concatenate([src, dst, neg]).astype(np.int32)
         positives = np.unique(np.concatenate([src, dst]))
@@ -305,7 +324,7 @@ class ProtocolOracle:
         elif not self.test_mode:
             mem.gru_update(self.gru, None, n_threads=self.n_threads)          # update_memory_in_test (:142-146)
             self.test_mode = True
-        on, oe, od, ow = self.topk(nodes, ts, eidx)
+        on, oe, od, ow = topk_out if topk_out is not None else self.topk(nodes, ts, eidx)
         table = mem.memory
         if train:                                                            # get_updated_memory(memory, index)
             index = np.unique(np.concatenate([a.ravel() for a in on]))

@@ -160,6 +160,27 @@ void zo_tppr_export(const zo_tppr *h, int32_t m, int32_t *len, double *norm,
     memcpy(w, h->w + off * h->k, h->N * h->k * sizeof(double));
 }
 
+/* inverse of the export for n chosen nodes (arrays [n], [n][k]); other rows stay.  Used to start the
+ * timed CPU baseline from the same warm state as the GPU run (bench.py). */
+int zo_tppr_import_rows(zo_tppr *h, int32_t m, const int64_t *ids, int64_t n, const int32_t *len,
+                        const double *norm, const int64_t *eidx, const int64_t *node, const double *ts,
+                        const double *w)
+{
+    if (m < 0 || m >= h->M) return -2;
+    const size_t k = (size_t)h->k;
+    for (int64_t q = 0; q < n; ++q) {
+        if (ids[q] < 0 || ids[q] >= h->N || len[q] < 0 || len[q] > h->k) return -1;
+        size_t row = (size_t)m * (size_t)h->N + (size_t)ids[q];
+        h->len[row] = len[q];
+        h->norm[row] = norm[q];
+        memcpy(h->eidx + row * k, eidx + (size_t)q * k, k * sizeof(int64_t));
+        memcpy(h->node + row * k, node + (size_t)q * k, k * sizeof(int64_t));
+        memcpy(h->ts + row * k, ts + (size_t)q * k, k * sizeof(double));
+        memcpy(h->w + row * k, w + (size_t)q * k, k * sizeof(double));
+    }
+    return 0;
+}
+
 /* extract_streaming_tppr (utils/util.py:447-469).  Empty dict: the reference
  * leaves the zero-initialised row alone; here the row is written as zeros. */
 static void emit_row(const zo_tppr *h, int32_t m, int64_t v, double t_now,

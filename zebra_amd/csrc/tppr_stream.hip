@@ -891,9 +891,12 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     STAMP(1);
     WL(0, 7); WL(3, wall_clock64() >> 7); WL(6, wl_fail | (hub_by_mail ? 256 : 0)); if (wl_fail & 14) WL(7, wl_seen);
     // ---- all reads done: later writers of these rows may go ahead ----
-    // release: the row loads above must have returned before a later writer may see the flag (the loads
-    // of a negative sample's row are not consumed until emission, so nothing else orders them)
-    __hip_atomic_store(done + i, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // every lane, same word (no lane-0 branch, see the dequeue)
+    // The row loads above must have RETURNED before a later writer may see the flag (the row of a negative
+    // sample is not consumed until emission, so nothing else orders its loads): drain vmcnt explicitly.  A
+    // release store at agent scope would do it too, but it also writes the XCD's L2 back (buffer_wbl2) on
+    // every hop; the rows themselves travel as write-through sc1 granules and need no such flush.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
 
     // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
     // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
