@@ -197,8 +197,8 @@ def test_pruning_vs_oracle_superuser_shape(zt, oracle):
                                                                  (np.int32, np.int32, np.float32, np.float32)])
 
 
-@pytest.mark.parametrize("n,k", [(16, 5), (17, 5), (31, 20), (41, 20), (41, 40), (64, 20), (65, 31), (81, 40),
-                                 (100, 50), (127, 63), (128, 20)])
+@pytest.mark.parametrize("n,k", [(16, 5), (17, 5), (31, 20), (41, 20), (41, 40), (63, 31), (64, 20), (65, 31), (81, 40),
+                                 (100, 50), (127, 63), (128, 20), (11, 5), (21, 10)])
 def test_exact_topk_selection_paths(zt, oracle, n, k):
     """The top-k prune must reproduce np.argsort(values)[-k:] under numba's
     quicksort for any tie pattern.  Every path (rank fast path, wave-parallel
@@ -226,8 +226,10 @@ def test_exact_topk_selection_paths(zt, oracle, n, k):
             vals[c] = 1.0                                                   # all equal
     want = np.stack([oracle.numba_argsort(v)[-k:] for v in vals])
     dv = torch.from_numpy(vals).cuda()
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 5, 6):
         if mode in (3, 4) and n > 64:
+            continue
+        if mode in (5, 6) and (n > 63 or k > 31):
             continue
         sel = torch.full((cases, k), -1, dtype=torch.int32, device="cuda")
         path = torch.full((cases,), -1, dtype=torch.int32, device="cuda")

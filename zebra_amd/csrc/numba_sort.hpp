@@ -347,6 +347,36 @@ __device__ inline bool topk_rank_reg(double v, int n, int k, int *sel, int *lt_o
     return ok;
 }
 
+// ---- cross-lane helpers of the register-resident merge ---------------------------------------------
+// push: lane i's value goes to lane dest_i (ds_permute_b32; lanes nobody writes read 0, of several
+// writers the highest lane wins).  Every lane must be active.
+__device__ __forceinline__ int push_i32(int v, int dest) { return __builtin_amdgcn_ds_permute(dest << 2, v); }
+__device__ __forceinline__ u64 push_u64(u64 v, int dest)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_permute(dest << 2, (int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_permute(dest << 2, (int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ double push_f64(double v, int dest)
+{
+    return __longlong_as_double((long long)push_u64((u64)__double_as_longlong(v), dest));
+}
+
+// OR of x over the wave (uniform result): inclusive prefix OR inside each row of 16 by DPP shifts
+// (OR is idempotent, overlaps do not matter), then the row totals are chained with the two row
+// broadcasts; lane 63 holds the total.
+__device__ __forceinline__ unsigned wave_or(unsigned x)
+{
+    int v = (int)x;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1 and 3
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int mbcnt64(u64 m)      // bits of m below this lane
 {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -362,21 +392,29 @@ __device__ __forceinline__ int mbcnt64(u64 m)      // bits of m below this lane
 // partitioned nor ordered (partitions of disjoint ranges are independent).  Finished segments
 // (< 16 entries) get the stable rank = insertion sort with strict <.  Writes sel[0..k).
 // ---------------------------------------------------------------------------
-__device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S)
+// sel != nullptr: writes sel[0..k).  sel == nullptr: returns in *f_out the final position of the candidate
+// *c_out this lane ends up holding (or -1 if that position is below the cut / not resolved).
+__device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S, int *f_out = nullptr, int *c_out = nullptr,
+                                     int cand_id = -1)
 {
+    // Everything about the segment being partitioned (lo, hi, the pivot, the stack of pending segments) is
+    // wave-uniform; readfirstlane pins those values to scalar registers so that the bookkeeping runs on the
+    // scalar unit and only the per-position work (keys, stop ranks, the permutation) on the vector unit.
+#define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
     const int p = lane_id();
-    const int drop = n - k;
-    int e = (lt << 8) | p;
+    const int drop = ZT_U(n - k);
+    int e = (lt << 8) | (cand_id >= 0 ? cand_id : p);   // (rank, candidate); the candidate defaults to the position
     int mylo = p, myhi = p - 1;                     // finished segment holding position p (empty: none)
-    u64 pending = 0ull;                             // segments still to partition, 16 bits each
+    unsigned pend_lo = 0u, pend_hi = 0u;            // stack of segments still to partition, 16 bits each
     int depth = 0;
-    int lo = 0, hi = n - 1;
+    int lo = 0, hi = ZT_U(n - 1);
     bool work = true;
     if (hi - lo < 15) {
         if (p <= hi) { mylo = lo; myhi = hi; }
         work = false;
     }
     while (work) {
+        lo = ZT_U(lo); hi = ZT_U(hi);
         // ---- median of three (uniform values, scalar unit) ----
         const int mid = (lo + hi) >> 1;
         int el = __builtin_amdgcn_readlane(e, lo), em = __builtin_amdgcn_readlane(e, mid),
@@ -387,29 +425,42 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S)
         const int pk = em >> 8;
         e = (p == lo ? el : e);
         e = (p == mid ? eh : e);
-        e = (p == hi ? em : e);  // pivot stashed at `hi`
+        e = (p == hi ? em : e);                     // pivot stashed at `hi`
         // ---- stops of the two scans over lo .. hi-1 ----
         const int key = e >> 8;
-        const bool in = p >= lo && p < hi;
-        const bool ge = in && key >= pk, le = in && key <= pk;
-        const u64 GE = __ballot(ge), LE = __ballot(le);
-        const int nI = __popcll(GE), nJ = __popcll(LE);
-        const int mi = mbcnt64(GE), mj = nJ - 1 - mbcnt64(LE);
-        if (ge) S.ilist[mi] = p;                    // i-stops ascending, j-stops descending
-        if (le) S.jlist[mj] = p;
-        wave_sync();
-        int src = p;
-        bool swi = false, swj = false;
-        if (ge && mi < nJ) { const int q = S.jlist[mi]; if (p < q) { src = q; swi = true; } }
-        if (le && mj < nI) { const int q = S.ilist[mj]; if (q < p) { src = q; swj = true; } }
+        const u64 seg = (((1ull << hi) - 1ull) >> lo) << lo;          // bits lo .. hi-1 (hi <= 62)
+        const u64 GE = __ballot(key >= pk) & seg, LE = __ballot(key <= pk) & seg;
+        const bool ge = (GE >> p) & 1ull, le = (LE >> p) & 1ull;
+        // Hoare's scans swap the m-th i-stop (ascending) with the m-th j-stop (descending) while the former lies
+        // to the left.  Number of swaps: with a(x) = i-stops at positions <= x and b(x) = j-stops at positions
+        // > x, pair m swaps iff some x has a(x) > m and b(x) > m, so S = max_x min(a(x), b(x)); a rises and b
+        // falls with x, so the maximum sits at the first position where a >= b, or just before it.
+        const int nJ = __popcll(LE);
+        const int mi = mbcnt64(GE), lb = mbcnt64(LE);                  // stops strictly below this position
+        const int a_p = mi + (ge ? 1 : 0), b_p = nJ - lb - (le ? 1 : 0);
+        const u64 C = __ballot(((seg >> p) & 1ull) && a_p >= b_p);     // never empty: b(hi-1) = 0
+        const int px = ZT_U(__ffsll((long long)C) - 1);
+        const u64 below_px = (1ull << px) - 1ull;
+        const int a_prev = __popcll(GE & below_px), b_at = __popcll(LE & ~below_px & ~(1ull << px));
+        const int Sw = ZT_U(a_prev > b_at ? a_prev : b_at);            // swaps of this partition
+        // The swapped i-stops are the Sw lowest, the swapped j-stops the Sw highest, and every swapped i-stop
+        // lies left of every swapped j-stop: the swaps REVERSE the sequence of elements at these 2*Sw
+        // positions.  Element number t of that sequence goes to compact lane 2*Sw-1-t (push), then position
+        // number t fetches compact lane t (pull): two register permutes, no lists in LDS.
+        const int mj = nJ - 1 - lb;                                    // rank among the j-stops, from the top
+        const bool swi = ge && mi < Sw, swj = le && mj < Sw;
+        const int t = swi ? mi : 2 * Sw - 1 - mj;
+        const int staged = push_i32(e, (swi || swj) ? 2 * Sw - 1 - t : 63);
+        const int got = __shfl(staged, (swi || swj) ? t : p);
         // where the i-scan ends: the first i-stop that did not swap, or the lowest swapped j-stop
         // (it received a >= pivot value), or `hi`
-        const u64 stay = __ballot(ge && !swi), sj = __ballot(swj);
+        const u64 stay = GE & ~__ballot(swi), sj = __ballot(swj);
         int ifin = stay ? __ffsll((long long)stay) - 1 : hi;
         if (sj) { const int jl = __ffsll((long long)sj) - 1; ifin = jl < ifin ? jl : ifin; }
-        e = __shfl(e, src);                         // all pair swaps at once
+        ifin = ZT_U(ifin);
+        e = (swi || swj) ? got : e;                 // all pair swaps at once
         const int x = __builtin_amdgcn_readlane(e, ifin);
-        e = (p == ifin ? em : e);    // pivot <-> ifin
+        e = (p == ifin ? em : e);                   // pivot <-> ifin
         e = (p == hi ? x : e);
         if (p == ifin) { mylo = p; myhi = p; }
         // ---- children: only those reaching the kept ranks matter ----
@@ -419,17 +470,24 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S)
         if (lneed && !lpart && p >= lo && p <= lhi) { mylo = lo; myhi = lhi; }
         if (rneed && !rpart && p >= rlo && p <= hi) { mylo = rlo; myhi = hi; }
         if (lpart) {
-            if (rpart) { pending = (pending << 16) | (u64)(unsigned)(rlo | (hi << 8)); ++depth; }
+            if (rpart) {                            // push the right child
+                pend_hi = (pend_hi << 16) | (pend_lo >> 16);
+                pend_lo = (pend_lo << 16) | (unsigned)(rlo | (hi << 8));
+                ++depth;
+            }
             hi = lhi;
         } else if (rpart) {
             lo = rlo;
         } else if (depth > 0) {
-            lo = (int)(pending & 0xffull); hi = (int)((pending >> 8) & 0xffull);
-            pending >>= 16; --depth;
+            lo = (int)(pend_lo & 0xffu); hi = (int)((pend_lo >> 8) & 0xffu);
+            pend_lo = (pend_lo >> 16) | (pend_hi << 16);
+            pend_hi >>= 16;
+            --depth;
         } else {
             work = false;
         }
     }
+#undef ZT_U
     // ---- stable rank inside every finished segment that reaches the cut ----
     if (p < n) S.r[p] = (e & ~0xff) | p;            // (rank, current position)
     wave_sync();
@@ -444,9 +502,57 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S)
             for (int t = 0; t < 8; ++t) rank += ((q0 + t) <= myhi && x[t] < cp) ? 1 : 0;
         }
         const int f = mylo + rank;
-        if (f >= drop) sel[f - drop] = e & 0xff;
+        if (sel != nullptr) { if (f >= drop) sel[f - drop] = e & 0xff; }
+        else *f_out = f >= drop ? f : -1;
+    } else if (sel == nullptr) {
+        *f_out = -1;
     }
+    if (sel == nullptr) *c_out = e & 0xff;
     wave_sync();
+}
+
+// Top-k of n <= 63 candidates held one per lane, not necessarily in adjacent lanes: `live` (uniform) marks the
+// lanes that hold a candidate, `pos` is this lane's place in the candidate LIST (the reference's dictionary
+// order, 0..n-1; the quicksort replay depends on it), v its value (no NaN); n = popcount(live) > k, k <= 31.
+// Returns in *out_slot the slot [0, k) this lane's candidate takes in np.argsort(values)[-k:], or -1 if it is
+// dropped.  No LDS on the tie-free path.  Returns the path taken (0 ranks, 4 quicksort replay).
+__device__ inline int topk_reg(double v, u64 live, int pos, int n, int k, SortLds &S, int *out_slot)
+{
+    const int lane = lane_id();
+    const int drop = n - k;
+    const bool mine = (live >> lane) & 1ull;
+    const double vc = mine ? v : __longlong_as_double(0x7ff0000000000000ll);    // dead lanes: +inf, never smaller
+    int l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+#pragma unroll
+    for (int q0 = 0; q0 < WAVE; q0 += 8) {
+        if (((live >> q0) & 0xffull) == 0ull) continue;                         // uniform: a scalar branch
+        l0 += (readlane_f64(vc, q0 + 0) < vc) ? 1 : 0;
+        l1 += (readlane_f64(vc, q0 + 1) < vc) ? 1 : 0;
+        l2 += (readlane_f64(vc, q0 + 2) < vc) ? 1 : 0;
+        l3 += (readlane_f64(vc, q0 + 3) < vc) ? 1 : 0;
+        l0 += (readlane_f64(vc, q0 + 4) < vc) ? 1 : 0;
+        l1 += (readlane_f64(vc, q0 + 5) < vc) ? 1 : 0;
+        l2 += (readlane_f64(vc, q0 + 6) < vc) ? 1 : 0;
+        l3 += (readlane_f64(vc, q0 + 7) < vc) ? 1 : 0;
+    }
+    const int lt = (l0 + l1) + (l2 + l3);
+    const bool keep = mine && lt >= drop;
+    // tie-free among the kept <=> exactly k lanes are kept and their ranks cover [drop, n) (equal values
+    // have equal counts, so a tie leaves a rank unclaimed)
+    const unsigned claimed = wave_or(keep ? 1u << (lt - drop) : 0u);
+    if (__popcll(__ballot(keep)) == k && claimed == (1u << k) - 1u) {
+        *out_slot = keep ? lt - drop : -1;
+        return 0;
+    }
+    // ties decide: bring (rank, lane) into list order (lane p = position p) and replay the quicksort
+    const int e_at_pos = push_i32(mine ? ((lt << 8) | lane) : 0, mine ? pos : 63);
+    int f, c;
+    topk_ties_reg(e_at_pos >> 8, n, k, nullptr, S, &f, &c, e_at_pos & 0xff);
+    // lane p holds the candidate of lane c at final position f: tell lane c its slot
+    const bool kept = lane < n && f >= drop;
+    const int got = push_i32(kept ? f - drop + 1 : 0, kept ? c : 63);
+    *out_slot = (mine && lane != 63) ? got - 1 : -1;
+    return 4;
 }
 
 // Wave-cooperative top-k selection.  On return sel[0..k) holds the indices of

@@ -16,7 +16,7 @@ struct HookLds {
 
 // one wavefront per case; mode 0 = production dispatch (fast / wave / seq),
 // 1 = force the wave-parallel exact sort (LDS), 2 = force the sequential replay,
-// 3 = force the register-resident replay (n <= 64)
+// 3 = force the register-resident replay (n <= 64), 4 = the replay on ranks, 5 / 6 = topk_reg, candidates adjacent / split over the two wave halves (n <= 63, k <= 31)
 __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ vals, int n, int k, int cases, int mode,
                                                   int *sel_out, int *path_out)
 {
@@ -36,6 +36,16 @@ __global__ __launch_bounds__(64) void k_test_topk(const double *__restrict__ val
         (void)topk_rank_reg(v, n, k, L.sel, &lt);
         topk_ties_reg(lt, n, k, L.sel, L.sort);
         path = 4;
+    } else if (mode == 5 || mode == 6) {          // the register-resident selection of merge_pair_reg:
+        // 5 = candidates in lanes [0, n); 6 = split like the merge: the first half in lanes [0, n1), the rest from lane 32
+        const int n1 = mode == 5 ? n : (n + 1) / 2;
+        const int pos = lane < n1 ? lane : (mode == 6 && lane >= 32 && lane - 32 < n - n1 ? n1 + lane - 32 : -1);
+        const u64 live = __ballot(pos >= 0);
+        const double v = pos >= 0 ? L.a[pos] : 0.0;
+        int slot;
+        path = topk_reg(v, live, pos, n, k, L.sort, &slot);
+        if (slot >= 0) L.sel[slot] = pos;
+        wave_sync();
     } else if (mode == 3) {
         numba_argsort_reg(L.a, n, L.sort);
         if (lane < k) L.sel[lane] = L.sort.r2[n - k + lane];
@@ -65,7 +75,7 @@ extern "C" int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_
                             int32_t *sel_out_dev, int32_t *path_out_dev, void *stream)
 {
     if (!vals_dev || !sel_out_dev || !path_out_dev || n < 2 || k < 1 || k >= n || k > 64 || cases < 1 || n > 1536 ||
-        (mode == 1 && n > 128) || ((mode == 3 || mode == 4) && n > 64)) {
+        (mode == 1 && n > 128) || ((mode == 3 || mode == 4) && n > 64) || ((mode == 5 || mode == 6) && (n > 63 || k > 31))) {
         set_error("zt_test_topk: bad argument");
         return ZT_ERR_ARG;
     }

@@ -646,6 +646,178 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     return k;
 }
 
+// A merged dictionary as merge_pair_reg leaves it: this lane's candidate (if any) and the slot [0, n_new)
+// it takes in the new dictionary (-1: dropped / no candidate).  The new row is never brought into lane
+// order: mailbox and row stores scatter straight from the candidate lanes.
+struct Cand {
+    u64 key;
+    double ts, w;
+    int slot;
+};
+
+// The same pair update with the candidate list held in REGISTERS, for k <= 31: s1's entries stay in lanes
+// [0, n1), s2's entries move to lanes 32 + j with ONE v_permlane32_swap per register (no LDS), the new key
+// sits behind them.  The top-k works on these register values (topk_reg: ranks by lane broadcasts, tie
+// test by a DPP OR-reduction, quicksort replay on the compacted ranks only when ties decide).  Compared
+// with merge_pair the candidate list, the selection vector and the gathered result never touch LDS.
+__device__ inline int merge_pair_reg(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
+                                     const Row &r2, u64 newkey, double newts, Cand &out, int pre = 0,
+                                     int g_stamp_i = -1)
+{
+    STAMP2(0);
+    int n1;
+    double scale_s1 = 0.0, scale_s2;
+    if (r1.norm == 0.0) {                       // :514-519
+        n1 = 0;
+        scale_s2 = 1.0 - alpha;
+    } else {                                    // :520-527
+        n1 = __builtin_amdgcn_readfirstlane(r1.len);        // row headers are wave-uniform: say so
+        const double new_norm = r1.norm * beta + beta;
+        scale_s1 = r1.norm / new_norm * beta;
+        scale_s2 = beta / new_norm * (1.0 - alpha);
+    }
+    const bool in1 = lane < n1;
+    double w1 = r1.w * scale_s1;                // t_s1_PPR[key] = value * scale_s1
+    const int len2 = __builtin_amdgcn_readfirstlane((r2.norm != 0.0) ? r2.len : 0);   // :530-538
+    const bool in2 = lane < len2;
+    const double add = r2.w * scale_s2;
+    u64 m2mask = 0ull;                          // lanes of s2 whose key is already in s1
+    if (n1 > 0 && len2 > 0) {
+        // hash matching as in merge_pair; which of s2's lanes were hit is collected from the (rare)
+        // hitting lanes by scalar reads instead of a flag array in LDS
+        int *T = L.htab;
+        const int h1 = key_hash(r1.key), h2 = key_hash(r2.key);
+        bool clash = pre == 2;
+        if (pre == 0) {
+            if (in2) T[h2] = lane;
+            wave_sync();
+            const int back = in2 ? T[h2] : lane;
+            clash = __ballot(in2 && back != lane) != 0ull;
+            if (clash && in2 && back == lane) T[h2] = -1;       // the slot's last writer clears it
+        }
+        if (!clash) {
+            const int cand = in1 ? T[h1] : -1;
+            if (in2) T[h2] = -1;
+            if (__ballot(cand >= 0) != 0ull) {                  // mostly no slot is even occupied
+                const int src = cand >= 0 ? cand : 0;
+                const u64 kj = __shfl(r2.key, src);
+                const double tj = __shfl(r2.ts, src), aj = __shfl(add, src);
+                const bool hit = in1 && cand >= 0 && kj == r1.key && tj == r1.ts;
+                if (hit) w1 = w1 + aj;                          // t_s1_PPR[key] += value * scale_s2
+                u64 hm = __ballot(hit);
+                while (hm) {
+                    const int l = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1ull;
+                    m2mask |= 1ull << __builtin_amdgcn_readlane(cand, l);
+                }
+            }
+        } else {
+            // slot collision: all pairs through LDS (merge_pair's fallback), results back into registers
+            int *m1 = L.sel, *m2 = L.sort.r;
+            wave_sync();
+            if (in1) { L.key[lane] = r1.key; L.ts[lane] = r1.ts; }
+            if (in2) { L.key[WAVE + lane] = r2.key; L.ts[WAVE + lane] = r2.ts; L.w[WAVE + lane] = add; }
+            m1[lane] = -1;
+            m2[lane] = 0;
+            wave_sync();
+            const int S = n1 <= 16 ? 4 : (n1 <= 21 ? 3 : (n1 <= 32 ? 2 : 1));
+            const int c = (lane >= n1 ? 1 : 0) + (lane >= 2 * n1 ? 1 : 0) + (lane >= 3 * n1 ? 1 : 0);
+            const int i = lane - c * n1;
+            if (c < S && i < n1) {
+                const u64 ki = L.key[i];
+                const double ti = L.ts[i];
+                int jm = -1;
+                for (int j0 = c; j0 < len2; j0 += 8 * S) {
+                    u64 kj[8];
+                    double tj[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int j = j0 + t * S, jj = j < len2 ? j : len2 - 1;
+                        kj[t] = L.key[WAVE + jj]; tj[t] = L.ts[WAVE + jj];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int j = j0 + t * S;
+                        if (j < len2 && kj[t] == ki && tj[t] == ti) jm = j;
+                    }
+                }
+                if (jm >= 0) { m1[i] = jm; m2[jm] = 1; L.sort.v[i] = L.w[WAVE + jm]; }
+            }
+            wave_sync();
+            if (in1 && m1[lane] >= 0) w1 = w1 + L.sort.v[lane];
+            m2mask = __ballot(in2 && m2[lane] != 0);
+            wave_sync();
+        }
+    }
+    if (pre == 1 && !(n1 > 0 && len2 > 0) && lane < r2.len) L.htab[key_hash(r2.key)] = -1;   // (cannot happen on a chain)
+    const bool un2 = in2 && ((m2mask >> lane) & 1ull) == 0ull;    // appended after s1's entries, in s2's order
+    const u64 um = __ballot(un2);                                  // bits < 32
+    int n = n1 + __popcll(um);
+    // new key (edge_idx, s2, ts): overwrite if present, else append last (:531 / :540-541)
+    const double v = (alpha != 0.0) ? scale_s2 * alpha : scale_s2;
+    const bool h1 = in1 && r1.key == newkey && r1.ts == newts;
+    const bool h2 = un2 && r2.key == newkey && r2.ts == newts;
+    const bool present = __ballot(h1 || h2) != 0ull;
+    if (h1) w1 = v;
+    const double w2 = h2 ? v : add;
+    STAMP2(1);
+    // candidates: lanes [0, n1) s1's entries, lanes 32 + j s2's unmatched entries, lane 32 + len2 the new key.
+    // v_permlane32_swap(a, b) exchanges a[32..63] with b[0..31]: the first result is [a's low half | b's low half].
+    u64 ck;
+    double ct, cw;
+    {
+        const unsigned a0 = (unsigned)r1.key, a1 = (unsigned)(r1.key >> 32), b0 = (unsigned)r2.key, b1 = (unsigned)(r2.key >> 32);
+        const u64 ta = (u64)__double_as_longlong(r1.ts), tb = (u64)__double_as_longlong(r2.ts);
+        const u64 wa = (u64)__double_as_longlong(w1), wb = (u64)__double_as_longlong(w2);
+#define ZT_SWAP(x, y) ((unsigned)__builtin_amdgcn_permlane32_swap((x), (y), false, false)[0])
+        ck = ((u64)ZT_SWAP(a1, b1) << 32) | ZT_SWAP(a0, b0);
+        ct = __longlong_as_double((long long)(((u64)ZT_SWAP((unsigned)(ta >> 32), (unsigned)(tb >> 32)) << 32) | ZT_SWAP((unsigned)ta, (unsigned)tb)));
+        cw = __longlong_as_double((long long)(((u64)ZT_SWAP((unsigned)(wa >> 32), (unsigned)(wb >> 32)) << 32) | ZT_SWAP((unsigned)wa, (unsigned)wb)));
+#undef ZT_SWAP
+    }
+    u64 live = (n1 > 0 ? ((1ull << n1) - 1ull) : 0ull) | (um << 32);
+    int pos = lane < 32 ? lane : n1 + __popcll((um << 32) & lanemask_lt());     // place in the reference's dictionary order
+    if (!present) {
+        const int nl = 32 + len2;                                               // <= 63 (len2 <= k <= 31)
+        if (lane == nl) { ck = newkey; ct = newts; cw = v; pos = n; }
+        live |= 1ull << nl;
+        ++n;
+    }
+    out.key = ck; out.ts = ct; out.w = cw;
+    STAMP2(2);
+    STAMP2(3);
+    live = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(live >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)live);
+    n = __builtin_amdgcn_readfirstlane(n);
+    const bool mine = (live >> lane) & 1ull;
+    if (n <= k) {                               // :549-551
+        out.slot = mine ? pos : -1;
+        return n;
+    }
+    if (__ballot(mine && cw != cw) != 0ull) {
+        // a NaN weight (only ever from imported state): numba's lt() orders NaNs by the quicksort's
+        // dynamics -> the general selection over LDS, on the compacted list
+        if (mine) { L.key[pos] = ck; L.ts[pos] = ct; L.w[pos] = cw; }
+        wave_sync();
+        (void)topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);
+        out.slot = -1;
+        if (lane < k) {
+            const int c = L.sel[lane];
+            out.key = L.key[c]; out.ts = L.ts[c]; out.w = L.w[c]; out.slot = lane;
+        }
+        wave_sync();
+        return k;
+    }
+    const int tk_path = topk_reg(cw, live, pos, n, k, L.sort, &out.slot);    // :553-559
+#ifdef ZT_STAMP
+    if (lane == 0) atomicAdd(&g_paths[tk_path & 7], 1);
+#endif
+    (void)tk_path;
+    STAMP2(4);
+    STAMP2(5);
+    return k;
+}
+
 // Write a whole row (all k entries, zeros beyond n) with one tag.
 __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, int lane, int n, u64 key, double ts,
                                           double w, double new_norm, unsigned tag)
@@ -664,6 +836,35 @@ __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, 
         st_agent(e + 3 * k, granule(tag, (unsigned)(tt >> 32)));
         st_agent(e + 4 * k, granule(tag, (unsigned)ww));
         st_agent(e + 5 * k, granule(tag, (unsigned)(ww >> 32)));
+    }
+    if (lane < 3) {
+        const u64 nn = (u64)__double_as_longlong(new_norm);
+        const unsigned pay = lane == 0 ? (unsigned)n : (lane == 1 ? (unsigned)nn : (unsigned)(nn >> 32));
+        st_agent(base + lane, granule(tag, pay));
+    }
+}
+
+// The same from a Cand (merge_pair_reg): every candidate lane writes its own entry into its slot; slots
+// [n, k) are zeroed by lanes n..k-1.
+__device__ __forceinline__ void store_row_scatter(const zt_tppr &h, int m, long long x, int lane, int n, const Cand &c,
+                                                  double new_norm, unsigned tag)
+{
+    u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
+    const int k = h.k;
+    if (c.slot >= 0) {
+        const u64 tt = (u64)__double_as_longlong(c.ts), ww = (u64)__double_as_longlong(c.w);
+        u64 *e = base + HDR + c.slot;
+        st_agent(e, granule(tag, (unsigned)c.key));
+        st_agent(e + k, granule(tag, (unsigned)(c.key >> 32)));
+        st_agent(e + 2 * k, granule(tag, (unsigned)tt));
+        st_agent(e + 3 * k, granule(tag, (unsigned)(tt >> 32)));
+        st_agent(e + 4 * k, granule(tag, (unsigned)ww));
+        st_agent(e + 5 * k, granule(tag, (unsigned)(ww >> 32)));
+    }
+    if (lane >= n && lane < k) {
+        u64 *e = base + HDR + lane;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) st_agent(e + q * k, granule(tag, 0u));
     }
     if (lane < 3) {
         const u64 nn = (u64)__double_as_longlong(new_norm);
@@ -905,34 +1106,32 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         const Row &r1 = sw ? rv : ru, &r2 = sw ? ru : rv;
         const long long x1 = sw ? v : u, x2 = sw ? u : v;
         const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
-        u64 nk = 0;
-        double nt = 0, nw = 0;
         // (edge_idx, s2, ts) is the key entering s1's dictionary
-        int n = merge_pair(L, lane, k, alpha, beta, r1, r2, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2, tnow, nk,
-                           nt, nw, pre_hash, mo == 0 ? i : -1);
-        if (mail != nullptr && x1 == hub) {     // mailbox first: the chain's next edge is spinning on it
-            mail->key[lane] = nk; mail->ts[lane] = nt; mail->w[lane] = nw;
-            if (lane == 0) { mail->len = n; mail->norm = r1.norm * beta + beta; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) __hip_atomic_store(&mail->tag, tag_base | (unsigned)(o1 + 1), __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (hub_to_memory || x1 != hub)
-            store_row(h, m, x1, lane, n, nk, nt, nw, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
+        const bool reg_path = k <= 31;          // 2k+1 candidates fit one wavefront: register-resident merge
+        Cand c;
+        auto merge = [&](const Row &a, const Row &b, long long xb, int pre, int stamp) {
+            const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)xb;
+            if (reg_path) return merge_pair_reg(L, lane, k, alpha, beta, a, b, nkey, tnow, c, pre, stamp);
+            const int n = merge_pair(L, lane, k, alpha, beta, a, b, nkey, tnow, c.key, c.ts, c.w, pre, stamp);
+            c.slot = lane < n ? lane : -1;
+            return n;
+        };
+        auto publish = [&](long long x, int n, double new_norm, unsigned tag) {
+            if (mail != nullptr && x == hub) {  // mailbox first: the chain's next edge is spinning on it
+                if (c.slot >= 0) { mail->key[c.slot] = c.key; mail->ts[c.slot] = c.ts; mail->w[c.slot] = c.w; }
+                if (lane == 0) { mail->len = n; mail->norm = new_norm; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&mail->tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (hub_to_memory || x != hub) store_row_scatter(h, m, x, lane, n, c, new_norm, tag);
+        };
+        int n = merge(r1, r2, x2, pre_hash, mo == 0 ? i : -1);
+        publish(x1, n, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
         STAMP(2);
         WL(0, 8);
         if (u != v) {
-            n = merge_pair(L, lane, k, alpha, beta, r2, r1, ((u64)(unsigned)e << 32) | (u64)(unsigned)x1, tnow, nk,
-                           nt, nw);
-            if (mail != nullptr && x2 == hub) {
-                mail->key[lane] = nk; mail->ts[lane] = nt; mail->w[lane] = nw;
-                if (lane == 0) { mail->len = n; mail->norm = r2.norm * beta + beta; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&mail->tag, tag_base | (unsigned)(o2 + 1), __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (hub_to_memory || x2 != hub)
-                store_row(h, m, x2, lane, n, nk, nt, nw, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
+            n = merge(r2, r1, x1, 0, -1);
+            publish(x2, n, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
         }
     }
 
