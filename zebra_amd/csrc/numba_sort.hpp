@@ -511,12 +511,15 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S,
     wave_sync();
 }
 
-// Top-k of n <= 63 candidates held one per lane, not necessarily in adjacent lanes: `live` (uniform) marks the
-// lanes that hold a candidate, `pos` is this lane's place in the candidate LIST (the reference's dictionary
-// order, 0..n-1; the quicksort replay depends on it), v its value (no NaN); n = popcount(live) > k, k <= 31.
-// Returns in *out_slot the slot [0, k) this lane's candidate takes in np.argsort(values)[-k:], or -1 if it is
-// dropped.  No LDS on the tie-free path.  Returns the path taken (0 ranks, 4 quicksort replay).
-__device__ inline int topk_reg(double v, u64 live, int pos, int n, int k, SortLds &S, int *out_slot)
+// Top-k of n <= 63 candidates held one per lane, not necessarily in adjacent lanes, in two steps so that a
+// caller can act on the kept SET before the ORDER is known (hub chains, tppr_stream.hip).
+//
+// rank_pass: `live` (uniform) marks the lanes that hold a candidate, v the value (no NaN), n = popcount(live)
+// > k, k <= 31.  *lt = number of strictly smaller candidates, *keep = this lane's candidate is certainly
+// kept.  Returns 1 if no tie reaches the kept ranks (slot = lt - drop is the answer), 2 if ties decide the
+// ORDER but the kept set is known (exactly k lanes have *keep), 3 if a tie group straddles the cut (the set
+// itself follows from the quicksort's dynamics).  No LDS.
+__device__ inline int rank_pass(double v, u64 live, int n, int k, int *lt_out, bool *keep_out)
 {
     const int lane = lane_id();
     const int drop = n - k;
@@ -537,21 +540,44 @@ __device__ inline int topk_reg(double v, u64 live, int pos, int n, int k, SortLd
     }
     const int lt = (l0 + l1) + (l2 + l3);
     const bool keep = mine && lt >= drop;
+    *lt_out = lt;
+    *keep_out = keep;
     // tie-free among the kept <=> exactly k lanes are kept and their ranks cover [drop, n) (equal values
     // have equal counts, so a tie leaves a rank unclaimed)
     const unsigned claimed = wave_or(keep ? 1u << (lt - drop) : 0u);
-    if (__popcll(__ballot(keep)) == k && claimed == (1u << k) - 1u) {
-        *out_slot = keep ? lt - drop : -1;
-        return 0;
-    }
-    // ties decide: bring (rank, lane) into list order (lane p = position p) and replay the quicksort
+    const bool full = __popcll(__ballot(keep)) == k;
+    if (full && claimed == (1u << k) - 1u) return 1;
+    return full ? 2 : 3;
+}
+
+// ties_order: the quicksort replay.  `pos` = this lane's place in the candidate LIST (the reference's
+// dictionary order, 0..n-1: numba's argsort depends on it).  Returns the slot [0, k) this lane's candidate
+// takes in np.argsort(values)[-k:], or -1 if it is dropped.
+__device__ inline int ties_order(int lt, u64 live, int pos, int n, int k, SortLds &S)
+{
+    const int lane = lane_id();
+    const int drop = n - k;
+    const bool mine = (live >> lane) & 1ull;
+    // bring (rank, lane) into list order (lane p = position p) and replay
     const int e_at_pos = push_i32(mine ? ((lt << 8) | lane) : 0, mine ? pos : 63);
     int f, c;
     topk_ties_reg(e_at_pos >> 8, n, k, nullptr, S, &f, &c, e_at_pos & 0xff);
     // lane p holds the candidate of lane c at final position f: tell lane c its slot
     const bool kept = lane < n && f >= drop;
     const int got = push_i32(kept ? f - drop + 1 : 0, kept ? c : 63);
-    *out_slot = (mine && lane != 63) ? got - 1 : -1;
+    return (mine && lane != 63) ? got - 1 : -1;
+}
+
+// both steps at once.  Returns the path taken (0 ranks, 4 quicksort replay).
+__device__ inline int topk_reg(double v, u64 live, int pos, int n, int k, SortLds &S, int *out_slot)
+{
+    int lt;
+    bool keep;
+    if (rank_pass(v, live, n, k, &lt, &keep) == 1) {
+        *out_slot = keep ? lt - (n - k) : -1;
+        return 0;
+    }
+    *out_slot = ties_order(lt, live, pos, n, k, S);
     return 4;
 }
 

@@ -646,13 +646,29 @@ __device__ inline int merge_pair(WaveLds &L, int lane, int k, double alpha, doub
     return k;
 }
 
-// A merged dictionary as merge_pair_reg leaves it: this lane's candidate (if any) and the slot [0, n_new)
-// it takes in the new dictionary (-1: dropped / no candidate).  The new row is never brought into lane
-// order: mailbox and row stores scatter straight from the candidate lanes.
+// A merged dictionary as the register-resident merge leaves it: this lane's candidate (if any) and the slot
+// [0, n_new) it takes in the new dictionary (-1: dropped / no candidate).  The new row is never brought into
+// lane order: mailbox and row stores scatter straight from the candidate lanes.
 struct Cand {
     u64 key;
     double ts, w;
     int slot;
+};
+
+// What the FRONT half of a pair update knows (merge_front): the candidates and, if a prune is needed, their
+// ranks -- everything that does not depend on the ORDER of s1's entries.  merge_order finishes the job once
+// the dictionary position of every s1 entry is known.  On a hub chain the two halves are separated by the
+// arrival of the previous hop's order (process_edge).
+enum { FR_NOPRUNE = 0, FR_RANKS = 1, FR_TIES = 2, FR_STRADDLE = 3, FR_NAN = 4 };
+struct Front {
+    u64 key;
+    double ts, w;      // this lane's candidate (valid if live)
+    u64 live;          // uniform: lanes holding a candidate (s1's entries in [0, n1), the rest from lane 32)
+    int n, n1;         // uniform: candidates, s1's entries among them
+    int pos_tail;      // lanes >= 32: dictionary position of the candidate (s1's entries precede them)
+    int lt;            // strictly smaller candidates (n > k)
+    int mode;          // FR_*: no prune / ranks decide / ties decide the order / ... and the kept set / NaN
+    bool keep;         // FR_RANKS, FR_TIES: this lane's candidate is kept
 };
 
 // The same pair update with the candidate list held in REGISTERS, for k <= 31: s1's entries stay in lanes
@@ -660,9 +676,9 @@ struct Cand {
 // sits behind them.  The top-k works on these register values (topk_reg: ranks by lane broadcasts, tie
 // test by a DPP OR-reduction, quicksort replay on the compacted ranks only when ties decide).  Compared
 // with merge_pair the candidate list, the selection vector and the gathered result never touch LDS.
-__device__ inline int merge_pair_reg(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
-                                     const Row &r2, u64 newkey, double newts, Cand &out, int pre = 0,
-                                     int g_stamp_i = -1)
+__device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
+                                   const Row &r2, u64 newkey, double newts, Front &F, int pre = 0,
+                                   int g_stamp_i = -1)
 {
     STAMP2(0);
     int n1;
@@ -783,39 +799,65 @@ __device__ inline int merge_pair_reg(WaveLds &L, int lane, int k, double alpha, 
         live |= 1ull << nl;
         ++n;
     }
-    out.key = ck; out.ts = ct; out.w = cw;
-    STAMP2(2);
-    STAMP2(3);
     live = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(live >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)live);
     n = __builtin_amdgcn_readfirstlane(n);
+    F.key = ck; F.ts = ct; F.w = cw;
+    F.live = live; F.n = n; F.n1 = n1; F.pos_tail = pos;
+    F.lt = 0; F.keep = false;
+    STAMP2(2);
+    STAMP2(3);
     const bool mine = (live >> lane) & 1ull;
-    if (n <= k) {                               // :549-551
-        out.slot = mine ? pos : -1;
-        return n;
-    }
-    if (__ballot(mine && cw != cw) != 0ull) {
+    if (n <= k) { F.mode = FR_NOPRUNE; return; }          // :549-551
+    if (__ballot(mine && cw != cw) != 0ull) { F.mode = FR_NAN; return; }
+    F.mode = rank_pass(cw, live, n, k, &F.lt, &F.keep);    // :553-559 (first half)
+#ifdef ZT_STAMP
+    if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : 4], 1);
+#endif
+    STAMP2(4);
+}
+
+// The ORDER half: posA = dictionary position of this lane's s1 entry (lanes < n1).  Returns the slot of this
+// lane's candidate in the new dictionary (-1: dropped / none); *n_new = its length.
+__device__ inline int merge_order(WaveLds &L, int lane, int k, Front &F, int posA, int *n_new, int g_stamp_i = -1)
+{
+    const bool mine = (F.live >> lane) & 1ull;
+    const int pos = lane < 32 ? posA : F.pos_tail;
+    const int n = F.n;
+    if (F.mode == FR_NOPRUNE) { *n_new = n; return mine ? pos : -1; }
+    *n_new = k;
+    int slot;
+    if (F.mode == FR_RANKS) {
+        slot = F.keep ? F.lt - (n - k) : -1;
+    } else if (F.mode == FR_NAN) {
         // a NaN weight (only ever from imported state): numba's lt() orders NaNs by the quicksort's
-        // dynamics -> the general selection over LDS, on the compacted list
-        if (mine) { L.key[pos] = ck; L.ts[pos] = ct; L.w[pos] = cw; }
+        // dynamics -> the general selection over LDS, on the list in dictionary order
+        int *lane_at = reinterpret_cast<int *>(L.key);              // candidate lane at every list position
+        if (mine) { lane_at[pos] = lane; L.w[pos] = F.w; }
         wave_sync();
         (void)topk_select_wave(L.w, n, k, L.sel, L.sort, L.sort.r, L.sort.stk);
-        out.slot = -1;
-        if (lane < k) {
-            const int c = L.sel[lane];
-            out.key = L.key[c]; out.ts = L.ts[c]; out.w = L.w[c]; out.slot = lane;
-        }
+        const int who = lane < k ? lane_at[L.sel[lane]] : 63;       // candidate lane that takes slot `lane`
         wave_sync();
-        return k;
+        const int got = push_i32(lane < k ? lane + 1 : 0, who);
+        slot = mine && lane != 63 ? got - 1 : -1;
+    } else {
+        slot = ties_order(F.lt, F.live, pos, n, k, L.sort);       // :553-559 (second half)
     }
-    const int tk_path = topk_reg(cw, live, pos, n, k, L.sort, &out.slot);    // :553-559
-#ifdef ZT_STAMP
-    if (lane == 0) atomicAdd(&g_paths[tk_path & 7], 1);
-#endif
-    (void)tk_path;
-    STAMP2(4);
     STAMP2(5);
-    return k;
+    return slot;
+}
+
+// both halves (s1's row is in dictionary order: position = lane)
+__device__ inline int merge_pair_reg(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
+                                     const Row &r2, u64 newkey, double newts, Cand &out, int pre = 0,
+                                     int g_stamp_i = -1)
+{
+    Front F;
+    merge_front(L, lane, k, alpha, beta, r1, r2, newkey, newts, F, pre, g_stamp_i);
+    int n_new;
+    out.slot = merge_order(L, lane, k, F, lane, &n_new, g_stamp_i);
+    out.key = F.key; out.ts = F.ts; out.w = F.w;
+    return n_new;
 }
 
 // Write a whole row (all k entries, zeros beyond n) with one tag.
@@ -942,18 +984,32 @@ __device__ inline bool load_row_wait(const zt_tppr &h, int m, long long x, int l
 }
 
 // ------------------------------------------------------------ main kernel ----
-// LDS mailbox of a chain workgroup: the hub's newest row and the tag it was written with.  The next
-// edge of the chain (held by a sibling wave) takes the row from here -- an LDS round trip instead of a
-// write-through store plus a memory poll.  Single producer (chain task t), single consumer (task t+1).
-struct Mail {
-    u64 key[64];
-    double ts[64];
-    double w[64];
+// LDS mailbox of a chain workgroup: a ring of hand-off slots, one per chain position modulo MAIL_R.  The hub's
+// new row passes from the edge at chain position t to the edge at t+1 (held by a sibling wave) through slot
+// t % MAIL_R, an LDS round trip instead of a write-through store plus a memory poll -- and in TWO stages:
+//   stage 1, the SET: the k kept entries in "set order" (any fixed order), published as soon as the kept set
+//            is known, i.e. after the rank pass (merge_front);
+//   stage 2, the ORDER: pos[i] = dictionary position of set-order entry i, published after the quicksort
+//            replay when ties decide it (merge_order), together with stage 1 otherwise.
+// The successor starts on stage 1 (scales, key matching, candidate list, rank pass: none of it depends on the
+// order of s1's entries) while this edge still replays its ties; it needs stage 2 only for its own replay,
+// for the partner's update and for emission.  The chain's critical path per hop drops from front + replay to
+// max(front, replay).  seq_set / seq_ord = chain position + 1 once published (0 at launch).
+constexpr int MAIL_R = WAVES_PER_WG;
+struct MailSlot {
+    u64 key[32];
+    double ts[32];
+    double w[32];
+    int pos[32];
     double norm;
     int len;
-    unsigned tag;      // written last
+    int seq_set;       // written last of stage 1
+    int seq_ord;       // written last of stage 2
+    int seq_free;      // = position of the READER once it is done with both stages: the slot may be rewritten
+};
+struct Mail {
+    MailSlot slot[MAIL_R];
     int head;          // next position of the chain's edge list
-    int pad;
 };
 
 struct StreamArgs {
@@ -969,15 +1025,33 @@ struct StreamArgs {
     unsigned epoch;
 };
 
-__device__ __forceinline__ unsigned lds_load_tag(const unsigned *p)
+__device__ __forceinline__ int lds_load_seq(const int *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// spin until *p == want (an LDS word of this workgroup's mailbox); bounded like every other wait
+__device__ inline bool wait_seq(const int *p, int want, int *status, int what, int aux)
+{
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (lds_load_seq(p) != want) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > WAIT_TICKS) { note_timeout(status, 3, what, want, lds_load_seq(p), aux); return false; }
+            if (launch_failed(status)) return false;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
 }
 
 // Apply edge i of the launch for emitted model mo.  mail != nullptr: this wave belongs to the chain
 // workgroup of node `hub`; prev_edge = the chain's previous edge (or -1).
 __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
-                                    long long hub, int prev_edge, int next_edge)
+                                    long long hub, int prev_edge, int next_edge, int tpos)
 {
     const int k = h.k, B = A.B, n_roles = A.n_roles;
     const int m = A.m_lo + mo;
@@ -1046,20 +1120,24 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
         if (!load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2, &wl_seen)) wl_fail |= 8;
     int pre_hash = 0;                           // 1: partner entered into this wave's hash table, 2: with a clash
+    const bool sw = v_first && u != v;          // v's new row is computed and published first
+    MailSlot *in_slot = hub_by_mail ? &mail->slot[(tpos - 1) % MAIL_R] : nullptr;
+    MailSlot *out_slot = mail != nullptr ? &mail->slot[tpos % MAIL_R] : nullptr;
+    // the hub's row arrives in set order and its order later (two-stage hand-off); otherwise rows are in
+    // dictionary order
+    bool hub_ordered = true;
+    const bool hub_is_u = u == hub;
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
-        const unsigned want = tag_base | (unsigned)((u == hub) ? wo_u : wo_v);
         WL(0, 6);
-        // while waiting: the partner of the first merge goes into the hash table already (merge_pair, pre)
+        // while waiting: the partner of the first merge goes into the hash table already (merge_front, pre)
         {
-            const bool sw0 = v_first && u != v;
-            const long long x1_0 = sw0 ? v : u;
-            const Row &rp = sw0 ? ru : rv;
+            const long long x1_0 = sw ? v : u;
+            const Row &rp = sw ? ru : rv;
             const int lenp = (rp.norm != 0.0) ? rp.len : 0;
             if (x1_0 == hub && u != v && lenp > 0) {
                 const int h2 = key_hash(rp.key);
                 if (lane < lenp) L.htab[h2] = lane;
-                L.sort.r[lane] = 0;
                 wave_sync();
                 const int back = lane < lenp ? L.htab[h2] : lane;
                 const bool clash = __ballot(lane < lenp && back != lane) != 0ull;
@@ -1068,26 +1146,40 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 wave_sync();
             }
         }
-        unsigned spins = 0;
-        long long t0 = 0;
-        while (lds_load_tag(&mail->tag) != want) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 4095u) == 0) {
-                const long long now = (long long)wall_clock64();
-                if (t0 == 0) t0 = now;
-                else if (now - t0 > WAIT_TICKS) { note_timeout(h.ctl + 2, 3, i, (int)want, (int)lds_load_tag(&mail->tag), prev_edge); break; }
-                if (launch_failed(h.ctl + 2)) break;
-            }
-        }
-        if (lds_load_tag(&mail->tag) != want) { wl_fail |= 16; WL(7, lds_load_tag(&mail->tag)); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
         Row rm;
-        rm.len = mail->len; rm.norm = mail->norm;
-        rm.key = mail->key[lane]; rm.ts = mail->ts[lane]; rm.w = mail->w[lane];
-        if (u == hub) ru = rm; else rv = rm;
+        rm.len = in_slot->len; rm.norm = in_slot->norm;
+        rm.key = in_slot->key[lane & 31]; rm.ts = in_slot->ts[lane & 31]; rm.w = in_slot->w[lane & 31];
+        if (hub_is_u) ru = rm; else rv = rm;
+        hub_ordered = false;
     }
+    // stage 2 of the hub's row: dictionary position of my set-order entry (identity when the row came from memory)
+    int hub_pos = lane;
+    auto hub_order = [&]() {
+        if (hub_ordered) return;
+        if (!wait_seq(&in_slot->seq_ord, tpos, h.ctl + 2, i, -prev_edge - 2)) wl_fail |= 32;
+        hub_pos = in_slot->pos[lane & 31];
+        hub_ordered = true;
+    };
+    // the hub's old row in dictionary order (what the partner's update, a self-loop and emission read)
+    auto hub_to_dict = [&]() {
+        hub_order();
+        Row &r = hub_is_u ? ru : rv;
+        if (__ballot(lane < r.len && hub_pos != lane) == 0ull) return;
+        const int d = lane < r.len ? hub_pos : 63;
+        r.key = push_u64(r.key, d); r.ts = push_f64(r.ts, d); r.w = push_f64(r.w, d);
+        hub_pos = lane;
+    };
+    // the split hand-off applies when the hub's update is the first of the two: it can then run ahead of the order
+    const bool split = hub_by_mail && u != v && (sw ? v : u) == hub;
+    // the previous position's slot is mine to release, whether or not the row came through it
+    auto release_in = [&]() {
+        if (mail != nullptr && tpos >= 1 && lane == 0)
+            __hip_atomic_store(&mail->slot[(tpos - 1) % MAIL_R].seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (hub_by_mail && !split) hub_to_dict();
+    if (!split) release_in();
     if (v == u) rv = ru;
-    if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
 
     STAMP(1);
     WL(0, 7); WL(3, wall_clock64() >> 7); WL(6, wl_fail | (hub_by_mail ? 256 : 0)); if (wl_fail & 14) WL(7, wl_seen);
@@ -1102,38 +1194,94 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
     // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
     {
-        const bool sw = v_first && u != v;
         const Row &r1 = sw ? rv : ru, &r2 = sw ? ru : rv;
         const long long x1 = sw ? v : u, x2 = sw ? u : v;
         const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
         // (edge_idx, s2, ts) is the key entering s1's dictionary
         const bool reg_path = k <= 31;          // 2k+1 candidates fit one wavefront: register-resident merge
         Cand c;
-        auto merge = [&](const Row &a, const Row &b, long long xb, int pre, int stamp) {
+        // a slot of the ring is reused every MAIL_R positions: wait until the reader of its previous content
+        // (chain position tpos - MAIL_R + 1) has let go of it
+        auto ring_free = [&]() {
+            if (tpos >= MAIL_R)
+                if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
+        };
+        auto publish_set = [&](int sidx, int n, double new_norm) {
+            if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
+            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; }
+        };
+        auto publish_seq = [&](bool set, bool ord) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0 && set) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && ord) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // one full pair update, rows in dictionary order; the hub's new row also goes to the mailbox (both stages)
+        auto update = [&](const Row &a, const Row &b, long long xa, long long xb, int oa, int pre, int stamp) {
             const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)xb;
-            if (reg_path) return merge_pair_reg(L, lane, k, alpha, beta, a, b, nkey, tnow, c, pre, stamp);
-            const int n = merge_pair(L, lane, k, alpha, beta, a, b, nkey, tnow, c.key, c.ts, c.w, pre, stamp);
-            c.slot = lane < n ? lane : -1;
-            return n;
-        };
-        auto publish = [&](long long x, int n, double new_norm, unsigned tag) {
-            if (mail != nullptr && x == hub) {  // mailbox first: the chain's next edge is spinning on it
-                if (c.slot >= 0) { mail->key[c.slot] = c.key; mail->ts[c.slot] = c.ts; mail->w[c.slot] = c.w; }
-                if (lane == 0) { mail->len = n; mail->norm = new_norm; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&mail->tag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int n;
+            if (reg_path) {
+                n = merge_pair_reg(L, lane, k, alpha, beta, a, b, nkey, tnow, c, pre, stamp);
+            } else {
+                n = merge_pair(L, lane, k, alpha, beta, a, b, nkey, tnow, c.key, c.ts, c.w, pre, stamp);
+                c.slot = lane < n ? lane : -1;
             }
-            if (hub_to_memory || x != hub) store_row_scatter(h, m, x, lane, n, c, new_norm, tag);
+            const double new_norm = a.norm * beta + beta;
+            if (mail != nullptr && xa == hub) {
+                ring_free();
+                publish_set(c.slot, n, new_norm);
+                if (c.slot >= 0) out_slot->pos[c.slot] = c.slot;
+                publish_seq(true, true);
+            }
+            if (hub_to_memory || xa != hub) store_row_scatter(h, m, xa, lane, n, c, new_norm, tag_base | (unsigned)(oa + 1));
         };
-        int n = merge(r1, r2, x2, pre_hash, mo == 0 ? i : -1);
-        publish(x1, n, r1.norm * beta + beta, tag_base | (unsigned)(o1 + 1));
-        STAMP(2);
-        WL(0, 8);
-        if (u != v) {
-            n = merge(r2, r1, x1, 0, -1);
-            publish(x2, n, r2.norm * beta + beta, tag_base | (unsigned)(o2 + 1));
+        if (!split) {
+            update(r1, r2, x1, x2, o1, pre_hash, mo == 0 ? i : -1);
+            STAMP(2);
+            WL(0, 8);
+            if (u != v) update(r2, r1, x2, x1, o2, 0, -1);
+        } else {
+            // ---- the hub's update, front half: needs only the SET of the hub's old entries ----
+            const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)x2;
+            const double new_norm = r1.norm * beta + beta;
+            Front F;
+            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1);
+            c.key = F.key; c.ts = F.ts; c.w = F.w;
+            const bool mine = (F.live >> lane) & 1ull;
+            int n_new = F.n <= k ? F.n : k, sidx = -1;
+            bool set_out = false;
+            ring_free();
+            if (F.mode == FR_NOPRUNE) sidx = mine ? (lane < 32 ? lane : F.pos_tail) : -1;
+            else if (F.mode == FR_RANKS) sidx = F.keep ? F.lt - (F.n - k) : -1;
+            else if (F.mode == FR_TIES) sidx = F.keep ? __popcll(__ballot(F.keep) & lanemask_lt()) : -1;
+            if (F.mode == FR_RANKS) {                    // set and order at once
+                publish_set(sidx, n_new, new_norm);
+                if (sidx >= 0) out_slot->pos[sidx] = sidx;
+                publish_seq(true, true);
+                c.slot = sidx;
+                set_out = true;
+            } else if (F.mode == FR_NOPRUNE || F.mode == FR_TIES) {
+                publish_set(sidx, n_new, new_norm);      // the successor can start
+                publish_seq(true, false);
+                set_out = true;
+            }
+            STAMP(2);
+            WL(0, 8);
+            // ---- order half: the dictionary positions of the hub's old entries are needed from here on ----
+            if (F.mode != FR_RANKS) {
+                hub_order();
+                c.slot = merge_order(L, lane, k, F, hub_pos, &n_new, mo == 0 ? i : -1);
+                if (!set_out) { sidx = c.slot; publish_set(sidx, n_new, new_norm); }
+                if (sidx >= 0) out_slot->pos[sidx] = c.slot;
+                publish_seq(!set_out, true);
+            }
+            if (hub_to_memory) store_row_scatter(h, m, x1, lane, n_new, c, new_norm, tag_base | (unsigned)(o1 + 1));
+            // ---- the partner's update reads the hub's old row in dictionary order ----
+            hub_to_dict();
+            release_in();
+            update(r2, r1, x2, x1, o2, 0, -1);
         }
     }
+    if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
 
     // ---- emission is off the critical path (utils/util.py:504-506) ----
     if (A.emit) {
@@ -1172,7 +1320,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         return;
     }
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
-    if (threadIdx.x == 0) { mail.head = 0; mail.tag = 0; }
+    if (threadIdx.x < MAIL_R) { mail.slot[threadIdx.x].seq_set = 0; mail.slot[threadIdx.x].seq_ord = 0; mail.slot[threadIdx.x].seq_free = 0; }
+    if (threadIdx.x == 0) mail.head = 0;
     for (int q = lane; q < HTAB; q += WAVE) L.htab[q] = -1;
     __syncthreads();
     const int n_models = A.n_models;
@@ -1189,7 +1338,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
             int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= len) break;
-            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1);
+            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t);
         }
     }
 
@@ -1206,7 +1355,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         if (idx >= total) return;
         const int i = idx / n_models;
         if (A.use_chains && h.owner_of[i] >= 0) continue;   // a chain workgroup applies this edge
-        process_edge(h, A, L, lane, i, idx % n_models, nullptr, -1, -1, -1);
+        process_edge(h, A, L, lane, i, idx % n_models, nullptr, -1, -1, -1, 0);
     }
 }
 
@@ -1382,7 +1531,8 @@ static void launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *gr
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
     *grid_out = grid;
-    *max_chains_out = chains_for_grid(grid, n_models);
+    // the chain hand-off (two-stage mailbox) is built on the register-resident merge: k <= 31
+    *max_chains_out = h->k <= 31 ? chains_for_grid(grid, n_models) : 0;
 }
 
 // The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
