@@ -213,12 +213,37 @@ typedef struct {
  *   (-1 = shape unsupported). */
 int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T,
                                  int32_t M, int32_t k);
+/*   weights_ready: 0 = pad the weight matrices into the workspace first (needed
+ *   once per weight change); 1 = the workspace already holds them (same
+ *   workspace, same shape, unchanged weights).
+ *   proj_table_dev: NULL, or the projected memory table of zt_project_memory for
+ *   memory_dev (see below): fc1's memory columns are then taken from it. */
 int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes,
              int64_t num_edges, int32_t D, int32_t F, int32_t T,
              const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
              const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev,
              const float *w_dev, const zt_embed_weights *weights, float *out_dev,
-             void *workspace_dev, int32_t *status_dev, void *stream);
+             void *workspace_dev, int32_t *status_dev, const float *proj_table_dev,
+             int32_t weights_ready, void *stream);
+
+/* Projected memory table (no reference counterpart; an algebraic rewrite of
+ * modules/embedding_module.py:264-265).  fc1 is linear, so
+ *   fc1([memory[nbr] | edge | time]) = W_m memory[nbr] + W_e edge + W_t time + b,
+ * and W_m memory[v] depends on the NODE only: P[v] = W_m memory[v] is kept in a
+ * table [num_nodes][round_up(D,16)] (zt_project_table_bytes) and refreshed for
+ * the <= 2B rows a batch rewrites instead of being recomputed for the 3B*k*M
+ * gathered neighbour rows.  rows_dev == NULL: every node (after the memory or
+ * the weights changed wholesale); else the rows listed (ids < 0 and entries
+ * beyond *count_dev, if given, are skipped).  workspace_dev / ws_N / ws_M / ws_k:
+ * the zt_embed workspace (and the N, M, k it was sized for) that holds the
+ * padded weights. */
+int64_t zt_project_table_bytes(int64_t num_nodes, int32_t D);
+int zt_project_memory(const float *memory_dev, int64_t num_nodes, int32_t D,
+                      int32_t F, int32_t T, const zt_embed_weights *weights,
+                      int32_t weights_ready, const int32_t *rows_dev,
+                      const int32_t *count_dev, int64_t max_rows, float *table_dev,
+                      void *workspace_dev, int64_t ws_N, int32_t ws_M, int32_t ws_k,
+                      void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Memory: last-message store + GRU update                                   */

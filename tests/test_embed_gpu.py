@@ -555,3 +555,73 @@ def test_deep_snapshots_restore_what_was_backed_up():
         assert np.array_equal(v, mem0[kk]), kk
     for kk, v in a.tppr_state().items():
         assert np.array_equal(v, tp0[kk]), kk
+
+
+# ---------------------------------------------------------------------------------------------------------
+# projected memory table (zt_project_memory): same embeddings as the full contraction, and it follows every
+# way the memory or the weights can change
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("F", [1, 172])
+def test_projected_table_follows_memory_and_weights(oracle, F):
+    D = T = 100
+    N, E, bs, k, al, be, seed = 1500, 3000, 250, 20, [0.1, 0.1], [0.5, 0.95], 209
+    src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+    w = I.model_weights(D, F, T, 2, seed)
+    mem0, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tw = I.time_encode_weights(T)
+    a = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()        # projected table
+    b = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()        # full contraction
+    b.embedding_module.use_projection = False
+    p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, tw, n_threads=8)
+    dev = a.device
+
+    def step(s, e):
+        outs = []
+        for t in (a, b):
+            with torch.no_grad():
+                se, de, ne = t.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, False)
+            outs.append(torch.cat([se, de, ne]).cpu().numpy())
+        want, _ = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        assert np.abs(outs[0] - want).max() <= TOL and np.abs(outs[1] - want).max() <= TOL, "edge %d" % s
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-5
+
+    for s in range(0, 1000, bs):
+        step(s, s + bs)
+    assert a.embedding_module._proj is not None and b.embedding_module._proj is None
+    # 1. torch-side in-place change of the memory (version bump) -> rebuilt
+    with torch.no_grad():
+        for t in (a, b):
+            t.memory.memory.copy_(torch.from_numpy(mem0).to(dev))
+    p.mem.memory[...] = mem0
+    step(1000, 1250)
+    # 2. set_memory on a few rows
+    ids = np.array([3, 17, 400], np.int64)
+    vals = torch.full((3, D), 0.25, device=dev)
+    for t in (a, b):
+        t.memory.set_memory(ids, vals)
+    p.mem.memory[ids] = 0.25
+    step(1250, 1500)
+    # 3. backup / restore (new tensors)
+    bk = [t.memory.backup_memory() for t in (a, b)]
+    pb = p.backup_memory()
+    step(1500, 1750)
+    for t, x in zip((a, b), bk):
+        t.memory.restore_memory(x)
+    p.restore_memory(pb)
+    p.mem.flags = p.mem.flags.copy()
+    p.mem.flags[...] = 0                                   # eval mode leaves no pending messages; deep copies agree
+    step(1500, 1750)
+    # 4. the weights change in place (what an optimizer step does)
+    with torch.no_grad():
+        for t in (a, b):
+            t.embedding_module.fc1.weight.mul_(0.5)
+            t.embedding_module.fc2_source.bias.add_(0.125)
+    p.w = dict(p.w)
+    p.w["fc1_w"] = p.w["fc1_w"] * np.float32(0.5)
+    p.w["fc2s_b"] = p.w["fc2s_b"] + np.float32(0.125)
+    step(1750, 2000)
+    # 5. __init_memory__ (new epoch)
+    for t in (a, b):
+        t.memory.__init_memory__()
+    p.init_memory()
+    step(2000, 2250)

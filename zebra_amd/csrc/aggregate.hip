@@ -42,14 +42,14 @@ __device__ unsigned long long g_agg[8];
 #define AGG_STAMP(i) do { } while (0)
 #endif
 
-// Zero-padded copy W[rows][cols] -> Wp[rows_p][cols_p].
-__global__ void k_pad_matrix(const float *__restrict__ W, int rows, int cols, float *__restrict__ Wp, int rows_p,
-                             int cols_p)
+// Zero-padded copy of the block W[0..rows)[c0..c0+cols) of a matrix with leading dimension ld -> Wp[rows_p][cols_p].
+__global__ void k_pad_matrix(const float *__restrict__ W, int ld, int c0, int rows, int cols, float *__restrict__ Wp,
+                             int rows_p, int cols_p)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows_p * cols_p) return;
     const int r = i / cols_p, c = i % cols_p;
-    Wp[i] = (r < rows && c < cols) ? W[(size_t)r * cols + c] : 0.f;
+    Wp[i] = (r < rows && c < cols) ? W[(size_t)r * ld + c0 + c] : 0.f;
 }
 
 // ---------------------------------------------------------------------------
@@ -59,12 +59,19 @@ __global__ void k_pad_matrix(const float *__restrict__ W, int rows, int cols, fl
 //   W1p: [Dp][K1p] zero padded (Dp = NT*16, K1p = round_up(K1,16)).
 //   H:   [M][N][D] reduced hidden rows;  S: [M][N] = 1 if sum(w) != 0 else 0.
 // ---------------------------------------------------------------------------
+// TAB = true: the memory columns are not gathered and not multiplied.  fc1 is linear, so
+//   fc1([mem | ef | cos]) = W_m mem + W_e ef + W_t cos + b1, and W_m mem[v] is a per-NODE quantity: it is kept in
+// a projected table P[v] = W_m memory[v] ([num_nodes][Dp], maintained by k_project_rows whenever a memory row
+// changes: at most 2B rows per batch instead of 3B*k*M gathered rows).  The accumulators START from the
+// gathered P rows, the tile holds only [ef | cos] and the contraction runs over F + T columns: for F = 1
+// half the matrix work and none of the memory-row staging.  `memory` then points at P and D is the row stride Dp.
+template <bool TAB>
 __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const float *__restrict__ memory, const float *__restrict__ efeat, const float *__restrict__ time_w,
     long long num_nodes, long long num_edges, int D, int F, int T, long long N, int k, int rq, int mt_count, int lda,
     const int *__restrict__ nbr, const int *__restrict__ eix, const float *__restrict__ dt,
     const float *__restrict__ w, const float *__restrict__ W1p, int K1p, const float *__restrict__ b1,
-    float *__restrict__ H, float *__restrict__ S, int *status)
+    float *__restrict__ H, float *__restrict__ S, int *status, int Dout)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);                       // [mt*16][lda]
@@ -74,11 +81,12 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const long long q0 = (long long)blockIdx.x * rq;
     const int nq = (int)((N - q0) < rq ? (N - q0) : rq);
     const int rows = nq * k, rows_p = mt_count * 16;
-    const int K1 = D + F + T;
+    const int CM = TAB ? 0 : D;                                       // memory columns held in the tile
+    const int K1 = CM + F + T;
     const size_t mb = ((size_t)m * N + q0) * k;                       // first entry of this tile in [M][N][k]
     // ---- this wave's N-tiles {wave, wave+4}; weight fragments stream from L2 one chunk ahead of their MFMAs
     // ---- (keeping all of them in registers was measured: no gain, and it halves the occupancy)
-    const int NT = (D + 15) / 16;
+    const int NT = (Dout + 15) / 16;
     const int r16 = lane & 15, g4 = lane >> 4;
     const float *bp[NTW];
     bool live[NTW];
@@ -126,13 +134,27 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     }
 
     AGG_STAMP(0);
+    // accumulators: zero, or (TAB) the projected rows P[nbr[row]][col] -- issued before the staging below so that the
+    // memory round trip is hidden behind it; the MFMAs then accumulate on top of them
+    f32x4 acc[MAX_MT][NTW];
+#pragma unroll
+    for (int a = 0; a < MAX_MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TAB && a < mt_count && live[b]) {
+                const int col = (wave + b * AGG_WAVES) * 16 + r16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][b][j] = memory[(size_t)g_nb[a * 16 + g4 * 4 + j] * D + col];
+            }
+        }
     // ---- gather: flat (row, column) loops, GU loads in flight per thread before any LDS store
     // ---- (a row-at-a-time loop serialises on HBM latency: 20 rows x ~3 us per wave)
     constexpr int GU = 8;
     const unsigned mD = fastdiv_magic((unsigned)D), mF = fastdiv_magic((unsigned)(F > 0 ? F : 1)),
                    mT = fastdiv_magic((unsigned)(T > 0 ? T : 1));
     // rows are whole float4s, 16-byte aligned in HBM and in the tile
-    const bool vecD = (D & 3) == 0 && ((size_t)memory & 15) == 0;
+    const bool vecD = TAB || ((D & 3) == 0 && ((size_t)memory & 15) == 0);
     const bool vecF = vecD && F > 0 && (F & 3) == 0 && ((size_t)efeat & 15) == 0;
     // cos(dt * w_c) for every (row, frequency); reads only LDS.  Element f = tid + n*256 -> (row g,
     // frequency c) is advanced incrementally: no division in the loop.
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     auto time_encode = [&]() {
         int g = fastdiv(tid, mT), c = tid - g * T;
         for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
-            A[g * lda + D + F + c] = g < rows ? time_cosf(g_dt[g] * tw[c]) : 0.f;      // cos(t*w + 0)
+            A[g * lda + CM + F + c] = g < rows ? time_cosf(g_dt[g] * tw[c]) : 0.f;      // cos(t*w + 0)
             g += step_g; c += step_c;
             if (c >= T) { c -= T; ++g; }
         }
@@ -154,12 +176,14 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         const unsigned mD4 = fastdiv_magic((unsigned)D4), mF4 = fastdiv_magic((unsigned)(F4 > 0 ? F4 : 1));
         f32x4 vm[GU], vf[GU];
         float sf[GU];
+        if (!TAB) {
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = tid + u * AGG_THREADS;
-            const int g = fastdiv(f, mD4), c = f - g * D4;
-            vm[u] = (f < rows_p * D4 && g < rows) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
-                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mD4), c = f - g * D4;
+                vm[u] = (f < rows_p * D4 && g < rows) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (vecF) {
 #pragma unroll
@@ -181,29 +205,31 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         AGG_STAMP(1);
         time_encode();
         AGG_STAMP(2);
+        if (!TAB) {
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-            const int f = tid + u * AGG_THREADS;
-            const int g = fastdiv(f, mD4), c = f - g * D4;
-            if (f < rows_p * D4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = vm[u];
+            for (int u = 0; u < GU; ++u) {
+                const int f = tid + u * AGG_THREADS;
+                const int g = fastdiv(f, mD4), c = f - g * D4;
+                if (f < rows_p * D4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = vm[u];
+            }
         }
         if (vecF) {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int f = tid + u * AGG_THREADS;
                 const int g = fastdiv(f, mF4), c = f - g * F4;
-                if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = vf[u];
+                if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + CM + 4 * c) = vf[u];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
                 const int f = tid + u * AGG_THREADS;
                 const int g = fastdiv(f, mF), c = f - g * F;
-                if (f < rows_p * F) A[(size_t)g * lda + D + c] = sf[u];
+                if (f < rows_p * F) A[(size_t)g * lda + CM + c] = sf[u];
             }
         }
         // whatever does not fit the first batch
-        for (int f0 = tid + AGG_THREADS * GU; f0 < rows_p * D4; f0 += AGG_THREADS * GU) {
+        for (int f0 = tid + AGG_THREADS * GU; !TAB && f0 < rows_p * D4; f0 += AGG_THREADS * GU) {
             f32x4 v[GU];
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 for (int u = 0; u < GU; ++u) {
                     const int f = f0 + u * AGG_THREADS;
                     const int g = fastdiv(f, mF4), c = f - g * F4;
-                    if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + D + 4 * c) = v[u];
+                    if (f < rows_p * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + CM + 4 * c) = v[u];
                 }
             }
         } else {
@@ -251,7 +277,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 for (int u = 0; u < GU; ++u) {
                     const int f = f0 + u * AGG_THREADS;
                     const int g = fastdiv(f, mF), c = f - g * F;
-                    if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+                    if (f < rows_p * F) A[(size_t)g * lda + CM + c] = v[u];
                 }
             }
         }
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
             for (int u = 0; u < GU; ++u) {
                 const int f = f0 + u * AGG_THREADS;
                 const int g = fastdiv(f, mF), c = f - g * F;
-                if (f < rows_p * F) A[(size_t)g * lda + D + c] = v[u];
+                if (f < rows_p * F) A[(size_t)g * lda + CM + c] = v[u];
             }
         }
         AGG_STAMP(2);
@@ -301,11 +327,6 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     AGG_STAMP(4);
 
     // ---- fc1 on f32 MFMA: wave handles N-tiles {wave, wave+4}, all M-tiles ----
-    f32x4 acc[MAX_MT][NTW];
-#pragma unroll
-    for (int a = 0; a < MAX_MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
         const int nchunk = K1p / 16;
         f32x4 bcur[NTW], bnext[NTW];
@@ -344,7 +365,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     for (int b = 0; b < NTW; ++b) {
         if (!live[b]) continue;
         const int col = (wave + b * AGG_WAVES) * 16 + r16;
-        const float bias = col < D ? b1[col] : 0.f;
+        const float bias = col < Dout ? b1[col] : 0.f;
 #pragma unroll
         for (int a = 0; a < MAX_MT; ++a) {
             if (a >= mt_count) continue;
@@ -360,11 +381,12 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     __syncthreads();
     AGG_STAMP(6);
     // ---- reduce over the k neighbours of each query row ----
-    for (int idx = tid; idx < nq * D; idx += AGG_THREADS) {
-        const int q = fastdiv(idx, mD), c = idx - q * D;
+    const unsigned mDo = fastdiv_magic((unsigned)Dout);
+    for (int idx = tid; idx < nq * Dout; idx += AGG_THREADS) {
+        const int q = fastdiv(idx, mDo), c = idx - q * Dout;
         float s = 0.f;
         for (int j = 0; j < k; ++j) s += Hs[(size_t)(q * k + j) * ldh + c];
-        H[((size_t)m * N + q0 + q) * D + c] = s;
+        H[((size_t)m * N + q0 + q) * Dout + c] = s;
     }
     AGG_STAMP(7);
 }
@@ -496,43 +518,105 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Projected memory table: P[v][0..Dp) = W_m memory[v] (W_m = the memory columns of fc1, zero padded to
+// [Dp][Dp]; columns >= D of P are zero).  rows == nullptr: every node; else the n rows listed (ids < 0 or
+// beyond *count are skipped): the rows a batch's GRU update / exchange has just rewritten.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(AGG_THREADS) void k_project_rows(const float *__restrict__ memory, long long num_nodes,
+                                                              int D, const float *__restrict__ Wm_p,
+                                                              const int *__restrict__ rows, const int *__restrict__ count,
+                                                              long long n_max, float *__restrict__ P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Dp = (D + 15) / 16 * 16, ldx = Dp + 4, NT = Dp / 16;
+    float *X = reinterpret_cast<float *>(smem);          // [32][ldx]
+    int *rid = reinterpret_cast<int *>(X + OUT_ROWS * ldx);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const long long r0 = (long long)blockIdx.x * OUT_ROWS;
+    long long n = n_max;
+    if (count != nullptr) { const long long c = *count; n = c < n ? c : n; }
+    if (r0 >= n) return;
+    if (tid < OUT_ROWS) {
+        long long v = -1;
+        if (r0 + tid < n) v = rows != nullptr ? (long long)rows[r0 + tid] : r0 + tid;
+        rid[tid] = (v >= 0 && v < num_nodes) ? (int)v : -1;
+    }
+    __syncthreads();
+    const unsigned mL = fastdiv_magic((unsigned)ldx);
+    for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
+        const int g = fastdiv(f, mL), c = f - g * ldx;
+        X[f] = (rid[g] >= 0 && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+    }
+    __syncthreads();
+    f32x4 acc[OUT_MT][NTW];
+    small_gemm(X, ldx, Wm_p, Dp, NT, wave, lane, acc);
+#pragma unroll
+    for (int b = 0; b < NTW; ++b) {
+        const int col = (wave + b * AGG_WAVES) * 16 + r16;
+        if (col >= Dp) continue;
+#pragma unroll
+        for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = a * 16 + g4 * 4 + j;
+                if (rid[g] >= 0) P[(size_t)rid[g] * Dp + col] = acc[a][b][j];
+            }
+    }
+}
+
 struct EmbedPlan {
     int Dp, K1p, lda, mt, rq;
     size_t lds;
-    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, total;
+    // table path (k_fc1_agg<true>): the tile holds only [ef | cos]
+    int K2p, lda2, mt2, rq2;
+    size_t lds2;
+    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, total;
 };
+
+// tile shape for a contraction over Kp columns: as many whole query rows as fit MAX_MT tiles / the LDS budget
+bool tile_shape(int Kp, int Dp, int k, int T, int *lda_out, int *mt_out, int *rq_out, size_t *lds_out)
+{
+    const int lda = Kp + 4;
+    static const int mt_env = getenv("ZT_AGG_MT") ? atoi(getenv("ZT_AGG_MT")) : 0;
+    int mt = (mt_env >= 1 && mt_env <= MAX_MT) ? mt_env : MAX_MT;
+    while (mt > 1 && ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
+    int rq = (mt * 16) / k;
+    if (rq < 1) {
+        // one query row must fit: grow to ceil(k/16) tiles if the budget allows
+        mt = (k + 15) / 16;
+        rq = 1;
+        if (mt > MAX_MT || ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) return false;
+    }
+    mt = (rq * k + 15) / 16;
+    // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
+    if ((size_t)mt * 16 * (Dp + 1) * 4 > (size_t)mt * 16 * lda * 4) return false;
+    *lda_out = lda; *mt_out = mt; *rq_out = rq;
+    *lds_out = (size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16 + (size_t)T * 4;   // A tile + wn, nbr, eix, dt per row + time_w
+    return true;
+}
 
 bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
 {
     const int K1 = D + F + T;
     p.Dp = round_up(D, 16);
     p.K1p = round_up(K1, 16);
-    p.lda = p.K1p + 4;
-    // M-tiles per workgroup: as many whole query rows as fit in 5 tiles / the LDS budget
-    static const int mt_env = getenv("ZT_AGG_MT") ? atoi(getenv("ZT_AGG_MT")) : 0;
-    int mt = (mt_env >= 1 && mt_env <= MAX_MT) ? mt_env : MAX_MT;
-    while (mt > 1 && ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
-    int rq = (mt * 16) / k;
-    if (rq < 1) {
-        // one query row must fit: grow to ceil(k/16) tiles if the budget allows
-        mt = (k + 15) / 16;
-        rq = 1;
-        if (mt > MAX_MT || ((size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) return false;
-    }
-    mt = (rq * k + 15) / 16;
-    p.mt = mt;
-    p.rq = rq;
-    p.lds = (size_t)mt * 16 * p.lda * 4 + (size_t)mt * 16 * 16 + (size_t)T * 4;   // A tile + wn, nbr, eix, dt per row + time_w
-    // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
-    if ((size_t)mt * 16 * (p.Dp + 1) * 4 > (size_t)mt * 16 * p.lda * 4) return false;
+    if (!tile_shape(p.K1p, p.Dp, k, T, &p.lda, &p.mt, &p.rq, &p.lds)) return false;
+    p.K2p = round_up(F + T, 16);
+    p.mt2 = 0;                                  // table path unavailable (e.g. F + T < D: the staging would not fit)
+    if (!tile_shape(p.K2p, p.Dp, k, T, &p.lda2, &p.mt2, &p.rq2, &p.lds2)) p.mt2 = 0;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    // padded weights first: their offsets depend on (D, F, T) only, so a workspace prepared once serves every N
     p.off_w1p = take((size_t)p.Dp * p.K1p * 4);
-    p.off_H = take((size_t)M * N * D * 4);
-    p.off_S = take((size_t)M * N * 4);
     p.off_fc2t = take((size_t)p.Dp * p.Dp * 4);
     p.off_fc1st = take((size_t)p.Dp * p.Dp * 4);
     p.off_fc2st = take((size_t)p.Dp * p.Dp * 4);
+    p.off_w1t = take((size_t)p.Dp * p.K2p * 4);
+    p.off_wm = take((size_t)p.Dp * p.Dp * 4);
+    p.off_H = take((size_t)M * N * D * 4);
+    p.off_S = take((size_t)M * N * 4);
     p.total = o;
     return true;
 }
@@ -557,11 +641,58 @@ extern "C" int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int
     return (int64_t)p.total;
 }
 
+// pads every weight matrix into the workspace (once per weight change: zt_embed's weights_ready = 0)
+static void embed_prepare(const zt_embed_weights *wt, int D, int F, int T, const EmbedPlan &p, char *ws, hipStream_t s)
+{
+    const int K1 = D + F + T;
+    auto pad = [&](const float *W, int ld, int c0, int cols, size_t off, int cols_p) {
+        k_pad_matrix<<<(p.Dp * cols_p + 255) / 256, 256, 0, s>>>(W, ld, c0, D, cols, reinterpret_cast<float *>(ws + off), p.Dp, cols_p);
+    };
+    pad(wt->fc1_w, K1, 0, K1, p.off_w1p, p.K1p);
+    pad(wt->fc2_w, D, 0, D, p.off_fc2t, p.Dp);
+    pad(wt->fc1s_w, D, 0, D, p.off_fc1st, p.Dp);
+    pad(wt->fc2s_w, D, 0, D, p.off_fc2st, p.Dp);
+    pad(wt->fc1_w, K1, D, F + T, p.off_w1t, p.K2p);       // the [ef | time] columns of fc1 (table path)
+    pad(wt->fc1_w, K1, 0, D, p.off_wm, p.Dp);             // W_m: the memory columns of fc1 (k_project_rows)
+}
+
+extern "C" int64_t zt_project_table_bytes(int64_t num_nodes, int32_t D)
+{
+    if (num_nodes <= 0 || D <= 0) return -1;
+    return (int64_t)num_nodes * round_up(D, 16) * 4;
+}
+
+extern "C" int zt_project_memory(const float *memory_dev, int64_t num_nodes, int32_t D, int32_t F, int32_t T,
+                                 const zt_embed_weights *wt, int32_t weights_ready, const int32_t *rows_dev,
+                                 const int32_t *count_dev, int64_t max_rows, float *table_dev, void *workspace_dev,
+                                 int64_t ws_N, int32_t ws_M, int32_t ws_k, void *stream)
+{
+    if (!memory_dev || !wt || !table_dev || !workspace_dev || num_nodes <= 0 || D <= 0 || F < 0 || T < 0 || max_rows < 0) {
+        set_error("zt_project_memory: bad argument");
+        return ZT_ERR_ARG;
+    }
+    EmbedPlan p;
+    if (D > 128 || !make_plan(ws_N > 0 ? ws_N : 1, D, F, T, ws_M, ws_k, p)) {
+        set_error("zt_project_memory: unsupported shape");
+        return ZT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    if (!weights_ready) embed_prepare(wt, D, F, T, p, ws, s);
+    const long long n = rows_dev ? max_rows : num_nodes;
+    if (n == 0) return ZT_OK;
+    const size_t lds = (size_t)OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
+    k_project_rows<<<(unsigned)((n + OUT_ROWS - 1) / OUT_ROWS), AGG_THREADS, lds, s>>>(
+        memory_dev, num_nodes, D, reinterpret_cast<const float *>(ws + p.off_wm), rows_dev, count_dev, n, table_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
 extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
                         int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
                         const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                         const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
-                        void *stream)
+                        const float *proj_table_dev, int32_t weights_ready, void *stream)
 {
     if (!memory_dev || !efeat_dev || !wt || !status_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) {
         set_error("zt_embed: bad argument");
@@ -581,29 +712,37 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     hipStream_t s = (hipStream_t)stream;
     char *ws = reinterpret_cast<char *>(workspace_dev);
     float *W1p = reinterpret_cast<float *>(ws + p.off_w1p);
+    float *W1t = reinterpret_cast<float *>(ws + p.off_w1t);
     float *H = reinterpret_cast<float *>(ws + p.off_H);
     float *S = reinterpret_cast<float *>(ws + p.off_S);
     float *fc2t = reinterpret_cast<float *>(ws + p.off_fc2t);
     float *fc1st = reinterpret_cast<float *>(ws + p.off_fc1st);
     float *fc2st = reinterpret_cast<float *>(ws + p.off_fc2st);
-    const int K1 = D + F + T;
-    ZT_PROF_BEGIN(s, P_EMBED_PREP);
-    k_pad_matrix<<<(p.Dp * p.K1p + 255) / 256, 256, 0, s>>>(wt->fc1_w, D, K1, W1p, p.Dp, p.K1p);
-    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc2_w, D, D, fc2t, p.Dp, p.Dp);
-    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc1s_w, D, D, fc1st, p.Dp, p.Dp);
-    k_pad_matrix<<<(p.Dp * p.Dp + 255) / 256, 256, 0, s>>>(wt->fc2s_w, D, D, fc2st, p.Dp, p.Dp);
-    ZT_PROF_END(s, P_EMBED_PREP);
-    static size_t attr_lds = 0;
-    if (p.lds > 48 * 1024 && p.lds > attr_lds) {
-        ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc1_agg), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)p.lds));
-        attr_lds = p.lds;
+    if (!weights_ready) {
+        ZT_PROF_BEGIN(s, P_EMBED_PREP);
+        embed_prepare(wt, D, F, T, p, ws, s);
+        ZT_PROF_END(s, P_EMBED_PREP);
     }
-    dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
+    const bool tab = proj_table_dev != nullptr && p.mt2 > 0;
+    const size_t lds = tab ? p.lds2 : p.lds;
+    static size_t attr_lds[2] = {0, 0};
+    if (lds > 48 * 1024 && lds > attr_lds[tab ? 1 : 0]) {
+        const void *fn = tab ? reinterpret_cast<const void *>(k_fc1_agg<true>) : reinterpret_cast<const void *>(k_fc1_agg<false>);
+        ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds[tab ? 1 : 0] = lds;
+    }
     ZT_PROF_BEGIN(s, P_FC1_AGG);
-    k_fc1_agg<<<grid, AGG_THREADS, p.lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N, k,
-                                               p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
-                                               wt->fc1_b, H, S, status_dev);
+    if (tab) {
+        dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
+        k_fc1_agg<true><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
+                                                       T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,
+                                                       p.K2p, wt->fc1_b, H, S, status_dev, D);
+    } else {
+        dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
+        k_fc1_agg<false><<<grid, AGG_THREADS, lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N,
+                                                        k, p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
+                                                        wt->fc1_b, H, S, status_dev, D);
+    }
     ZT_PROF_END(s, P_FC1_AGG);
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;

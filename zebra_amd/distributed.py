@@ -120,7 +120,7 @@ def exchange_touched_rows(tables, ids, n_valid, cap, group=None):
             recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
             dist.all_gather_into_tensor(recv, send, group=group)
         unpack_rows_device(tables, recv)
-        return None
+        return recv[:, 0].contiguous().view(torch.int32)       # ids of every row written (-1 = padding)
     send = pack_rows(tables, ids, n_valid, cap)
     recv = torch.empty((world * cap, send.shape[1]), dtype=torch.float32, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)
@@ -148,19 +148,23 @@ class ShardedTGN:
             ts3 = torch.cat([ts_d, ts_d, ts_d])
             mine = nodes_d[r0:r1].contiguous()
             on, oe, od, ow = em.pruning_topk_device(mine, ts3[r0:r1].contiguous(), check_status=check_status)
-            emb = em.embed_device(tgn.memory.memory, mine, on, oe, od, ow, check_status=check_status)
+            emb = em.embed_device(tgn.memory.memory, mine, on, oe, od, ow, check_status=check_status,
+                                  memory_obj=tgn.memory)
         else:
             nodes_d, on, oe, od, ow = tgn.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch,
                                                             check_status, plan)                    # replicated
             emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
                                   oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),
-                                  check_status=check_status)
+                                  check_status=check_status, memory_obj=tgn.memory)
         p0, p1 = shard_range(2 * B, self.rank, self.world)
         tgn.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=(p0, p1))
         # only this rank's winners are flagged: the GRU compacts them out of the endpoint list
         tgn.memory_updater.update_device(tgn.memory, nodes_d[: 2 * B], 2 * B)
         rows, count = tgn.memory_updater.last_rows()
         m = tgn.memory
-        exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,
-                              shard_capacity(2 * B, self.world), self.group)
+        got = exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,
+                                    shard_capacity(2 * B, self.world), self.group)
+        hook = getattr(m, "_rows_changed", None)
+        if hook is not None and torch.is_tensor(got):          # rows the other ranks rewrote: the projected table follows
+            hook(got, None, got.numel())
         return emb

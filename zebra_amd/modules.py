@@ -172,6 +172,10 @@ class GRUMemoryUpdater(nn.Module):
                                   ptr(memory.timestamps), ptr(memory._flag_buf), C.c_int64(memory.n_nodes),
                                   C.c_int32(D), C.c_int32(self.message_dimension), ptr(ids_d), C.c_int64(n_ids),
                                   ptr(n_ids_d), C.byref(self._weights()), ptr(ws), stream_ptr()), "zt_gru_update")
+        hook = getattr(memory, "_rows_changed", None)
+        if hook is not None:                       # e.g. the embedding module's projected table follows the rows
+            rows, count = self.last_rows()
+            hook(rows, count, max_rows)
 
     def last_rows(self):
         """(rows int32[max_rows], count int32[1]) views of the ids the last update_device
@@ -259,6 +263,10 @@ class GraphDiffusionEmbedding(nn.Module):
             self.tppr_finder = tppr_finder(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list,
                                            reference_compat_aliasing=getattr(args, "reference_compat_aliasing", False))
         self._ws = None
+        self._ws_key = None                     # weights the workspace's padded copies were made from
+        self._ws_shape = None
+        self._proj = None                       # projected memory table (see embed_device)
+        self.use_projection = getattr(args, "use_projection", True)
         self._status = None
         self._avg_topk_t = None
 
@@ -325,24 +333,85 @@ class GraphDiffusionEmbedding(nn.Module):
             return self.pruning_topk_device(nodes_d, ts_d, check_status=check_status)
         raise ValueError("tppr_strategy must be 'streaming' or 'pruning'")
 
-    def embed_device(self, memory_t, nodes_d, on, oe, od, ow, check_status=True):
-        """Eval forward of :243-276 on the HIP kernels: [N, D*(n_tppr+1)]."""
-        N, D = nodes_d.numel(), self.embedding_dimension
-        F, T = self.n_edge_features, self.n_time_features
+    def _weights_key(self):
+        """Identity + in-place version of every weight the kernels read: the padded copies in the workspace are
+        remade only when this changes (an optimizer step, load_state_dict, .to())."""
+        ps = (self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, self.fc1_source.weight,
+              self.fc1_source.bias, self.fc2_source.weight, self.fc2_source.bias, self.time_encoder.w.weight)
+        return tuple((t.data_ptr(), t._version) for t in ps)
+
+    def _workspace(self, N):
+        """(workspace tensor, weights_ready) for N output rows."""
+        D, F, T = self.embedding_dimension, self.n_edge_features, self.n_time_features
         need = lib().zt_embed_workspace_bytes(C.c_int64(N), C.c_int32(D), C.c_int32(F), C.c_int32(T),
                                               C.c_int32(self.n_tppr), C.c_int32(self.k))
         if need < 0:
             raise ValueError("zt_embed: unsupported shape D=%d F=%d T=%d k=%d" % (D, F, T, self.k))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+            self._ws_key = None
+        key = self._weights_key()
+        ready = self._ws_key == key
+        return self._ws, ready, key
+
+    def _project(self, memory_obj, rows=None, count=None, max_rows=0):
+        """Refresh the projected table P[v] = W_m memory[v] for all nodes (rows None) or the listed rows."""
+        D, F, T = self.embedding_dimension, self.n_edge_features, self.n_time_features
+        ws, ready, key = self._workspace(max(1, self._ws_shape or 1))
+        pr = self._proj
+        check(lib().zt_project_memory(ptr(memory_obj.memory), C.c_int64(memory_obj.n_nodes), C.c_int32(D), C.c_int32(F),
+                                      C.c_int32(T), C.byref(self._embed_weights()), C.c_int32(1 if ready else 0),
+                                      ptr(rows), ptr(count), C.c_int64(max_rows), ptr(pr["table"]), ptr(ws),
+                                      C.c_int64(max(1, self._ws_shape or 1)), C.c_int32(self.n_tppr), C.c_int32(self.k),
+                                      stream_ptr()), "zt_project_memory")
+        self._ws_key = key
+
+    def _projection(self, memory_obj):
+        """The projected table for ``memory_obj.memory`` if it can be used, else None.  Valid for one memory tensor
+        (identity and torch in-place version: HIP kernels that rewrite rows report them through
+        ``memory_obj._rows_changed`` instead) and one set of weights; anything else triggers a full rebuild."""
+        if not self.use_projection or memory_obj is None:
+            return None
+        mem = memory_obj.memory
+        key = (mem.data_ptr(), mem._version, self._weights_key())
+        pr = self._proj
+        if pr is None or pr["table"].shape[0] != memory_obj.n_nodes:
+            nbytes = lib().zt_project_table_bytes(C.c_int64(memory_obj.n_nodes), C.c_int32(self.embedding_dimension))
+            pr = self._proj = {"table": torch.empty((memory_obj.n_nodes, int(nbytes) // (4 * memory_obj.n_nodes)),
+                                                    dtype=torch.float32, device=self.device), "key": None}
+        if pr["key"] != key:
+            self._project(memory_obj)                                  # every node
+            pr["key"] = key
+        em = self
+
+        def rows_changed(rows, count, max_rows):                       # called after HIP kernels rewrote memory rows
+            p2 = em._proj
+            m2 = memory_obj.memory
+            if p2 is None or p2["key"] != (m2.data_ptr(), m2._version, em._weights_key()):
+                if p2 is not None:
+                    p2["key"] = None                                   # stale: rebuilt at the next use
+                return
+            em._project(memory_obj, rows, count, max_rows)
+        memory_obj._rows_changed = rows_changed
+        return pr["table"]
+
+    def embed_device(self, memory_t, nodes_d, on, oe, od, ow, check_status=True, memory_obj=None):
+        """Eval forward of :243-276 on the HIP kernels: [N, D*(n_tppr+1)].  ``memory_obj``: the Memory whose
+        ``.memory`` tensor ``memory_t`` is -- its projected table then replaces fc1's memory columns."""
+        N, D = nodes_d.numel(), self.embedding_dimension
+        F, T = self.n_edge_features, self.n_time_features
+        self._ws_shape = max(N, self._ws_shape or 0)
+        table = self._projection(memory_obj) if (memory_obj is not None and memory_t is memory_obj.memory) else None
+        ws, ready, key = self._workspace(self._ws_shape)
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         out = torch.empty((N, D * (self.n_tppr + 1)), dtype=torch.float32, device=self.device)
         check(lib().zt_embed(ptr(memory_t), ptr(self.edge_features), C.c_int64(memory_t.shape[0]),
                              C.c_int64(self.edge_features.shape[0]), C.c_int32(D), C.c_int32(F), C.c_int32(T),
                              ptr(nodes_d), C.c_int64(N), C.c_int32(self.n_tppr), C.c_int32(self.k), ptr(on), ptr(oe),
-                             ptr(od), ptr(ow), C.byref(self._embed_weights()), ptr(out), ptr(self._ws),
-                             ptr(self._status), stream_ptr()), "zt_embed")
+                             ptr(od), ptr(ow), C.byref(self._embed_weights()), ptr(out), ptr(ws),
+                             ptr(self._status), ptr(table), C.c_int32(1 if ready else 0), stream_ptr()), "zt_embed")
+        self._ws_key = key
         if check_status:
             st = int(self._status.item())
             if st != 0:

@@ -196,7 +196,8 @@ class TGN(torch.nn.Module):
                                                         plan)
         if stats:                                    # average_topk (modules/embedding_module.py:232-233)
             em._avg_topk_t = ow[0, : 2 * src_d.numel()].sum(dim=1).mean()
-        emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status)
+        emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status,
+                              memory_obj=self.memory)
         B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
         self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each
         if check_status:
