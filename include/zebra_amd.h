@@ -297,14 +297,70 @@ typedef struct {
  *   workspace_dev: zt_gru_workspace_bytes(max_rows, D, msg_dim) bytes, where
  *   max_rows = n_ids (or num_nodes when ids_dev == NULL).  On return its first
  *   int32 holds the number of rows updated and the int32 array at byte 256
- *   their ids (duplicates in ids_dev are updated once). */
+ *   their ids (duplicates in ids_dev are updated once).
+ *   weights_ready: 0 = pack the GRU weights into the workspace first; 1 = the
+ *   workspace already holds them (same workspace, same max_rows, same weights). */
 int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t msg_dim);
 int zt_gru_update(float *memory_dev, float *last_update_dev,
                   const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D,
                   int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                   const int32_t *n_ids_dev, const zt_gru_weights *weights,
-                  void *workspace_dev, void *stream);
+                  void *workspace_dev, int32_t weights_ready, void *stream);
+
+/* ------------------------------------------------------------------------ */
+/* One batch as one call -- TGN.compute_temporal_embeddings, train=False      */
+/*   (model/tgn_model.py:124-174) for device-resident batches.  The reference */
+/*   issues these steps from Python on one stream (train.py:145-146); here     */
+/*   they are enqueued from C++ on three streams: the T-PPR query of batch b+1 */
+/*   (side stream, CU-masked to tppr_cus compute units when > 0) beside        */
+/*   aggregate + messages + GRU of batch b (main stream, the remaining CUs),   */
+/*   the dependency prepass of batch b+2 on a third.                           */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    zt_tppr *tppr;                 /* streaming strategy: the T-PPR state; else NULL      */
+    const zt_csr *csr;             /* pruning strategy: the adjacency; else NULL          */
+    int32_t width, depth;          /* pruning: n_degree, n_layer (train.py:25,28)         */
+    double alpha[16], beta[16];    /* pruning: per model                                  */
+    float *memory, *last_update, *messages, *msg_ts;   /* Memory (modules/memory.py:19-25) */
+    uint8_t *flags;                /* pending-message flags, padded to 4 bytes            */
+    int32_t *scratch;              /* int32[num_nodes], all -1 (zt_store_messages)        */
+    const float *efeat;
+    int64_t num_nodes, num_edges;
+    int32_t D, F, T, M, k;
+    zt_embed_weights ew;
+    zt_gru_weights gw;
+    void *embed_ws;                /* zt_embed_workspace_bytes(3*max_B, ...)              */
+    void *gru_ws;                  /* zt_gru_workspace_bytes(2*max_B, ...)                */
+    float *proj_table;             /* zt_project_memory table kept current by the step, or NULL */
+    int32_t *status;               /* latched ZT_ERR_RANGE of the aggregate / message kernels   */
+    int64_t max_B;                 /* largest batch                                       */
+} zt_pipeline_desc;                /* all pointers device memory */
+
+typedef struct {
+    const int32_t *src, *dst, *neg;   /* int32[B] each */
+    const double *ts;                 /* float64[B]    */
+    const int64_t *eidx;              /* int64[B]; also identifies the batch between calls */
+    int64_t B;
+} zt_batch;
+
+typedef struct zt_pipeline zt_pipeline;
+int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *desc, int32_t tppr_cus);
+int zt_pipeline_destroy(zt_pipeline *p);
+/* The stream the outputs are produced on (hipStream_t): consumers and any collective that follows a step
+ * (the row exchange of a sharded run) are enqueued there. */
+void *zt_pipeline_main_stream(zt_pipeline *p);
+/* New table pointers / handles (Memory tensors replaced, neighbour finder swapped: desc != NULL) and / or
+ * weights changed in place (weights_changed: the padded copies in the workspaces are remade). */
+int zt_pipeline_update(zt_pipeline *p, const zt_pipeline_desc *desc, int32_t weights_changed);
+/* One eval-mode batch.  next / plan (optional): the batches of the following two steps; `next` is QUERIED now
+ * (streaming: its T-PPR update is applied), so it must be the batch of the next call.  Rows [row_lo, row_hi)
+ * of [src|dst|neg] are embedded into out_emb_dev [row_hi-row_lo][D*(M+1)] and the last messages of the
+ * endpoints at positions [pos_lo, pos_hi) of [src|dst] are stored and applied (a single GPU passes 0, 3B, 0,
+ * 2B; shards of a multi-GPU run their slices and exchange the touched rows afterwards).  No host
+ * synchronisation; errors of the device side are latched (zt_tppr_status, desc.status). */
+int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, const zt_batch *plan,
+                     int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
 
 /* ------------------------------------------------------------------------ */
 /* TemporalAttentionLayer.forward -- model/temporal_attention.py:7-68        */

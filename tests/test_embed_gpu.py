@@ -126,10 +126,13 @@ def test_protocol_vs_oracle(oracle, cfg):
     assert np.array_equal(tgn.memory.nodes.astype(np.uint8), mem.flags)
 
 
-@pytest.mark.parametrize("tppr_cus", [0, 32])
-def test_pipelined_step_matches_sequential(tppr_cus):
-    """The side-stream T-PPR prefetch (optionally on CU-masked streams) and the dependency prepass
-    planned two batches ahead on a third stream must not change any result."""
+@pytest.mark.parametrize("tppr_cus,strategy", [(0, "streaming"), (32, "streaming"), (0, "pruning")])
+def test_pipelined_step_matches_sequential(tppr_cus, strategy):
+    """The native step pipeline (T-PPR query of the next batch on a side stream, optionally CU-masked, the
+    dependency prepass planned two batches ahead on a third stream, everything enqueued by one C call) must
+    not change any result; nor must restricting the embedded rows to a shard."""
+    import types
+    from zebra_amd.tppr import get_neighbor_finder
     name = "d100_f1"
     N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
     src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
@@ -138,28 +141,37 @@ def test_pipelined_step_matches_sequential(tppr_cus):
     dev = torch.device("cuda")
     t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
     outs = {}
-    for mode in ("seq", "pipe"):
-        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
-        if mode == "pipe":
-            tgn.enable_pipeline(tppr_cus=tppr_cus)
+    for mode in ("seq", "pipe", "pipe_rows"):
+        nf = None
+        if strategy == "pruning":
+            nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf).eval()
+        if mode != "seq":
+            tgn.enable_pipeline(tppr_cus=tppr_cus, max_batch=64)
         nbt = E // bs
         embs = []
+        rows = (bs, 3 * bs - 7) if mode == "pipe_rows" else None
         main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
         with torch.cuda.stream(main):
             for b in range(nbt):
                 cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
-                nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
+                nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode != "seq" and b + 1 < nbt) else None
                 # every third batch is left unplanned: planned and inline prepasses interleave
-                nx2 = tuple(x[(b + 2) * bs:(b + 3) * bs] for x in t) if (mode == "pipe" and b + 2 < nbt and b % 3) else None
-                embs.append(tgn.step_device(*cur, prefetch=nxt, plan=nx2).clone())
+                nx2 = tuple(x[(b + 2) * bs:(b + 3) * bs] for x in t) if (mode != "seq" and b + 2 < nbt and b % 3) else None
+                embs.append(tgn.step_device(*cur, prefetch=nxt, plan=nx2, rows=rows).clone())
         torch.cuda.synchronize()
-        tgn.embedding_module.tppr_finder.check_status()
-        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(),
-                      tgn.embedding_module.tppr_finder.export_state(0))
+        state = {}
+        if strategy == "streaming":
+            tgn.embedding_module.tppr_finder.check_status()
+            state = tgn.embedding_module.tppr_finder.export_state(0)
+        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(), state)
+        tgn.enable_pipeline(False)
     assert np.array_equal(outs["seq"][0], outs["pipe"][0])
-    assert np.array_equal(outs["seq"][1], outs["pipe"][1])
-    for kk in outs["seq"][2]:
-        assert np.array_equal(outs["seq"][2][kk], outs["pipe"][2][kk])
+    assert np.array_equal(outs["seq"][0][:, bs:3 * bs - 7], outs["pipe_rows"][0])
+    for mode in ("pipe", "pipe_rows"):
+        assert np.array_equal(outs["seq"][1], outs[mode][1])
+        for kk in outs["seq"][2]:
+            assert np.array_equal(outs["seq"][2][kk], outs[mode][2][kk])
 
 
 def test_full_size_step_properties():

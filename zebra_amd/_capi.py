@@ -25,7 +25,7 @@ SYMBOLS = [
     "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
-    "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory",
+    "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step",
     "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_update", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
 ]
 
@@ -47,6 +47,23 @@ class GruWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w_ih", "w_hh", "b_ih", "b_hh")]
 
 
+class PipelineDesc(C.Structure):
+    _fields_ = [("tppr", C.c_void_p), ("csr", C.c_void_p), ("width", C.c_int32), ("depth", C.c_int32),
+                ("alpha", C.c_double * 16), ("beta", C.c_double * 16),
+                ("memory", C.c_void_p), ("last_update", C.c_void_p), ("messages", C.c_void_p), ("msg_ts", C.c_void_p),
+                ("flags", C.c_void_p), ("scratch", C.c_void_p), ("efeat", C.c_void_p),
+                ("num_nodes", C.c_int64), ("num_edges", C.c_int64),
+                ("D", C.c_int32), ("F", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("k", C.c_int32),
+                ("ew", EmbedWeights), ("gw", GruWeights),
+                ("embed_ws", C.c_void_p), ("gru_ws", C.c_void_p), ("proj_table", C.c_void_p), ("status", C.c_void_p),
+                ("max_B", C.c_int64)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("neg", C.c_void_p), ("ts", C.c_void_p), ("eidx", C.c_void_p),
+                ("B", C.c_int64)]
+
+
 _lib = None
 
 
@@ -60,6 +77,8 @@ def lib():
                 "(hipcc, --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
         _lib = C.CDLL(LIB_PATH)
         _lib.zt_last_error.restype = C.c_char_p
+        if hasattr(_lib, "zt_pipeline_main_stream"):
+            _lib.zt_pipeline_main_stream.restype = C.c_void_p
         _lib.zt_version.restype = C.c_char_p
         for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes", "zt_attention_workspace_bytes", "zt_project_table_bytes"):
             if hasattr(_lib, name):

@@ -22,6 +22,7 @@ SOURCES = {
     "aggregate.hip": [],
     "memory_update.hip": [],
     "attention.hip": [],
+    "pipeline.hip": [],
     "test_hooks.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

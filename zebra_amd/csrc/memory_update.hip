@@ -386,7 +386,7 @@ extern "C" int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t m
 extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const float *messages_dev,
                              const float *msg_ts_dev, uint8_t *flags_dev, int64_t num_nodes, int32_t D,
                              int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids, const int32_t *n_ids_dev,
-                             const zt_gru_weights *wt, void *workspace_dev, void *stream)
+                             const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready, void *stream)
 {
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
@@ -409,8 +409,10 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     ZT_PROF_BEGIN(s, P_GRU);
     k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
                                                                       rows, cnt);
-    k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
-    k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
+    if (!weights_ready) {                       // gate-packed, padded copies: once per weight change and max_rows
+        k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
+        k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
+    }
     static size_t attr_lds = 0;
     if (p.lds > 48 * 1024 && p.lds > attr_lds) {
         ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru), hipFuncAttributeMaxDynamicSharedMemorySize,

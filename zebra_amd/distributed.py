@@ -22,6 +22,7 @@ world_size-2 CPU tests cover; on the GPU the pack and the scatter are one HIP
 kernel each (``zt_pack_rows`` / ``zt_scatter_rows``, tested against the torch
 form) and the step never synchronises with the host.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -136,35 +137,21 @@ class ShardedTGN:
     @torch.no_grad()
     def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):
         tgn = self.tgn
-        em = tgn.embedding_module
-        if not tgn.test_mode:
-            tgn.update_memory_in_test(tgn.memory)
-            tgn.test_mode = True
         B = src_d.numel()
         r0, r1 = shard_range(3 * B, self.rank, self.world)
-        if em.tppr_strategy == "pruning":
-            # the pruning query reads only the static adjacency: rows are independent, so P1 shards with P2
-            nodes_d = torch.cat([src_d, dst_d, neg_d])
-            ts3 = torch.cat([ts_d, ts_d, ts_d])
-            mine = nodes_d[r0:r1].contiguous()
-            on, oe, od, ow = em.pruning_topk_device(mine, ts3[r0:r1].contiguous(), check_status=check_status)
-            emb = em.embed_device(tgn.memory.memory, mine, on, oe, od, ow, check_status=check_status,
-                                  memory_obj=tgn.memory)
-        else:
-            nodes_d, on, oe, od, ow = tgn.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch,
-                                                            check_status, plan)                    # replicated
-            emb = em.embed_device(tgn.memory.memory, nodes_d[r0:r1].contiguous(), on[:, r0:r1].contiguous(),
-                                  oe[:, r0:r1].contiguous(), od[:, r0:r1].contiguous(), ow[:, r0:r1].contiguous(),
-                                  check_status=check_status, memory_obj=tgn.memory)
         p0, p1 = shard_range(2 * B, self.rank, self.world)
-        tgn.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=(p0, p1))
-        # only this rank's winners are flagged: the GRU compacts them out of the endpoint list
-        tgn.memory_updater.update_device(tgn.memory, nodes_d[: 2 * B], 2 * B)
-        rows, count = tgn.memory_updater.last_rows()
-        m = tgn.memory
-        got = exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,
-                                    shard_capacity(2 * B, self.world), self.group)
-        hook = getattr(m, "_rows_changed", None)
-        if hook is not None and torch.is_tensor(got):          # rows the other ranks rewrote: the projected table follows
-            hook(got, None, got.numel())
+        main = getattr(tgn, "main_stream", None)
+        ctx = torch.cuda.stream(main) if main is not None else contextlib.nullcontext()
+        with ctx:
+            # P1 streaming: whole batch on every rank (replicas stay bit-identical); P1 pruning, P2: rows [r0, r1);
+            # P3: winners at positions [p0, p1) -- only this rank's winners are flagged, the GRU compacts them
+            emb = tgn.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=check_status, prefetch=prefetch,
+                                  plan=plan, rows=(r0, r1), positions=(p0, p1))
+            rows, count = tgn.memory_updater.last_rows()
+            m = tgn.memory
+            got = exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,
+                                        shard_capacity(2 * B, self.world), self.group)
+            hook = getattr(m, "_rows_changed", None)
+            if hook is not None and torch.is_tensor(got):      # rows the other ranks rewrote: the projected table follows
+                hook(got, None, got.numel())
         return emb

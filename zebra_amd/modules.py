@@ -168,10 +168,15 @@ class GRUMemoryUpdater(nn.Module):
         if max_rows == 0:
             return
         ws = self._workspace(max_rows, D)
+        g = self.memory_updater
+        key = (ws.data_ptr(), max_rows) + tuple((t.data_ptr(), t._version) for t in (g.weight_ih, g.weight_hh))
+        ready = key == getattr(self, "_ws_key", None)
         check(lib().zt_gru_update(ptr(memory.memory), ptr(memory.last_update), ptr(memory.messages),
                                   ptr(memory.timestamps), ptr(memory._flag_buf), C.c_int64(memory.n_nodes),
                                   C.c_int32(D), C.c_int32(self.message_dimension), ptr(ids_d), C.c_int64(n_ids),
-                                  ptr(n_ids_d), C.byref(self._weights()), ptr(ws), stream_ptr()), "zt_gru_update")
+                                  ptr(n_ids_d), C.byref(self._weights()), ptr(ws), C.c_int32(1 if ready else 0),
+                                  stream_ptr()), "zt_gru_update")
+        self._ws_key = key
         hook = getattr(memory, "_rows_changed", None)
         if hook is not None:                       # e.g. the embedding module's projected table follows the rows
             rows, count = self.last_rows()

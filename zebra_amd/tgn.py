@@ -12,6 +12,7 @@ import logging
 import numpy as np
 import torch
 
+from . import _capi
 from ._capi import check, lib, ptr, stream_ptr
 from .modules import Memory, MergeLayer, TimeEncode, get_embedding_module, get_memory_updater
 
@@ -99,111 +100,155 @@ class TGN(torch.nn.Module):
                                       None, ptr(self._status), stream_ptr()), "zt_store_messages")
         return B
 
-    # -- P1 on a side stream: the T-PPR state depends only on the edge stream, never on the node
-    # -- memory, so the query of batch b+1 can run while batch b is being aggregated / written back.
-    def enable_pipeline(self, on=True, tppr_cus=0):
-        """Run the T-PPR query on its own HIP stream and allow ``prefetch`` in step_device.
-        ``tppr_cus`` > 0 pins that stream to the first tppr_cus compute units (CU mask) and the
-        caller should run everything else on ``self.main_stream`` (the remaining CUs)."""
-        self._pending = None
-        self._planned = {}
-        self._plan_stream = None
-        self.main_stream = None
-        for hptr in getattr(self, "_masked", []):          # CU-masked streams of an earlier call
+    # -- the step as ONE native call (csrc/pipeline.hip): P1 of batch b+1 on a side stream beside P2 + P3 of batch b
+    def enable_pipeline(self, on=True, tppr_cus=0, max_batch=8192):
+        """Create (or drop) the native step pipeline.  ``tppr_cus`` > 0 pins the T-PPR stream to the first
+        tppr_cus compute units (CU mask) and everything else to the rest; callers run their own work on
+        ``self.main_stream``.  With it, ``step_device`` takes ``prefetch`` (the NEXT batch: its T-PPR query is
+        issued at once -- it must be the batch of the next call) and ``plan`` (the one after it)."""
+        if getattr(self, "_pipe", None) is not None:
             torch.cuda.synchronize(self.device)
-            check(lib().zt_stream_destroy(C.c_void_p(hptr)))
-        self._masked = []
+            check(lib().zt_pipeline_destroy(self._pipe))
+        self._pipe = None
+        self._pipe_sig = None
+        self._pipe_keep = None
+        self.main_stream = None
         if not on:
-            self._side = None
             return
-        self._plan_stream = torch.cuda.Stream(device=self.device)
-        if tppr_cus > 0:
-            n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            hs, hm = C.c_void_p(), C.c_void_p()
-            check(lib().zt_stream_create_masked(C.byref(hs), C.c_int32(0), C.c_int32(tppr_cus)))
-            check(lib().zt_stream_create_masked(C.byref(hm), C.c_int32(tppr_cus), C.c_int32(n_cu)))
-            self._masked = [hs.value, hm.value]
-            self._side = torch.cuda.ExternalStream(hs.value, device=self.device)
-            self.main_stream = torch.cuda.ExternalStream(hm.value, device=self.device)
-        else:
-            self._side = torch.cuda.Stream(device=self.device)
+        self._pipe_args = (int(tppr_cus), int(max_batch))
+        self._pipe_refresh(create=True)
 
-    def plan_batch(self, batch):
-        """Pipeline mode, streaming T-PPR: the dependency prepass of a batch still two steps away, on
-        its own stream (it reads only the ids and overlaps the update kernel of the batch before)."""
-        em = self.embedding_module
-        if getattr(self, "_side", None) is None or em.tppr_strategy != "streaming":
+    def _pipe_signature(self):
+        """Everything the native pipeline holds pointers to: (tables, weight versions)."""
+        em, m, g = self.embedding_module, self.memory, self.memory_updater.memory_updater
+        nf = self.embedding_module.neighbor_finder
+        tables = (m.memory.data_ptr(), m.last_update.data_ptr(), m.messages.data_ptr(), m.timestamps.data_ptr(),
+                  m._flag_buf.data_ptr(), self.edge_raw_features.data_ptr(),
+                  em.tppr_finder._live.h.value if em.tppr_strategy == "streaming" else nf._h.value)
+        weights = em._weights_key() + tuple((t.data_ptr(), t._version) for t in (g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh))
+        return tables, weights
+
+    def _pipe_refresh(self, create=False):
+        """(Re)build the descriptor when a table was replaced (restore_memory, __init_memory__, a new neighbour
+        finder, restore_tppr) or a weight changed in place; cheap when nothing did.  Runs on the main stream."""
+        sig = self._pipe_signature()
+        if not create and sig == self._pipe_sig:
             return
-        src_d, dst_d, neg_d, _, eidx_d = batch
-        with torch.cuda.stream(self._plan_stream):
-            nodes_d = torch.cat([src_d, dst_d, neg_d])
-            token = em.tppr_finder.plan_device(nodes_d, eidx_d, 3, -1)
-        nodes_d.record_stream(self._side)
-        self._planned[(eidx_d.data_ptr(), eidx_d.numel())] = (nodes_d, token)
-
-    def _tppr_launch(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status):
-        em = self.embedding_module
-        nodes_d, token = getattr(self, "_planned", {}).pop((eidx_d.data_ptr(), eidx_d.numel()), (None, 0))
-        if nodes_d is None:
-            nodes_d = torch.cat([src_d, dst_d, neg_d])
-        ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
-        return (nodes_d,) + tuple(em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status, plan_token=token))
-
-    def tppr_batch_device(self, batch, prefetch=None, check_status=False, plan=None):
-        """T-PPR query of ``batch`` = (src, dst, neg, ts, eidx) -> (nodes, nbr, eidx, dt, w) device
-        tensors, valid on the current stream.  With the pipeline enabled, ``prefetch`` (the NEXT
-        batch) is enqueued on the side stream before returning."""
-        side = getattr(self, "_side", None)
-        if side is None:
-            return self._tppr_launch(*batch, check_status)
-        main = torch.cuda.current_stream()
-        key = (batch[4].data_ptr(), batch[4].numel())
-        if self._pending is not None and self._pending[0] == key:
-            _, outs, ev = self._pending
+        em, m, mu = self.embedding_module, self.memory, self.memory_updater
+        tppr_cus, max_b = self._pipe_args
+        D, F, T = self.memory_dimension, self.n_edge_features, self.time_dimension
+        em._ws_shape = max(3 * max_b, em._ws_shape or 0)
+        ws, _, _ = em._workspace(em._ws_shape)
+        gws = mu._workspace(2 * max_b, D)
+        table = em._projection(m)                       # rebuilt here if the memory or W_m changed
+        if em._status is None:
+            em._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        d = _capi.PipelineDesc()
+        if em.tppr_strategy == "streaming":
+            d.tppr = em.tppr_finder._live.h
         else:
-            with torch.cuda.stream(side):
-                outs = self._tppr_launch(*batch, False)
-                ev = torch.cuda.Event()
-                ev.record(side)
-        self._pending = None
-        main.wait_event(ev)
-        for t in outs:
-            t.record_stream(main)
-        if prefetch is not None:
-            with torch.cuda.stream(side):
-                nxt = self._tppr_launch(*prefetch, False)
-                ev2 = torch.cuda.Event()
-                ev2.record(side)
-            self._pending = ((prefetch[4].data_ptr(), prefetch[4].numel()), nxt, ev2)
-        if plan is not None:
-            self.plan_batch(plan)
-        if check_status and self.embedding_module.tppr_strategy == "streaming":
-            self.embedding_module.tppr_finder.check_status()
-        return outs
+            d.csr = em.neighbor_finder._h
+            d.width, d.depth = em.width, em.depth
+            for q, (a, bb) in enumerate(zip(em.alpha_list, em.beta_list)):
+                d.alpha[q], d.beta[q] = float(a), float(bb)
+        d.memory, d.last_update, d.messages, d.msg_ts = (m.memory.data_ptr(), m.last_update.data_ptr(),
+                                                         m.messages.data_ptr(), m.timestamps.data_ptr())
+        d.flags, d.scratch, d.efeat = m._flag_buf.data_ptr(), self._scratch.data_ptr(), self.edge_raw_features.data_ptr()
+        d.num_nodes, d.num_edges = m.n_nodes, self.edge_raw_features.shape[0]
+        d.D, d.F, d.T, d.M, d.k = D, F, T, em.n_tppr, em.k
+        d.ew, d.gw = em._embed_weights(), mu._weights()
+        d.embed_ws, d.gru_ws = ws.data_ptr(), gws.data_ptr()
+        d.proj_table = table.data_ptr() if table is not None else None
+        d.status = em._status.data_ptr()
+        d.max_B = max_b
+        self._pipe_keep = (ws, gws, table, d)
+        if create:
+            h = C.c_void_p()
+            check(lib().zt_pipeline_create(C.byref(h), C.byref(d), C.c_int32(tppr_cus)), "zt_pipeline_create")
+            self._pipe = h
+            self.main_stream = torch.cuda.ExternalStream(lib().zt_pipeline_main_stream(h), device=self.device)
+        else:
+            check(lib().zt_pipeline_update(self._pipe, C.byref(d), C.c_int32(1)), "zt_pipeline_update")
+        em._ws_key = None                               # the pipeline remakes the padded weights at its next step
+        mu._ws_key = None
+        self._pipe_sig = self._pipe_signature()
+
+    @staticmethod
+    def _batch_struct(batch):
+        b = _capi.Batch()
+        b.src, b.dst, b.neg, b.ts, b.eidx = [t.data_ptr() for t in batch]
+        b.B = batch[0].numel()
+        return b
+
+    def _pipe_step(self, batch, prefetch, plan, rows=None, positions=None):
+        """zt_pipeline_step; returns the embeddings of ``rows`` (valid on the caller's current stream)."""
+        caller = torch.cuda.current_stream(self.device)
+        foreign = caller.cuda_stream != self.main_stream.cuda_stream
+        if foreign:                                     # inputs produced on the caller's stream
+            self.main_stream.wait_stream(caller)
+        with torch.cuda.stream(self.main_stream):
+            out = self._pipe_step_main(batch, prefetch, plan, rows, positions)
+        if foreign:
+            caller.wait_stream(self.main_stream)
+            out.record_stream(caller)
+        return out
+
+    def _pipe_step_main(self, batch, prefetch, plan, rows, positions):
+        self._pipe_refresh()
+        B = batch[0].numel()
+        r0, r1 = rows if rows is not None else (0, 3 * B)
+        p0, p1 = positions if positions is not None else (0, 2 * B)
+        em = self.embedding_module
+        out = torch.empty((r1 - r0, self.embedding_dimension * (em.n_tppr + 1)), dtype=torch.float32, device=self.device)
+        cur = self._batch_struct(batch)
+        nxt = self._batch_struct(prefetch) if prefetch is not None else None
+        pln = self._batch_struct(plan) if plan is not None else None
+        check(lib().zt_pipeline_step(self._pipe, C.byref(cur), C.byref(nxt) if nxt is not None else None,
+                                     C.byref(pln) if pln is not None else None, C.c_int64(r0), C.c_int64(r1),
+                                     C.c_int64(p0), C.c_int64(p1), ptr(out)), "zt_pipeline_step")
+        return out
 
     @torch.no_grad()
     def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None,
-                    stats=False):
+                    stats=False, rows=None, positions=None):
         """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
         int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
-        ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings.
-        ``prefetch`` = the next batch's five tensors, ``plan`` = the one after it (pipeline mode only)."""
+        ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings (or those of ``rows`` = (lo, hi);
+        ``positions`` = (lo, hi) restricts the memory update to winners at those batch positions: the two
+        are how a multi-GPU run shards a batch).  With ``enable_pipeline``: ``prefetch`` = the next batch's
+        five tensors (queried at once), ``plan`` = the one after it; call from ``self.main_stream``."""
         if not self.test_mode:
             self.update_memory_in_test(self.memory)
             self.test_mode = True
         em = self.embedding_module
-        nodes_d, on, oe, od, ow = self.tppr_batch_device((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, check_status,
-                                                        plan)
-        if stats:                                    # average_topk (modules/embedding_module.py:232-233)
-            em._avg_topk_t = ow[0, : 2 * src_d.numel()].sum(dim=1).mean()
-        emb = em.embed_device(self.memory.memory, nodes_d, on, oe, od, ow, check_status=check_status,
-                              memory_obj=self.memory)
-        B = self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
-        self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each
+        B = src_d.numel()
+        if getattr(self, "_pipe", None) is not None and not stats:
+            emb = self._pipe_step((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, plan, rows, positions)
+        else:
+            nodes_d = torch.cat([src_d, dst_d, neg_d])
+            ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
+            r0, r1 = rows if rows is not None else (0, 3 * B)
+            if em.tppr_strategy == "pruning" and rows is not None:       # rows are independent: query the shard only
+                on, oe, od, ow = em.pruning_topk_device(nodes_d[r0:r1].contiguous(), ts3[r0:r1].contiguous(),
+                                                        check_status=check_status)
+            else:
+                on, oe, od, ow = em.topk_device(nodes_d, ts3, eidx_d, check_status=check_status)
+                if stats:                                # average_topk (modules/embedding_module.py:232-233)
+                    em._avg_topk_t = ow[0, : 2 * B].sum(dim=1).mean()
+                if rows is not None:
+                    on, oe, od, ow = [t[:, r0:r1].contiguous() for t in (on, oe, od, ow)]
+            emb = em.embed_device(self.memory.memory, nodes_d[r0:r1].contiguous() if rows is not None else nodes_d,
+                                  on, oe, od, ow, check_status=check_status, memory_obj=self.memory)
+            self.store_messages_device(src_d, dst_d, ts_d, eidx_d, pos_range=positions)
+            self.memory_updater.update_device(self.memory, nodes_d[: 2 * B], 2 * B)      # [src | dst], flagged once each
         if check_status:
-            st = int(self._status.item())
+            if em.tppr_strategy == "streaming":
+                em.tppr_finder.check_status()
+            st = int(self._status.item()) or (int(em._status.item()) if em._status is not None else 0)
             if st != 0:
                 self._status.zero_()
+                if em._status is not None:
+                    em._status.zero_()
                 raise IndexError("node / edge id out of range (status %d)" % st)
         return emb
 
