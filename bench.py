@@ -272,9 +272,12 @@ def main():
             tgn.enable_pipeline(tppr_cus=0)
     main_stream = getattr(tgn, "main_stream", None)
 
+    # views of every batch, made once: slicing tensors is host work that is not part of the path
+    batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
+                ts_d[b * bs:(b + 1) * bs], eidx_d[b * bs:(b + 1) * bs]) for b in range(n_steps_total)]
+
     def batch(b):
-        s, e = b * bs, (b + 1) * bs
-        return src_d[s:e], dst_d[s:e], neg_d[s:e], ts_d[s:e], eidx_d[s:e]
+        return batches[b]
 
     def run(b0, nb):
         # exactly nb steps; nothing of step b0+nb is enqueued (no prefetch on the last one)

@@ -112,6 +112,7 @@ class TGN(torch.nn.Module):
         self._pipe = None
         self._pipe_sig = None
         self._pipe_keep = None
+        self._batch_cache = {}
         self.main_stream = None
         if not on:
             return
@@ -120,12 +121,15 @@ class TGN(torch.nn.Module):
 
     def _pipe_signature(self):
         """Everything the native pipeline holds pointers to: (tables, weight versions)."""
+        # identity of every table / handle object and in-place version of every weight (the objects are kept
+        # alive by _pipe_keep, so an id cannot be recycled while it is part of the signature)
         em, m, g = self.embedding_module, self.memory, self.memory_updater.memory_updater
-        nf = self.embedding_module.neighbor_finder
-        tables = (m.memory.data_ptr(), m.last_update.data_ptr(), m.messages.data_ptr(), m.timestamps.data_ptr(),
-                  m._flag_buf.data_ptr(), self.edge_raw_features.data_ptr(),
-                  em.tppr_finder._live.h.value if em.tppr_strategy == "streaming" else nf._h.value)
-        weights = em._weights_key() + tuple((t.data_ptr(), t._version) for t in (g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh))
+        tables = (id(m.memory), m.memory._version, id(m.last_update), id(m.messages), id(m.timestamps), id(m._flag_buf),
+                  id(self.edge_raw_features),
+                  id(em.tppr_finder._live) if em.tppr_strategy == "streaming" else id(em.neighbor_finder))
+        weights = tuple((id(t), t._version) for t in (em.fc1.weight, em.fc1.bias, em.fc2.weight, em.fc2.bias,
+                                                      em.fc1_source.weight, em.fc1_source.bias, em.fc2_source.weight,
+                                                      em.fc2_source.bias, g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh))
         return tables, weights
 
     def _pipe_refresh(self, create=False):
@@ -161,7 +165,8 @@ class TGN(torch.nn.Module):
         d.proj_table = table.data_ptr() if table is not None else None
         d.status = em._status.data_ptr()
         d.max_B = max_b
-        self._pipe_keep = (ws, gws, table, d)
+        self._pipe_keep = (ws, gws, table, d, m.memory, m.last_update, m.messages, m.timestamps, m._flag_buf,
+                           em.tppr_finder._live if em.tppr_strategy == "streaming" else em.neighbor_finder)
         if create:
             h = C.c_void_p()
             check(lib().zt_pipeline_create(C.byref(h), C.byref(d), C.c_int32(tppr_cus)), "zt_pipeline_create")
@@ -173,24 +178,32 @@ class TGN(torch.nn.Module):
         mu._ws_key = None
         self._pipe_sig = self._pipe_signature()
 
-    @staticmethod
-    def _batch_struct(batch):
+    def _batch_struct(self, batch):
+        """zt_batch of five device tensors; remembered by the identity of the edge-id tensor (a batch is
+        presented three times: as plan, as prefetch, as the current one)."""
+        cache = self._batch_cache
+        key = id(batch[4])
+        hit = cache.get(key)
+        if hit is not None and hit[0] is batch[4]:
+            return hit[1]
         b = _capi.Batch()
         b.src, b.dst, b.neg, b.ts, b.eidx = [t.data_ptr() for t in batch]
         b.B = batch[0].numel()
+        if len(cache) > 16:
+            cache.clear()
+        cache[key] = (batch[4], b)
         return b
 
     def _pipe_step(self, batch, prefetch, plan, rows=None, positions=None):
         """zt_pipeline_step; returns the embeddings of ``rows`` (valid on the caller's current stream)."""
         caller = torch.cuda.current_stream(self.device)
-        foreign = caller.cuda_stream != self.main_stream.cuda_stream
-        if foreign:                                     # inputs produced on the caller's stream
-            self.main_stream.wait_stream(caller)
+        if caller.cuda_stream == self.main_stream.cuda_stream:
+            return self._pipe_step_main(batch, prefetch, plan, rows, positions)
+        self.main_stream.wait_stream(caller)            # inputs produced on the caller's stream
         with torch.cuda.stream(self.main_stream):
             out = self._pipe_step_main(batch, prefetch, plan, rows, positions)
-        if foreign:
-            caller.wait_stream(self.main_stream)
-            out.record_stream(caller)
+        caller.wait_stream(self.main_stream)
+        out.record_stream(caller)
         return out
 
     def _pipe_step_main(self, batch, prefetch, plan, rows, positions):
