@@ -245,6 +245,30 @@ int zt_project_memory(const float *memory_dev, int64_t num_nodes, int32_t D,
                       void *workspace_dev, int64_t ws_N, int32_t ws_M, int32_t ws_k,
                       void *stream);
 
+/* Training path of the same aggregation: modules/embedding_module.py:227-276 with
+ * train=True.  The reference clones the whole memory table per batch (modules/memory_updater.py:79) and lets
+ * autograd walk an [N,k,2D+F] tensor; here the lazily updated rows are a compact overlay
+ * (row_map_dev[v] = overlay row of node v or -1; NULL = no overlay) and the backward is one fused kernel.
+ *   forward : H_dev [M][N][D] = sum_k w_k/sum(w) relu(fc1([memory'[nbr] | ef | cos])), S_dev [M][N] = (sum w != 0)
+ *   backward: from dH_dev [M][N][D] ACCUMULATES (+=) dW1_dev [D][D+F+T], db1_dev [D] and d_overlay_dev [U][D]
+ *             (the gradient wrt the overlay rows; stored memory rows carry none)
+ * fc2 and transform_source act on [N, D] matrices and stay plain GEMMs outside.
+ * workspaces: zt_embed_workspace_bytes(N, ...) / zt_agg_backward_workspace_bytes(D, F, T). */
+int zt_agg_train_forward(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
+                         const float *efeat_dev, int64_t num_nodes, int64_t num_edges, int32_t D,
+                         int32_t F, int32_t T, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev,
+                         const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                         const zt_embed_weights *weights, float *H_dev, float *S_dev,
+                         void *workspace_dev, int32_t *status_dev, void *stream);
+int64_t zt_agg_backward_workspace_bytes(int32_t D, int32_t F, int32_t T);
+int zt_agg_train_backward(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
+                          const float *efeat_dev, const float *time_w_dev, int64_t num_nodes,
+                          int64_t num_edges, int32_t D, int32_t F, int32_t T, int64_t N, int32_t M,
+                          int32_t k, const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev,
+                          const float *w_dev, const float *fc1_w_dev, const float *fc1_b_dev,
+                          const float *dH_dev, float *dW1_dev, float *db1_dev, float *d_overlay_dev,
+                          void *workspace_dev, void *stream);
+
 /* ------------------------------------------------------------------------ */
 /* Memory: last-message store + GRU update                                   */
 /* ------------------------------------------------------------------------ */

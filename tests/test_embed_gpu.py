@@ -637,3 +637,48 @@ def test_projected_table_follows_memory_and_weights(oracle, F):
         t.memory.__init_memory__()
     p.init_memory()
     step(2000, 2250)
+
+
+@pytest.mark.parametrize("F,k", [(1, 20), (172, 20), (4, 40)])
+def test_fused_training_backward_full_dims(F, k):
+    """The fused HIP training path (overlay forward + k_fc1_agg_bwd) at the real layer sizes (D = T = 100,
+    two T-PPR models) against the torch composition of the same step, which fixture g8_train_grads pins to the
+    reference at small sizes.  The cotangent of the embeddings is a fixed random matrix (a linear loss), so
+    that nothing downstream -- a ReLU of the scorer sitting at zero -- can amplify rounding differences:
+    embeddings and the gradients of all embedding / GRU parameters must agree over dependent batches."""
+    D = T = 100
+    N, E, bs, al, be, seed = 900, 2400, 200, [0.1, 0.1], [0.5, 0.95], 210
+    src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+    w = I.model_weights(D, F, T, 2, seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    G = [torch.from_numpy(np.random.RandomState(700 + b).standard_normal((3 * bs, 3 * D)).astype(np.float32)).to(dev)
+         for b in range(6)]
+    res = {}
+    for fused in (True, False):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+        tgn.embedding_module.fused_training = fused
+        tgn.train(True)
+        out = []
+        for b in range(6):
+            s, e = b * bs, (b + 1) * bs
+            tgn.zero_grad()
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, True)
+            emb = torch.cat([se, de, ne])
+            (emb * G[b]).sum().backward()
+            out.append((emb.detach().cpu().numpy(), {pn: p.grad.detach().cpu().numpy().copy()
+                                                    for pn, p in tgn.named_parameters() if p.grad is not None}))
+        res[fused] = out
+    for b in range(6):
+        ea, ga = res[True][b]
+        eb, gb = res[False][b]
+        assert np.abs(ea - eb).max() <= 1e-5, "embeddings of batch %d" % b
+        assert set(ga) == set(gb) and len(ga) >= 8
+        for pn in ga:
+            # float32 sums in another order, and now and then a ReLU whose pre-activation is within rounding of
+            # zero (the two paths round the fc1 product differently): a flipped unit changes one row of a gradient
+            # by one term.  So: all but a sliver of the elements to 1e-4 of the scale, the whole to 2e-3 in norm.
+            d, scale = np.abs(ga[pn] - gb[pn]), max(1.0, np.abs(gb[pn]).max())
+            assert (d > 1e-4 * scale).mean() <= 0.01, "%s in batch %d: %.3g of the elements differ" % (pn, b, (d > 1e-4 * scale).mean())
+            assert np.linalg.norm(ga[pn] - gb[pn]) <= 2e-3 * max(1.0, np.linalg.norm(gb[pn])), "%s in batch %d" % (pn, b)
+    assert any(np.abs(res[True][b][1]["memory_updater.memory_updater.weight_ih"]).max() > 0 for b in range(1, 6))

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     long long num_nodes, long long num_edges, int D, int F, int T, long long N, int k, int rq, int mt_count, int lda,
     const int *__restrict__ nbr, const int *__restrict__ eix, const float *__restrict__ dt,
     const float *__restrict__ w, const float *__restrict__ W1p, int K1p, const float *__restrict__ b1,
-    float *__restrict__ H, float *__restrict__ S, int *status, int Dout)
+    float *__restrict__ H, float *__restrict__ S, int *status, int Dout, const int *__restrict__ row_map,
+    const float *__restrict__ overlay)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);                       // [mt*16][lda]
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 atomicExch(status, ZT_ERR_RANGE);
                 nb = 0; ei = 0;
             }
+            // training: rows of the lazily updated memory live in a compact overlay (aggregate_bwd.hip)
+            if (!TAB && row_map != nullptr) { const int ov = row_map[nb]; if (ov >= 0) nb = -ov - 1; }
         }
         g_nb[g] = nb; g_ei[g] = ei; g_dt[g] = d; wn[g] = wv;
     }
@@ -133,6 +136,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         if (tid % k == 0) S[(size_t)m * N + q0 + tid / k] = (my_sum == 0.f) ? 0.f : 1.f;
     }
 
+    auto mem_row = [&](int s) { return s >= 0 ? memory + (size_t)s * D : overlay + (size_t)(-s - 1) * D; };
     AGG_STAMP(0);
     // accumulators: zero, or (TAB) the projected rows P[nbr[row]][col] -- issued before the staging below so that the
     // memory round trip is hidden behind it; the MFMAs then accumulate on top of them
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
             for (int u = 0; u < GU; ++u) {
                 const int f = tid + u * AGG_THREADS;
                 const int g = fastdiv(f, mD4), c = f - g * D4;
-                vm[u] = (f < rows_p * D4 && g < rows) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
+                vm[u] = (f < rows_p * D4 && g < rows) ? *reinterpret_cast<const f32x4 *>(mem_row(g_nb[g]) + 4 * c)
                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 const int f = f0 + u * AGG_THREADS;
                 const int g = fastdiv(f, mD4), c = f - g * D4;
                 v[u] = (f < rows_p * D4 && g < rows)
-                           ? *reinterpret_cast<const f32x4 *>(memory + (size_t)g_nb[g] * D + 4 * c)
+                           ? *reinterpret_cast<const f32x4 *>(mem_row(g_nb[g]) + 4 * c)
                            : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
             for (int u = 0; u < GU; ++u) {
                 const int f = f0 + u * AGG_THREADS;
                 const int g = fastdiv(f, mD), c = f - g * D;
-                v[u] = (f < rows_p * D && g < rows) ? memory[(size_t)g_nb[g] * D + c] : 0.f;
+                v[u] = (f < rows_p * D && g < rows) ? mem_row(g_nb[g])[c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < GU; ++u) {
@@ -736,12 +740,12 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
         k_fc1_agg<true><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
                                                        T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,
-                                                       p.K2p, wt->fc1_b, H, S, status_dev, D);
+                                                       p.K2p, wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
     } else {
         dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
         k_fc1_agg<false><<<grid, AGG_THREADS, lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N,
                                                         k, p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
-                                                        wt->fc1_b, H, S, status_dev, D);
+                                                        wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
     }
     ZT_PROF_END(s, P_FC1_AGG);
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
@@ -750,6 +754,47 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
         out_dev, status_dev);
     ZT_PROF_END(s, P_EMBED_OUT);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+// Training forward of the neighbour half (backward: aggregate_bwd.hip):
+//   H[m][n][:] = sum_k w_k/sum(w) relu(fc1([memory'[nbr] | ef | cos(dt w)])),  S[m][n] = (sum_k w != 0)
+// where memory'[v] = overlay[row_map[v]] if row_map[v] >= 0 (rows of the lazily updated memory,
+// modules/memory_updater.py:61-90) else memory[v].  fc2 and the source transform run on the [N, D] results
+// outside (plain GEMMs).  workspace: zt_embed_workspace_bytes(N, D, F, T, M, k).
+extern "C" int zt_agg_train_forward(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
+                                    const float *efeat_dev, int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F,
+                                    int32_t T, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev,
+                                    const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                                    const zt_embed_weights *wt, float *H_dev, float *S_dev, void *workspace_dev,
+                                    int32_t *status_dev, void *stream)
+{
+    if (!memory_dev || !efeat_dev || !wt || !status_dev || !H_dev || !S_dev || !workspace_dev || N < 0 || D <= 0 || F < 0 ||
+        T < 0 || M <= 0 || k <= 0 || (row_map_dev != nullptr && !overlay_dev)) {
+        set_error("zt_agg_train_forward: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (N == 0) return ZT_OK;
+    EmbedPlan p;
+    if (D > 128 || !make_plan(N, D, F, T, M, k, p)) {
+        set_error("zt_agg_train_forward: unsupported shape");
+        return ZT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    embed_prepare(wt, D, F, T, p, ws, s);          // the weights change every optimizer step
+    static size_t attr_lds = 0;
+    if (p.lds > 48 * 1024 && p.lds > attr_lds) {
+        ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fc1_agg<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+        attr_lds = p.lds;
+    }
+    dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
+    k_fc1_agg<false><<<grid, AGG_THREADS, p.lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N, k,
+                                                    p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev,
+                                                    reinterpret_cast<const float *>(ws + p.off_w1p), p.K1p, wt->fc1_b, H_dev,
+                                                    S_dev, status_dev, D, row_map_dev, overlay_dev);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -94,6 +94,14 @@ class Memory(nn.Module):
     def flags(self):
         return self._flag_buf[: self.n_nodes]
 
+    def row_map(self):
+        """int32[n_nodes], all -1 between uses: node -> row of a compact overlay (the training forward's
+        lazily updated rows, GraphDiffusionEmbedding._train_forward)."""
+        rm = getattr(self, "_row_map", None)
+        if rm is None or rm.numel() != self.n_nodes or rm.device != self.memory.device:
+            rm = self._row_map = torch.full((self.n_nodes,), -1, dtype=torch.int32, device=self.memory.device)
+        return rm
+
     @property
     def nodes(self):
         return self.flags.cpu().numpy().astype(bool)
@@ -218,6 +226,63 @@ def get_memory_updater(module_type, message_dimension, memory_dimension, device)
     if module_type != "gru":
         raise ValueError("only the GRU memory updater is on the accelerated path (got %r)" % module_type)
     return GRUMemoryUpdater(message_dimension, memory_dimension, device)
+
+
+class _NeighbourAggregate(torch.autograd.Function):
+    """H[m][n] = sum_k w_k/sum(w) relu(fc1([memory'[nbr] | ef | cos(dt w)])), S[m][n] = (sum_k w != 0) with
+    memory' = overlay rows where row_map says so (zt_agg_train_forward / zt_agg_train_backward)."""
+
+    @staticmethod
+    def forward(ctx, overlay, fc1_w, fc1_b, em, memory_t, row_map, ids32, on, oe, od, ow):
+        M, N, k = on.shape
+        D, F, T = em.embedding_dimension, em.n_edge_features, em.n_time_features
+        need = lib().zt_embed_workspace_bytes(C.c_int64(N), C.c_int32(D), C.c_int32(F), C.c_int32(T), C.c_int32(M),
+                                              C.c_int32(k))
+        if need < 0:
+            raise ValueError("zt_agg_train_forward: unsupported shape")
+        ws = torch.empty(int(need), dtype=torch.uint8, device=on.device)
+        H = torch.empty((M, N, D), dtype=torch.float32, device=on.device)
+        S = torch.empty((M, N), dtype=torch.float32, device=on.device)
+        if em._status is None:
+            em._status = torch.zeros(1, dtype=torch.int32, device=on.device)
+        ov = overlay.detach().contiguous()
+        use_map = ids32 is not None
+        check(lib().zt_agg_train_forward(ptr(memory_t), ptr(ov) if use_map else None, ptr(row_map) if use_map else None,
+                                         ptr(em.edge_features), C.c_int64(memory_t.shape[0]),
+                                         C.c_int64(em.edge_features.shape[0]), C.c_int32(D), C.c_int32(F), C.c_int32(T),
+                                         C.c_int64(N), C.c_int32(M), C.c_int32(k), ptr(on), ptr(oe), ptr(od), ptr(ow),
+                                         C.byref(em._embed_weights()), ptr(H), ptr(S), ptr(ws), ptr(em._status),
+                                         stream_ptr()), "zt_agg_train_forward")
+        ctx.save_for_backward(ov, fc1_w, fc1_b)
+        ctx.misc = (em, memory_t, row_map, ids32, on, oe, od, ow)
+        ctx.mark_non_differentiable(S)
+        return H, S
+
+    @staticmethod
+    def backward(ctx, dH, dS):
+        ov, fc1_w, fc1_b = ctx.saved_tensors
+        em, memory_t, row_map, ids32, on, oe, od, ow = ctx.misc
+        M, N, k = on.shape
+        D, F, T = em.embedding_dimension, em.n_edge_features, em.n_time_features
+        dW1 = torch.zeros_like(fc1_w)
+        db1 = torch.zeros_like(fc1_b)
+        d_ov = torch.zeros_like(ov)
+        use_map = ids32 is not None
+        if use_map:                                       # the map is shared scratch: set for this call, reset after
+            row_map[ids32.long()] = torch.arange(ids32.numel(), dtype=torch.int32, device=ov.device)
+        ws = torch.empty(int(lib().zt_agg_backward_workspace_bytes(C.c_int32(D), C.c_int32(F), C.c_int32(T))),
+                         dtype=torch.uint8, device=ov.device)
+        w1 = fc1_w.detach().contiguous()
+        check(lib().zt_agg_train_backward(ptr(memory_t), ptr(ov) if use_map else None, ptr(row_map) if use_map else None,
+                                          ptr(em.edge_features), ptr(em.time_encoder.w.weight),
+                                          C.c_int64(memory_t.shape[0]), C.c_int64(em.edge_features.shape[0]), C.c_int32(D),
+                                          C.c_int32(F), C.c_int32(T), C.c_int64(N), C.c_int32(M), C.c_int32(k), ptr(on),
+                                          ptr(oe), ptr(od), ptr(ow), ptr(w1), ptr(fc1_b.detach()),
+                                          ptr(dH.contiguous()), ptr(dW1), ptr(db1), ptr(d_ov) if use_map else None,
+                                          ptr(ws), stream_ptr()), "zt_agg_train_backward")
+        if use_map:
+            row_map[ids32.long()] = -1
+        return d_ov, dW1, db1, None, None, None, None, None, None, None, None
 
 
 class GraphDiffusionEmbedding(nn.Module):
@@ -444,18 +509,52 @@ class GraphDiffusionEmbedding(nn.Module):
         return self._train_forward(memory, nodes_d, on, oe, od, ow, memory_updater)
 
     def _train_forward(self, memory, nodes_d, on, oe, od, ow, memory_updater):
-        """Autograd path (:227-276) composed from torch device ops."""
-        index = torch.unique(on.reshape(-1).long()).cpu().numpy()
-        mem, _ = memory_updater.get_updated_memory(memory, index)
-        embeddings = self.transform_source(mem[nodes_d.long()])
-        for m in range(self.n_tppr):
-            x = torch.cat([mem[on[m].long()], self.edge_features[oe[m].long(), :], self.time_encoder(od[m])], dim=-1)
+        """Autograd path (:227-276).  The lazily updated memory (get_updated_memory, which clones the whole
+        [N, D] table in the reference) is a compact OVERLAY here: the GRU runs on the flagged neighbour rows
+        only ([U, msg] x plain GEMMs, autograd to the GRU weights) and ``row_map`` says which nodes read their
+        row from it.  The neighbour half -- gather, TimeEncode, fc1, ReLU, weighted k-reduction -- is one
+        fused HIP kernel forward and one backward (csrc/aggregate_bwd.hip); fc2 and the source transform act
+        on [N, D] matrices."""
+        index = torch.unique(on.reshape(-1).long())
+        ids = index[memory.flags[index] != 0]                                   # neighbours with a pending message
+        U = int(ids.numel())
+        if U:
+            overlay = memory_updater.memory_updater(memory.messages[ids], memory.memory[ids])      # [U, D]
+        else:
+            overlay = torch.zeros((1, self.embedding_dimension), device=self.device)
+        row_map = memory.row_map()
+        ids32 = ids.to(torch.int32)
+        src_rows = memory.memory[nodes_d.long()]
+        if U:
+            row_map[ids] = torch.arange(U, dtype=torch.int32, device=self.device)
+            m = row_map[nodes_d.long()].long()
+            src_rows = torch.where((m >= 0).unsqueeze(1), overlay[m.clamp(min=0)], src_rows)
+        embeddings = self.transform_source(src_rows)
+        fused = (getattr(self, "fused_training", True) and not (self.training and self.drop.p > 0)
+                 and self.embedding_dimension <= 128)
+        if fused:
+            H, S = _NeighbourAggregate.apply(overlay, self.fc1.weight, self.fc1.bias, self, memory.memory, row_map,
+                                             ids32 if U else None, on, oe, od, ow)
+            if U:
+                row_map[ids] = -1
+            for m_ in range(self.n_tppr):
+                # fc2 is linear: sum_k w_k fc2(h_k) = fc2(sum_k w_k h_k) + b2 * [sum_k w_k != 0]
+                out = torch.nn.functional.linear(H[m_], self.fc2.weight) + self.fc2.bias * S[m_].unsqueeze(1)
+                embeddings = torch.cat((embeddings, out), dim=1)
+            return embeddings
+        # dropout inside the neighbour transform: composed from torch ops on the same overlay
+        mem_rows = lambda idx: memory.memory[idx] if not U else torch.where(
+            (row_map[idx] >= 0).unsqueeze(-1), overlay[row_map[idx].long().clamp(min=0)], memory.memory[idx])
+        for m_ in range(self.n_tppr):
+            x = torch.cat([mem_rows(on[m_].long()), self.edge_features[oe[m_].long(), :], self.time_encoder(od[m_])], dim=-1)
             x = self.transform(x)
-            w = ow[m]
+            w = ow[m_]
             ws = torch.sum(w, dim=1)
             w = w / ws.unsqueeze(1)
             w[ws == 0] = 0
             embeddings = torch.cat((embeddings, torch.sum(x * w[:, :, None], dim=1)), dim=1)
+        if U:
+            row_map[ids] = -1
         return embeddings
 
     def transform_source(self, x):
