@@ -98,3 +98,39 @@ def test_exchange_touched_rows_gloo(world):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
+
+
+def _grads_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from zebra_amd.distributed import allreduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+        frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+        x = torch.arange(28, dtype=torch.float32).reshape(4, 7) / 10 + rank
+        model(x).sum().backward()
+        if rank == 1:
+            model[2].bias.grad = None                        # a parameter unused on one rank still takes part
+        local = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [None if g is None else g.numpy() for g in local])
+        n = allreduce_gradients(list(model.parameters()) + [frozen], bucket_bytes=64)     # several small buckets
+        assert n >= 2
+        for q, p in enumerate(model.parameters()):
+            want = sum(torch.from_numpy(g[q]) for g in gathered if g[q] is not None)
+            assert torch.allclose(p.grad, want, atol=1e-6), q
+        out[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_gradients_gloo():
+    """The bucketed gradient all-reduce of data-parallel training (on GPUs: RCCL) with world_size 2 on gloo."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grads_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert len(out) == 2

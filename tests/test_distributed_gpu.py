@@ -121,3 +121,66 @@ def test_pack_scatter_rows_match_torch_form():
         torch.cuda.synchronize()
         for x, y in zip(a, b):
             assert torch.equal(x, y.cpu())
+
+
+def _train_run(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import build_tgn
+    from zebra_amd.distributed import ShardedTGN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        os.environ["ZT_STREAM_CHAINS"] = "0"
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, D, F, T, k, al, be, seed, bs = 300, 640, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 303, 160
+        src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+        w = I.model_weights(D, F, T, len(al), seed)
+        _, efeat = I.random_tables(N, E + 1, D, F, seed)
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+        tgn.train(True)
+        crit = torch.nn.BCELoss()
+        runner = ShardedTGN(tgn, rank, world)
+        res = []
+        for b in range(E // bs):
+            s, e = b * bs, (b + 1) * bs
+            tgn.zero_grad()
+            if world > 1:
+                loss = runner.train_step(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, crit)
+                lt = loss.clone().cpu()
+                dist.all_reduce(lt)                                   # shares of the loss add up
+                loss = float(lt)
+            else:
+                pos, negp = tgn.compute_edge_probabilities(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, True)
+                l = crit(pos.squeeze(), torch.ones(bs, device="cuda")) + crit(negp.squeeze(), torch.zeros(bs, device="cuda"))
+                l.backward()
+                loss = float(l)
+            res.append((loss, {pn: p.grad.detach().cpu().numpy().copy() for pn, p in tgn.named_parameters() if p.grad is not None}))
+        out[rank] = dict(steps=res, memory=tgn.memory.memory.cpu().numpy())
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_equals_single():
+    """two ranks, each embedding and scoring half of the batch's edges, gradients summed with
+    the bucketed all-reduce (gloo here, RCCL on a node): loss and all parameter gradients of four dependent
+    training steps equal the single-process step; the replicated state stays identical."""
+    mgr = mp.Manager()
+    ref, out = mgr.dict(), mgr.dict()
+    mp.spawn(_train_run, args=(1, _free_port(), ref), nprocs=1, join=True)
+    mp.spawn(_train_run, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        assert np.array_equal(out[r]["memory"], ref[0]["memory"])
+        for b, ((la, ga), (lb, gb)) in enumerate(zip(out[r]["steps"], ref[0]["steps"])):
+            assert abs(la - lb) <= 1e-5, "loss of step %d" % b
+            assert set(gb) <= set(ga)
+            for pn in ga:
+                if pn not in gb:                      # never touched by the loss: the all-reduce filled in zeros
+                    assert not ga[pn].any(), pn
+                    continue
+                assert np.linalg.norm(ga[pn] - gb[pn]) <= 2e-3 * max(1e-3, np.linalg.norm(gb[pn])), "%s step %d" % (pn, b)

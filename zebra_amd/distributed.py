@@ -25,6 +25,7 @@ form) and the step never synchronises with the host.
 import contextlib
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -128,11 +129,61 @@ def exchange_touched_rows(tables, ids, n_valid, cap, group=None):
     return unpack_rows(tables, recv)
 
 
+def allreduce_gradients(params, group=None, bucket_bytes=64 << 20):
+    """Data-parallel training: SUM-all-reduce the gradients of ``params`` over the group, in
+    flat buckets (the model has ~0.44 M parameters = 1.8 MB: one bucket, one collective; on GPUs the backend is
+    "nccl" = RCCL, a ring over xGMI).  Parameters without a gradient on this rank contribute zeros, so every
+    rank issues the same collectives.  Returns the number of collectives."""
+    params = [p for p in params if p.requires_grad]
+    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    n_coll, i = 0, 0
+    while i < len(params):
+        bucket, size = [], 0
+        while i < len(params) and (not bucket or size + params[i].numel() * 4 <= bucket_bytes):
+            bucket.append(params[i]); size += params[i].numel() * 4; i += 1
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        o = 0
+        for p in bucket:
+            g = flat[o:o + p.numel()].reshape(p.shape).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            o += p.numel()
+        n_coll += 1
+    return n_coll
+
+
 class ShardedTGN:
     """Eval-mode step of a replicated TGN with sharded aggregation / memory update."""
 
     def __init__(self, tgn, rank, world, group=None):
         self.tgn, self.rank, self.world, self.group = tgn, rank, world, group
+
+    def train_step(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs, n_neighbors, criterion):
+        """One data-parallel training step in the reference's style (train.py:205-213, without the optimizer):
+        every rank applies the whole batch to its replica of the state (T-PPR, memory, messages -- no
+        communication, replicas stay identical), embeds and scores only its share of the edges, and the
+        gradients are summed over the ranks.  The loss of the batch is the mean over ALL its edges, so the
+        result equals the single-GPU step.  Returns this rank's share of the loss (sum over ranks = the loss)."""
+        tgn = self.tgn
+        B = len(source_nodes)
+        e0, e1 = shard_range(B, self.rank, self.world)
+        sel = np.arange(e0, e1)
+        s, d, n = tgn.compute_temporal_embeddings(source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
+                                                  n_neighbors, True, edge_sel=sel)
+        score = tgn.affinity_score(torch.cat([s, s], dim=0), torch.cat([d, n])).squeeze(dim=0)
+        m = e1 - e0
+        pos, neg = score[:m].sigmoid(), score[m:].sigmoid()
+        dev = pos.device
+        # criterion is a mean over its inputs (BCELoss): weight this rank's mean by its share of the batch
+        loss = (criterion(pos.squeeze(-1), torch.ones(m, device=dev)) +
+                criterion(neg.squeeze(-1), torch.zeros(m, device=dev))) * (m / float(B)) if m else score.sum() * 0.0
+        loss.backward()
+        allreduce_gradients(tgn.parameters(), self.group)
+        return loss.detach()
 
     @torch.no_grad()
     def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):

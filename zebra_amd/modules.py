@@ -489,9 +489,12 @@ class GraphDiffusionEmbedding(nn.Module):
                 raise IndexError("zt_embed: node / edge id out of range (status %d)" % st)
         return out
 
-    def compute_embedding_tppr_ensemble(self, memory, source_nodes, timestamps, edge_idxs, memory_updater, train):
+    def compute_embedding_tppr_ensemble(self, memory, source_nodes, timestamps, edge_idxs, memory_updater, train,
+                                        row_sel=None):
         """modules/embedding_module.py:217-278.  ``memory`` is the Memory object
-        in train mode and the raw memory tensor in eval mode, as in the reference."""
+        in train mode and the raw memory tensor in eval mode, as in the reference.
+        ``row_sel`` (train mode, optional): LongTensor of the rows to embed -- a data-parallel rank embeds (and
+        back-propagates through) its share of the batch only; the T-PPR update always covers the whole batch."""
         d = self.device
         nodes_d = torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=d)
         ts_d = torch.as_tensor(np.ascontiguousarray(timestamps, np.float64), device=d)
@@ -506,16 +509,24 @@ class GraphDiffusionEmbedding(nn.Module):
         if not train:
             with torch.no_grad():
                 return self.embed_device(memory, nodes_d, on, oe, od, ow)
-        return self._train_forward(memory, nodes_d, on, oe, od, ow, memory_updater)
+        index = None
+        if row_sel is not None:
+            # which nodes read their lazily updated row is decided by the WHOLE batch's neighbours (:227-230), a
+            # node of this share may be another share's neighbour
+            index = torch.unique(on.reshape(-1).long())
+            nodes_d = nodes_d[row_sel].contiguous()
+            on, oe, od, ow = [t[:, row_sel].contiguous() for t in (on, oe, od, ow)]
+        return self._train_forward(memory, nodes_d, on, oe, od, ow, memory_updater, index)
 
-    def _train_forward(self, memory, nodes_d, on, oe, od, ow, memory_updater):
+    def _train_forward(self, memory, nodes_d, on, oe, od, ow, memory_updater, index=None):
         """Autograd path (:227-276).  The lazily updated memory (get_updated_memory, which clones the whole
         [N, D] table in the reference) is a compact OVERLAY here: the GRU runs on the flagged neighbour rows
         only ([U, msg] x plain GEMMs, autograd to the GRU weights) and ``row_map`` says which nodes read their
         row from it.  The neighbour half -- gather, TimeEncode, fc1, ReLU, weighted k-reduction -- is one
         fused HIP kernel forward and one backward (csrc/aggregate_bwd.hip); fc2 and the source transform act
         on [N, D] matrices."""
-        index = torch.unique(on.reshape(-1).long())
+        if index is None:
+            index = torch.unique(on.reshape(-1).long())
         ids = index[memory.flags[index] != 0]                                   # neighbours with a pending message
         U = int(ids.numel())
         if U:

@@ -267,7 +267,7 @@ class TGN(torch.nn.Module):
 
     # ------------------------------------------------------------------ reference surface
     def compute_temporal_embeddings(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
-                                    n_neighbors, train):
+                                    n_neighbors, train, edge_sel=None):
         self.batch_counter += 1
         n_samples = len(source_nodes)
         positives = np.concatenate([source_nodes, destination_nodes])
@@ -288,9 +288,15 @@ class TGN(torch.nn.Module):
             self.test_mode = False
             nodes = np.concatenate([source_nodes, destination_nodes, negative_nodes])
             timestamps = np.concatenate([edge_times, edge_times, edge_times])
+            # edge_sel (data-parallel training): embed the rows of these edges only; state updates cover the batch
+            row_sel = None
+            if edge_sel is not None:
+                es = torch.as_tensor(np.asarray(edge_sel), device=d).long()
+                row_sel = torch.cat([es, es + n_samples, es + 2 * n_samples])
+                n_samples = int(es.numel())
             node_embedding = self.embedding_module.compute_embedding_tppr_ensemble(
                 memory=self.memory, source_nodes=nodes, timestamps=timestamps, edge_idxs=edge_idxs,
-                memory_updater=self.memory_updater, train=True)
+                memory_updater=self.memory_updater, train=True, row_sel=row_sel)
             # update memory without gradients, THEN collect raw messages (:155-168)
             self.update_memory(self.memory, unique_positives)
             with torch.no_grad():
