@@ -669,6 +669,7 @@ struct Front {
     int lt;            // strictly smaller candidates (n > k)
     int mode;          // FR_*: no prune / ranks decide / ties decide the order / ... and the kept set / NaN
     bool keep;         // FR_RANKS, FR_TIES: this lane's candidate is kept
+    u64 touched;       // uniform: s1 lanes whose weight a key match or the new key changed
 };
 
 // The same pair update with the candidate list held in REGISTERS, for k <= 31: s1's entries stay in lanes
@@ -698,6 +699,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     const bool in2 = lane < len2;
     const double add = r2.w * scale_s2;
     u64 m2mask = 0ull;                          // lanes of s2 whose key is already in s1
+    u64 touched = 0ull;                         // lanes of s1 that a match (or the new key, below) lands on
     if (n1 > 0 && len2 > 0) {
         // hash matching as in merge_pair; which of s2's lanes were hit is collected from the (rare)
         // hitting lanes by scalar reads instead of a flag array in LDS
@@ -721,6 +723,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
                 const bool hit = in1 && cand >= 0 && kj == r1.key && tj == r1.ts;
                 if (hit) w1 = w1 + aj;                          // t_s1_PPR[key] += value * scale_s2
                 u64 hm = __ballot(hit);
+                touched = hm;
                 while (hm) {
                     const int l = __ffsll((long long)hm) - 1;
                     hm &= hm - 1ull;
@@ -761,6 +764,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
             }
             wave_sync();
             if (in1 && m1[lane] >= 0) w1 = w1 + L.sort.v[lane];
+            touched = __ballot(in1 && m1[lane] >= 0);
             m2mask = __ballot(in2 && m2[lane] != 0);
             wave_sync();
         }
@@ -775,6 +779,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     const bool h2 = un2 && r2.key == newkey && r2.ts == newts;
     const bool present = __ballot(h1 || h2) != 0ull;
     if (h1) w1 = v;
+    touched |= __ballot(h1);
     const double w2 = h2 ? v : add;
     STAMP2(1);
     // candidates: lanes [0, n1) s1's entries, lanes 32 + j s2's unmatched entries, lane 32 + len2 the new key.
@@ -804,7 +809,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     n = __builtin_amdgcn_readfirstlane(n);
     F.key = ck; F.ts = ct; F.w = cw;
     F.live = live; F.n = n; F.n1 = n1; F.pos_tail = pos;
-    F.lt = 0; F.keep = false;
+    F.lt = 0; F.keep = false; F.touched = touched;
     STAMP2(2);
     STAMP2(3);
     const bool mine = (live >> lane) & 1ull;
@@ -812,7 +817,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     if (__ballot(mine && cw != cw) != 0ull) { F.mode = FR_NAN; return; }
     F.mode = rank_pass(cw, live, n, k, &F.lt, &F.keep);    // :553-559 (first half)
 #ifdef ZT_STAMP
-    if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : 4], 1);
+    if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : (F.mode == FR_TIES ? 4 : 5)], 1);
 #endif
     STAMP2(4);
 }
@@ -987,14 +992,20 @@ __device__ inline bool load_row_wait(const zt_tppr &h, int m, long long x, int l
 // LDS mailbox of a chain workgroup: a ring of hand-off slots, one per chain position modulo MAIL_R.  The hub's
 // new row passes from the edge at chain position t to the edge at t+1 (held by a sibling wave) through slot
 // t % MAIL_R, an LDS round trip instead of a write-through store plus a memory poll -- and in TWO stages:
-//   stage 1, the SET: the k kept entries in "set order" (any fixed order), published as soon as the kept set
-//            is known, i.e. after the rank pass (merge_front);
-//   stage 2, the ORDER: pos[i] = dictionary position of set-order entry i, published after the quicksort
-//            replay when ties decide it (merge_order), together with stage 1 otherwise.
-// The successor starts on stage 1 (scales, key matching, candidate list, rank pass: none of it depends on the
-// order of s1's entries) while this edge still replays its ties; it needs stage 2 only for its own replay,
-// for the partner's update and for emission.  The chain's critical path per hop drops from front + replay to
-// max(front, replay).  seq_set / seq_ord = chain position + 1 once published (0 at launch).
+//   stage 1, the SET in a PROVISIONAL arrangement: the kept entries in ascending order of weight, entries of
+//            equal weight in arbitrary order among themselves (`unc` marks them).  This is known after the rank
+//            pass (merge_front), before the quicksort replay that decides the order inside such runs;
+//   stage 2, the ORDER: pos[s] = dictionary position of the entry at provisional slot s (a permutation inside
+//            the runs of equal weight), published after the replay.
+// What makes the split pay: numba's argsort only ever COMPARES values, so its dynamics -- and the final slot of
+// every list POSITION -- follow from the sequence of values by position, which the provisional arrangement
+// already has exactly.  The successor therefore runs its whole update on stage 1 (scales, key matching,
+// candidate list, rank pass AND its own replay) and publishes its own stage 1 without waiting for anybody's
+// replay; only the identities inside runs of equal weight are settled afterwards, by composing permutations
+// along the chain (stage 2: one LDS gather per hop).  The chain's critical path per hop is the front half.
+// The one thing that does depend on identities is a key match (or the new key) falling on an entry whose slot
+// is still provisional: that hop waits for stage 2 first (process_edge).
+// seq_set / seq_ord = chain position + 1 once published (0 at launch).
 constexpr int MAIL_R = WAVES_PER_WG;
 struct MailSlot {
     u64 key[32];
@@ -1003,6 +1014,7 @@ struct MailSlot {
     int pos[32];
     double norm;
     int len;
+    unsigned unc;      // stage 1: bit s = the entry at provisional slot s may sit elsewhere in its run of equal weights
     int seq_set;       // written last of stage 1
     int seq_ord;       // written last of stage 2
     int seq_free;      // = position of the READER once it is done with both stages: the slot may be rewritten
@@ -1126,6 +1138,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // the hub's row arrives in set order and its order later (two-stage hand-off); otherwise rows are in
     // dictionary order
     bool hub_ordered = true;
+    unsigned hub_unc = 0u;                      // slots of the hub's row that are provisional (stage 2 pending)
     const bool hub_is_u = u == hub;
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
@@ -1151,7 +1164,8 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         rm.len = in_slot->len; rm.norm = in_slot->norm;
         rm.key = in_slot->key[lane & 31]; rm.ts = in_slot->ts[lane & 31]; rm.w = in_slot->w[lane & 31];
         if (hub_is_u) ru = rm; else rv = rm;
-        hub_ordered = false;
+        hub_unc = in_slot->unc;
+        hub_ordered = hub_unc == 0u;               // no provisional slot: the arrangement is the dictionary order
     }
     // stage 2 of the hub's row: dictionary position of my set-order entry (identity when the row came from memory)
     int hub_pos = lane;
@@ -1160,6 +1174,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         if (!wait_seq(&in_slot->seq_ord, tpos, h.ctl + 2, i, -prev_edge - 2)) wl_fail |= 32;
         hub_pos = in_slot->pos[lane & 31];
         hub_ordered = true;
+        hub_unc = 0u;
     };
     // the hub's old row in dictionary order (what the partner's update, a self-loop and emission read)
     auto hub_to_dict = [&]() {
@@ -1206,9 +1221,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             if (tpos >= MAIL_R)
                 if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
         };
-        auto publish_set = [&](int sidx, int n, double new_norm) {
+        auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u) {
             if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
-            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; }
+            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; }
         };
         auto publish_seq = [&](bool set, bool ord) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1240,40 +1255,89 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             WL(0, 8);
             if (u != v) update(r2, r1, x2, x1, o2, 0, -1);
         } else {
-            // ---- the hub's update, front half: needs only the SET of the hub's old entries ----
+            // ---- the hub's update on a row that may still be in its provisional arrangement ----
             const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)x2;
             const double new_norm = r1.norm * beta + beta;
             Front F;
             merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1);
+            if (hub_unc != 0u && (F.touched & (u64)hub_unc) != 0ull) {
+                // a key match (or the new key) fell on an entry whose slot is provisional: the weights by
+                // position would depend on identities.  Settle the order first, then start over.
+                hub_to_dict();
+                merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, 0, -1);
+#ifdef ZT_STAMP
+                if (lane == 0) atomicAdd(&g_paths[6], 1);
+#endif
+            }
+#ifdef ZT_STAMP
+            if (lane == 0 && mo == 0) atomicAdd(&g_paths[7], 1);                        // split hops of model 0
+            if (lane == 0 && mo == 0 && F.mode >= FR_STRADDLE) atomicAdd(&g_paths[3], 1);   // ... whose kept set needs the replay
+            if (lane == 0 && mo == 0 && F.mode == FR_TIES) atomicAdd(&g_paths[2], 1);
+            if (lane == 0 && mo == 0 && F.mode == FR_RANKS) atomicAdd(&g_paths[1], 1);
+#endif
             c.key = F.key; c.ts = F.ts; c.w = F.w;
             const bool mine = (F.live >> lane) & 1ull;
-            int n_new = F.n <= k ? F.n : k, sidx = -1;
-            bool set_out = false;
+            const int pos_prov = lane < 32 ? lane : F.pos_tail;          // my candidate's place in the list as it arrived
+            const int drop = F.n - k;
+            int n_new = F.n <= k ? F.n : k, provslot = -1, trueslot = -1;
+            unsigned unc_out = 0u;
+            bool set_out = false, final_out = false;
             ring_free();
-            if (F.mode == FR_NOPRUNE) sidx = mine ? (lane < 32 ? lane : F.pos_tail) : -1;
-            else if (F.mode == FR_RANKS) sidx = F.keep ? F.lt - (F.n - k) : -1;
-            else if (F.mode == FR_TIES) sidx = F.keep ? __popcll(__ballot(F.keep) & lanemask_lt()) : -1;
-            if (F.mode == FR_RANKS) {                    // set and order at once
-                publish_set(sidx, n_new, new_norm);
-                if (sidx >= 0) out_slot->pos[sidx] = sidx;
-                publish_seq(true, true);
-                c.slot = sidx;
+            if (F.mode == FR_NOPRUNE) {
+                provslot = mine ? pos_prov : -1;                         // s1's entries keep their slots, and their doubts
+                unc_out = hub_unc;
                 set_out = true;
-            } else if (F.mode == FR_NOPRUNE || F.mode == FR_TIES) {
-                publish_set(sidx, n_new, new_norm);      // the successor can start
-                publish_seq(true, false);
+            } else if (F.mode == FR_RANKS) {
+                provslot = F.keep ? F.lt - drop : -1;                    // all kept weights distinct: nothing provisional
                 set_out = true;
+            } else if (F.mode == FR_TIES) {
+                // ascending by weight; equal weights take the slots of their run in arrival order at an LDS counter
+                int *cnt = L.sort.r2;
+                if (lane < k) cnt[lane] = 0;
+                wave_sync();
+                int first = 0;
+                if (F.keep) first = atomicAdd(&cnt[F.lt - drop], 1);
+                wave_sync();
+                const int run = F.keep ? cnt[F.lt - drop] : 0;
+                provslot = F.keep ? F.lt - drop + first : -1;
+                unc_out = wave_or((F.keep && run >= 2) ? 1u << provslot : 0u);
+                wave_sync();
+                set_out = true;
+            }
+            if (set_out) {
+                publish_set(provslot, n_new, new_norm, unc_out);
+                final_out = unc_out == 0u && F.mode != FR_TIES;
+                if (final_out) {
+                    if (provslot >= 0) out_slot->pos[provslot] = provslot;
+                    trueslot = provslot;
+                }
+                publish_seq(true, final_out);                            // the successor can start
             }
             STAMP(2);
             WL(0, 8);
-            // ---- order half: the dictionary positions of the hub's old entries are needed from here on ----
-            if (F.mode != FR_RANKS) {
-                hub_order();
-                c.slot = merge_order(L, lane, k, F, hub_pos, &n_new, mo == 0 ? i : -1);
-                if (!set_out) { sidx = c.slot; publish_set(sidx, n_new, new_norm); }
-                if (sidx >= 0) out_slot->pos[sidx] = c.slot;
-                publish_seq(!set_out, true);
+            if (!final_out) {
+                // ---- my own replay: final slot of every list POSITION (identity-free, see Mail) ----
+                const int slot_c = merge_order(L, lane, k, F, lane, &n_new, mo == 0 ? i : -1);
+                int *sig = L.sel;                                        // final slot by list position
+                if (mine) sig[pos_prov] = slot_c;
+                wave_sync();
+                // ---- identities: where my candidate REALLY stood in the list ----
+                const bool doubt = hub_unc != 0u;
+                if (doubt) hub_order();
+                const int truepos = lane < 32 ? hub_pos : F.pos_tail;    // hub_pos = lane when nothing was provisional
+                trueslot = mine ? sig[truepos] : -1;
+                wave_sync();
+                if (!set_out) {                                          // the kept set itself needed the replay
+                    provslot = trueslot;
+                    publish_set(provslot, n_new, new_norm, 0u);
+                    if (provslot >= 0) out_slot->pos[provslot] = provslot;
+                    publish_seq(true, true);
+                } else {
+                    if (provslot >= 0) out_slot->pos[provslot] = trueslot;
+                    publish_seq(false, true);
+                }
             }
+            c.slot = trueslot;
             if (hub_to_memory) store_row_scatter(h, m, x1, lane, n_new, c, new_norm, tag_base | (unsigned)(o1 + 1));
             // ---- the partner's update reads the hub's old row in dictionary order ----
             hub_to_dict();
