@@ -47,3 +47,10 @@ allph = (s2[:, 1:6] - s2[:, 0:5]) * 0.01
 ok = (s2[:, 5] > 0)
 print("ALL edges: topk percentiles:", np.percentile(allph[ok, 3], [10, 25, 50, 75, 90]).round(2), " frac topk>2us: %.2f" % np.mean(allph[ok, 3] > 2.0))
 pp = np.zeros(16, np.int32); lib.zt_debug_paths(pp.ctypes.data_as(C.c_void_p)); print("topk paths [rank, lds, seq, reg, ties]:", pp)
+# set chain of the hub: stage-1 publication times (stamp 7) and where a hop spends its turn
+pub = s2[idx, 7] * 0.01; seen = s2[idx, 6] * 0.01; st = s2[idx, 0] * 0.01; rk = s2[idx, 4] * 0.01
+okm = (pub[1:] > 0) & (pub[:-1] > 0) & (seen[1:] > 0)
+d = lambda a: np.percentile(a[okm], [10, 50, 90]).round(2)
+print("set chain: publish(t) - publish(t-1):", d(pub[1:] - pub[:-1]), "mean %.2f" % (pub[1:] - pub[:-1])[okm].mean())
+print("  publish(t-1) -> seen(t):", d(seen[1:] - pub[:-1]), " seen -> merge start:", d(st[1:] - seen[1:]),
+      " merge start -> rank pass end:", d(rk[1:] - st[1:]), " rank pass end -> publish:", d(pub[1:] - rk[1:]))

@@ -511,6 +511,17 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S,
     wave_sync();
 }
 
+// max of x >= 0 over the wave (uniform result); same scheme as wave_or (0 is the identity)
+__device__ __forceinline__ int wave_max0(int x)
+{
+    int v = x;
+#define ZT_MAXDPP(ctrl, rm) { const int o = __builtin_amdgcn_update_dpp(0, v, ctrl, rm, 0xf, true); v = o > v ? o : v; }
+    ZT_MAXDPP(0x111, 0xf) ZT_MAXDPP(0x112, 0xf) ZT_MAXDPP(0x114, 0xf) ZT_MAXDPP(0x118, 0xf)
+    ZT_MAXDPP(0x142, 0xa) ZT_MAXDPP(0x143, 0xc)
+#undef ZT_MAXDPP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Top-k of n <= 63 candidates held one per lane, not necessarily in adjacent lanes, in two steps so that a
 // caller can act on the kept SET before the ORDER is known (hub chains, tppr_stream.hip).
 //
@@ -519,7 +530,7 @@ __device__ inline void topk_ties_reg(int lt, int n, int k, int *sel, SortLds &S,
 // kept.  Returns 1 if no tie reaches the kept ranks (slot = lt - drop is the answer), 2 if ties decide the
 // ORDER but the kept set is known (exactly k lanes have *keep), 3 if a tie group straddles the cut (the set
 // itself follows from the quicksort's dynamics).  No LDS.
-__device__ inline int rank_pass(double v, u64 live, int n, int k, int *lt_out, bool *keep_out)
+__device__ inline int rank_pass(double v, u64 live, int n, int k, int *lt_out, bool *keep_out, unsigned *claimed_out = nullptr)
 {
     const int lane = lane_id();
     const int drop = n - k;
@@ -545,6 +556,7 @@ __device__ inline int rank_pass(double v, u64 live, int n, int k, int *lt_out, b
     // tie-free among the kept <=> exactly k lanes are kept and their ranks cover [drop, n) (equal values
     // have equal counts, so a tie leaves a rank unclaimed)
     const unsigned claimed = wave_or(keep ? 1u << (lt - drop) : 0u);
+    if (claimed_out) *claimed_out = claimed;       // bit r: some kept candidate has rank drop + r (a run of g equal values claims one bit)
     const bool full = __popcll(__ballot(keep)) == k;
     if (full && claimed == (1u << k) - 1u) return 1;
     return full ? 2 : 3;

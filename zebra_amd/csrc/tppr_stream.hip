@@ -669,6 +669,7 @@ struct Front {
     int lt;            // strictly smaller candidates (n > k)
     int mode;          // FR_*: no prune / ranks decide / ties decide the order / ... and the kept set / NaN
     bool keep;         // FR_RANKS, FR_TIES: this lane's candidate is kept
+    unsigned claimed;  // uniform: bit r = some candidate has exactly drop + r smaller ones (rank_pass)
     u64 touched;       // uniform: s1 lanes whose weight a key match or the new key changed
 };
 
@@ -809,13 +810,13 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     n = __builtin_amdgcn_readfirstlane(n);
     F.key = ck; F.ts = ct; F.w = cw;
     F.live = live; F.n = n; F.n1 = n1; F.pos_tail = pos;
-    F.lt = 0; F.keep = false; F.touched = touched;
+    F.lt = 0; F.keep = false; F.touched = touched; F.claimed = 0u;
     STAMP2(2);
     STAMP2(3);
     const bool mine = (live >> lane) & 1ull;
     if (n <= k) { F.mode = FR_NOPRUNE; return; }          // :549-551
     if (__ballot(mine && cw != cw) != 0ull) { F.mode = FR_NAN; return; }
-    F.mode = rank_pass(cw, live, n, k, &F.lt, &F.keep);    // :553-559 (first half)
+    F.mode = rank_pass(cw, live, n, k, &F.lt, &F.keep, &F.claimed);    // :553-559 (first half)
 #ifdef ZT_STAMP
     if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : (F.mode == FR_TIES ? 4 : 5)], 1);
 #endif
@@ -1011,10 +1012,15 @@ struct MailSlot {
     u64 key[32];
     double ts[32];
     double w[32];
-    int pos[32];
+    int pos[32];       // stage 2: dictionary position of the entry at provisional slot s (-1: it is not in the row after all)
+    u64 key2[32];      // stage 2: keys / timestamps in dictionary order (the weights by slot are those of stage 1)
+    double ts2[32];
+    u64 alt_key[32];   // stage 1: the members of a straddling run that were NOT picked (see munc)
     double norm;
     int len;
     unsigned unc;      // stage 1: bit s = the entry at provisional slot s may sit elsewhere in its run of equal weights
+    int munc;          // stage 1: slots [0, munc) hold a PICK of munc members out of a run of munc + n_alt equal
+    int n_alt;         //          weights that straddles the cut; which members stay is settled by the replay
     int seq_set;       // written last of stage 1
     int seq_ord;       // written last of stage 2
     int seq_free;      // = position of the READER once it is done with both stages: the slot may be rewritten
@@ -1139,6 +1145,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // dictionary order
     bool hub_ordered = true;
     unsigned hub_unc = 0u;                      // slots of the hub's row that are provisional (stage 2 pending)
+    int hub_munc = 0, hub_nalt = 0;             // slots [0, hub_munc) hold a pick out of a straddling run; its other members
+    u64 hub_alt = 0ull;                         // (this lane's, if lane < hub_nalt)
+    bool hub_final = true;                      // stage 1 was already the dictionary order
     const bool hub_is_u = u == hub;
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
@@ -1160,12 +1169,19 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             }
         }
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
+#ifdef ZT_STAMP
+        { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(6); }
+#endif
         Row rm;
         rm.len = in_slot->len; rm.norm = in_slot->norm;
         rm.key = in_slot->key[lane & 31]; rm.ts = in_slot->ts[lane & 31]; rm.w = in_slot->w[lane & 31];
         if (hub_is_u) ru = rm; else rv = rm;
         hub_unc = in_slot->unc;
-        hub_ordered = hub_unc == 0u;               // no provisional slot: the arrangement is the dictionary order
+        hub_munc = in_slot->munc;
+        hub_nalt = in_slot->n_alt;
+        hub_alt = in_slot->alt_key[lane & 31];
+        hub_ordered = hub_unc == 0u && hub_munc == 0;   // nothing provisional: the arrangement is the dictionary order
+        hub_final = hub_ordered;
     }
     // stage 2 of the hub's row: dictionary position of my set-order entry (identity when the row came from memory)
     int hub_pos = lane;
@@ -1174,16 +1190,17 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         if (!wait_seq(&in_slot->seq_ord, tpos, h.ctl + 2, i, -prev_edge - 2)) wl_fail |= 32;
         hub_pos = in_slot->pos[lane & 31];
         hub_ordered = true;
-        hub_unc = 0u;
     };
-    // the hub's old row in dictionary order (what the partner's update, a self-loop and emission read)
+    // the hub's old row in dictionary order (what the partner's update, a self-loop and emission read): the
+    // keys of stage 2; the weights by slot are the same in both arrangements
     auto hub_to_dict = [&]() {
         hub_order();
+        if (hub_final) return;
         Row &r = hub_is_u ? ru : rv;
-        if (__ballot(lane < r.len && hub_pos != lane) == 0ull) return;
-        const int d = lane < r.len ? hub_pos : 63;
-        r.key = push_u64(r.key, d); r.ts = push_f64(r.ts, d); r.w = push_f64(r.w, d);
+        r.key = in_slot->key2[lane & 31]; r.ts = in_slot->ts2[lane & 31];
         hub_pos = lane;
+        hub_final = true;
+        hub_unc = 0u; hub_munc = 0; hub_nalt = 0;
     };
     // the split hand-off applies when the hub's update is the first of the two: it can then run ahead of the order
     const bool split = hub_by_mail && u != v && (sw ? v : u) == hub;
@@ -1221,9 +1238,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             if (tpos >= MAIL_R)
                 if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
         };
-        auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u) {
+        auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u, int munc = 0, int n_alt = 0) {
             if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
-            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; }
+            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt; }
         };
         auto publish_seq = [&](bool set, bool ord) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1259,15 +1276,36 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)x2;
             const double new_norm = r1.norm * beta + beta;
             Front F;
+            bool settled = hub_final;                                    // the row is known to be the dictionary
+            if (!settled && hub_munc > 0) {
+                // members of a straddling run that were not picked may turn out to be in the row: a key match (any
+                // occupied hash slot counts) or the new key falling on one of them needs the real row
+                bool t = lane < hub_nalt && hub_alt == nkey;
+                if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
+                if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
+            }
             merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1);
-            if (hub_unc != 0u && (F.touched & (u64)hub_unc) != 0ull) {
-                // a key match (or the new key) fell on an entry whose slot is provisional: the weights by
-                // position would depend on identities.  Settle the order first, then start over.
-                hub_to_dict();
-                merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, 0, -1);
+            if (!settled) {
+                // a key match (or the new key) on an entry whose slot is provisional: the weights by position would
+                // depend on identities.  Likewise a picked member of a straddling run that would be kept: whether it
+                // is in the row at all is not known yet.  Then: settle the row first and start over.
+                bool redo = (F.touched & (u64)hub_unc) != 0ull;
+                if (!redo && hub_munc > 0) {
+                    const bool picked = lane < hub_munc;
+                    if (F.mode == FR_RANKS || F.mode == FR_TIES) redo = __ballot(picked && F.keep) != 0ull;
+                    else if (F.mode == FR_STRADDLE) {
+                        const int top_below = wave_max0(((F.live >> lane) & 1ull) && F.lt < F.n - k ? F.lt + 1 : 0) - 1;   // rank of the straddling run
+                        redo = __ballot(picked && F.lt >= top_below) != 0ull;
+                    } else redo = true;
+                }
+                if (redo) {
+                    hub_to_dict();
+                    settled = true;
+                    merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, 0, -1);
 #ifdef ZT_STAMP
-                if (lane == 0) atomicAdd(&g_paths[6], 1);
+                    if (lane == 0) atomicAdd(&g_paths[6], 1);
 #endif
+                }
             }
 #ifdef ZT_STAMP
             if (lane == 0 && mo == 0) atomicAdd(&g_paths[7], 1);                        // split hops of model 0
@@ -1275,44 +1313,72 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             if (lane == 0 && mo == 0 && F.mode == FR_TIES) atomicAdd(&g_paths[2], 1);
             if (lane == 0 && mo == 0 && F.mode == FR_RANKS) atomicAdd(&g_paths[1], 1);
 #endif
+            const unsigned unc_in = settled ? 0u : hub_unc;              // provisional slots of the row as I used it
             c.key = F.key; c.ts = F.ts; c.w = F.w;
             const bool mine = (F.live >> lane) & 1ull;
             const int pos_prov = lane < 32 ? lane : F.pos_tail;          // my candidate's place in the list as it arrived
             const int drop = F.n - k;
             int n_new = F.n <= k ? F.n : k, provslot = -1, trueslot = -1;
             unsigned unc_out = 0u;
+            int munc_out = 0, nalt_out = 0;
             bool set_out = false, final_out = false;
             ring_free();
             if (F.mode == FR_NOPRUNE) {
                 provslot = mine ? pos_prov : -1;                         // s1's entries keep their slots, and their doubts
-                unc_out = hub_unc;
+                unc_out = unc_in;
                 set_out = true;
             } else if (F.mode == FR_RANKS) {
                 provslot = F.keep ? F.lt - drop : -1;                    // all kept weights distinct: nothing provisional
                 set_out = true;
-            } else if (F.mode == FR_TIES) {
-                // ascending by weight; equal weights take the slots of their run in arrival order at an LDS counter
-                int *cnt = L.sort.r2;
-                if (lane < k) cnt[lane] = 0;
-                wave_sync();
-                int first = 0;
-                if (F.keep) first = atomicAdd(&cnt[F.lt - drop], 1);
-                wave_sync();
-                const int run = F.keep ? cnt[F.lt - drop] : 0;
-                provslot = F.keep ? F.lt - drop + first : -1;
-                unc_out = wave_or((F.keep && run >= 2) ? 1u << provslot : 0u);
-                wave_sync();
+            } else if (F.mode == FR_TIES || F.mode == FR_STRADDLE) {
+                // ascending by weight; equal weights take the slots of their run in lane order.
+                // A run that STRADDLES the cut (g members of which j stay): the first j by lane are picked for slots
+                // [0, j) -- the run has the smallest kept weight -- and the others go along as alternates.
+                int ltG = -1, j = 0;
+                u64 Gm = 0ull;
+                if (F.mode == FR_STRADDLE) {
+                    ltG = wave_max0(mine && F.lt < drop ? F.lt + 1 : 0) - 1;
+                    Gm = __ballot(mine && F.lt == ltG);
+                    j = ltG + __popcll(Gm) - drop;
+                }
+                const bool certain = mine && F.lt >= drop;
+                // a run of g equal weights at rank r claims bit r only (rank_pass): its members are the certain
+                // candidates whose next rank is unclaimed.  Run by run (there are two or three), the members take
+                // consecutive slots in lane order -- registers only.
+                const int r0 = F.lt - drop;
+                provslot = certain ? r0 : -1;
+                unsigned ub = 0u;
+                u64 todo = __ballot(certain && r0 + 1 < k && ((F.claimed >> ((r0 + 1) & 31)) & 1u) == 0u);
+                while (todo != 0ull) {
+                    const int l = __ffsll((long long)todo) - 1;
+                    const int rv = __builtin_amdgcn_readlane(r0, l);
+                    const u64 grp = __ballot(certain && r0 == rv);
+                    if ((grp >> lane) & 1ull) { provslot = rv + __popcll(grp & lanemask_lt()); ub = 1u << provslot; }
+                    todo &= ~grp;
+                }
+                if (F.mode == FR_STRADDLE) {
+                    const int gi = __popcll(Gm & lanemask_lt());
+                    const bool member = (Gm >> lane) & 1ull;
+                    if (member && gi < j) { provslot = gi; ub = 1u << gi; }
+                    if (member && gi >= j) out_slot->alt_key[gi - j] = c.key;
+                    munc_out = j;
+                    nalt_out = __popcll(Gm) - j;
+                }
+                unc_out = wave_or(ub);
                 set_out = true;
             }
             if (set_out) {
-                publish_set(provslot, n_new, new_norm, unc_out);
-                final_out = unc_out == 0u && F.mode != FR_TIES;
+                publish_set(provslot, n_new, new_norm, unc_out, munc_out, nalt_out);
+                final_out = unc_out == 0u && munc_out == 0 && F.mode != FR_TIES && F.mode != FR_STRADDLE;
                 if (final_out) {
                     if (provslot >= 0) out_slot->pos[provslot] = provslot;
                     trueslot = provslot;
                 }
                 publish_seq(true, final_out);                            // the successor can start
             }
+#ifdef ZT_STAMP
+            { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(7); }
+#endif
             STAMP(2);
             WL(0, 8);
             if (!final_out) {
@@ -1322,12 +1388,12 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 if (mine) sig[pos_prov] = slot_c;
                 wave_sync();
                 // ---- identities: where my candidate REALLY stood in the list ----
-                const bool doubt = hub_unc != 0u;
-                if (doubt) hub_order();
+                if (unc_in != 0u) hub_order();
                 const int truepos = lane < 32 ? hub_pos : F.pos_tail;    // hub_pos = lane when nothing was provisional
-                trueslot = mine ? sig[truepos] : -1;
+                trueslot = (mine && truepos >= 0) ? sig[truepos] : -1;
                 wave_sync();
-                if (!set_out) {                                          // the kept set itself needed the replay
+                if (trueslot >= 0) { out_slot->key2[trueslot] = c.key; out_slot->ts2[trueslot] = c.ts; }
+                if (!set_out) {                                          // (NaN weights) the kept set itself needed the replay
                     provslot = trueslot;
                     publish_set(provslot, n_new, new_norm, 0u);
                     if (provslot >= 0) out_slot->pos[provslot] = provslot;
