@@ -18,7 +18,8 @@ def per_kernel(path, counter, last):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v[-last:]) / len(v[-last:]) for k, v in agg.items()}
 
 
@@ -26,8 +27,9 @@ def main():
     fetch, write, last, workload = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, w = per_kernel(fetch, "FETCH_SIZE", last), per_kernel(write, "WRITE_SIZE", last)
     out = {"workload": workload, "launches_averaged": last, "unit": "bytes per launch", "kernels": {}}
-    names = {"k_stream": "tppr_stream", "k_fc1_agg": "fc1_agg", "k_embed_out": "embed_out", "k_gru": "gru_update",
-             "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass"}
+    names = {"k_stream": "tppr_stream", "k_fc1_agg<true>": "fc1_agg", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
+             "k_gru": "gru_update", "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass",
+             "k_project_rows": "project_rows"}
     for k, n in names.items():
         if k in f or k in w:
             fr, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
