@@ -62,10 +62,15 @@ def algorithmic_flops(k, F, M, D=100, T=100):
     return dict(p2=p2, src=src, gru=gru, scorer=scorer, total=M * p2 + src + gru + scorer)
 
 
-def executed_flops(k, F, M, D=100, T=100):
+def executed_flops(k, F, M, D=100, T=100, projected=True):
     """FLOPs the HIP kernels execute per edge: fc2 is hoisted behind the k-reduction (aggregate.hip), so
-    k_fc1_agg runs fc1 only and k_embed_out runs fc2 once per row and model plus the source transform."""
-    return dict(fc1_agg=M * 3 * k * 2 * (D + F + T) * D, embed_out=M * 3 * 2 * D * D + 3 * 4 * D * D)
+    k_fc1_agg runs fc1 only and k_embed_out runs fc2 once per row and model plus the source transform.
+    With the projected memory table (W_m memory[v] kept per node) k_fc1_agg contracts over the F + T
+    edge-feature / time columns only, and k_project_rows redoes W_m memory[v] for the <= 2 rows per edge the
+    GRU rewrites."""
+    kc = (F + T) if projected else (D + F + T)
+    return dict(fc1_agg=M * 3 * k * 2 * kc * D, embed_out=M * 3 * 2 * D * D + 3 * 4 * D * D,
+                project_rows=M * 2 * 2 * D * D if projected else 0)
 
 
 def make_stream(wl, n_edges, seed=2020):
@@ -363,7 +368,7 @@ def main():
                 break
     ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
     af = algorithmic_flops(k, F, M)
-    ex = executed_flops(k, F, M)
+    ex = executed_flops(k, F, M, projected=bool(getattr(tgn.embedding_module, "use_projection", False)))
 
     def kernel_roofline(name):
         """achieved = ALGORITHMIC bytes (or EXECUTED flops) of one launch / its average HIP-event time."""
@@ -374,8 +379,8 @@ def main():
             ach = ex[name] * bs / shard / us / 1e12
             return dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
                         frac=ach / MFMA_F32_PEAK_TF, traffic=tr,
-                        note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out); the reference "
-                             "formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
+                        note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
+                             "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
         if name == "tppr_stream":
             byts = ab["p1"] * M * bs                       # one k_stream launch covers all M models
             note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
@@ -431,7 +436,7 @@ def main():
         "cpu_baseline": cpu,
         "row_fill": fill,
         "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
-                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + af["gru"] + af["scorer"],
+                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"] + af["scorer"],
                         "hbm_gbs_at_value": ab["total"] * value / 1e9,
                         "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
                         "mfma_tflops_at_value": af["total"] * value / 1e12,

@@ -436,6 +436,13 @@ class GraphDiffusionEmbedding(nn.Module):
                                       stream_ptr()), "zt_project_memory")
         self._ws_key = key
 
+    def invalidate_projection(self):
+        """For callers that write the memory table or fc1's weights behind torch's back (raw pointers): the
+        projected table is rebuilt at its next use."""
+        self._proj_serial = getattr(self, "_proj_serial", 0) + 1      # part of TGN._pipe_signature
+        if self._proj is not None:
+            self._proj["key"] = None
+
     def _projection(self, memory_obj):
         """The projected table for ``memory_obj.memory`` if it can be used, else None.  Valid for one memory tensor
         (identity and torch in-place version: HIP kernels that rewrite rows report them through
