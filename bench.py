@@ -180,7 +180,8 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
         p.tppr.streaming_topk = single
     out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=n_threads, kind="port",
                p1_edges_per_s_1thread=n_e[0] / max(t_p1[0], 1e-9),
-               sample="%d timed batches (%d edges) of the same stream from the GPU run's warm state; value = first "
+               sample="%d batches (%d edges) of the same stream starting from the GPU run's state after the prefill "
+                      "(where its warm-up steps start); value = first "
                       "%d batches with the T-PPR loop on 1 thread (as the reference's Numba loop); aggregation / "
                       "GRU / scorer on %d OpenMP threads" % (len(batches), n_e[0] + n_e[1], half, n_threads))
     if n_e[1]:
@@ -295,15 +296,16 @@ def main():
 
     lib = _capi.lib()
     run(0, prefill)
-    run(prefill, a.warmup)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
     torch.cuda.synchronize()
-    # ---- warm state for the CPU leg (same warm-up as the GPU leg) and row-fill statistics ----
-    e0 = (prefill + a.warmup) * bs
+    # ---- warm state for the CPU leg (the state after the 10 % prefill, where the GPU leg's warm-up steps start)
+    # and row-fill statistics.  Taken BEFORE the warm-up so that the W warm-up steps run right before the timed
+    # region (the snapshot idles the GPU for seconds).
+    e0 = prefill * bs
     cpu_nb = 0
     if world == 1 and a.cpu_edges != 0:
         ce = a.cpu_edges if a.cpu_edges > 0 else {"c5": 48 * bs, "c3": 40 * bs, "c2": 60 * bs, "c4": 20 * bs}[a.workload]
-        cpu_nb = max(2, min(a.steps, ce // bs))
+        cpu_nb = max(2, min(a.steps + a.warmup, ce // bs))
     snap, fill = None, None
     if cpu_nb:
         touched = np.unique(np.concatenate([src[:e0], dst[:e0]])) if e0 else np.zeros(0, np.int64)
@@ -314,6 +316,7 @@ def main():
             seen = (pos < len(touched)) & (touched[np.minimum(pos, len(touched) - 1)] == ends)
             ln = np.where(seen, snap["tppr"][0]["len"][np.minimum(pos, len(touched) - 1)], 0)
             fill = dict(mean_row_len=float(ln.mean()), frac_empty=float((ln == 0).mean()), frac_full=float((ln == k).mean()))
+    run(prefill, a.warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
         lib.zt_profile_enable(1)
@@ -411,7 +414,7 @@ def main():
     if cpu_nb:
         n_threads = min(16, os.cpu_count() or 1)
         weights, time_w = model_weights(tgn)
-        b0 = prefill + a.warmup
+        b0 = prefill
         batches = [(src[b * bs:(b + 1) * bs], dst[b * bs:(b + 1) * bs], neg[b * bs:(b + 1) * bs], ts[b * bs:(b + 1) * bs],
                     eidx[b * bs:(b + 1) * bs]) for b in range(b0, b0 + cpu_nb)]
         extra = dict(src=src, dst=dst, eidx=eidx, ts=ts)

@@ -13,12 +13,9 @@ except SystemExit:
 a = np.zeros(8, np.uint64)
 lib.zt_debug_agg(a.ctypes.data_as(C.c_void_p), C.c_int(0))
 a = a.astype(np.float64)
-names = ["cons mfma", "cons epilogue", "prod work", "prod wait", "cons wait", "p:normalize", "p:issue", "p:cos"]
+names = ["scalars+normalise", "gather issue", "time encode", "LDS stores + pad", "barrier", "fc1 MFMA", "bias/relu -> LDS", "k-reduction + store"]
 tot = a.sum()
-import os
-mt = int(os.environ.get("ZT_AGG_MT", "5"))
-rq = (mt * 16) // 20
-nwg = ((12288 + rq - 1) // rq) * 2 * 83   # = tiles          # prefill 60 + warmup 3 + 20 steps
+wl = sys.argv[-1] if sys.argv[-1] in ("c2", "c3", "c4", "c5") else "c5"
 for n, v in zip(names, a):
-    print("%-22s %5.1f%%   %8.0f clk/WG" % (n, 100 * v / tot, v / nwg))
-print("total %.0f clk/WG" % (tot / nwg))
+    print("%-22s %5.1f%%   %10.0f clk total" % (n, 100 * v / tot, v))
+print("total %.3e clk (thread 0 of every workgroup, summed over workgroups and launches)" % tot)

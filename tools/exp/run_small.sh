@@ -1,0 +1,6 @@
+python -m pytest tests/test_embed_gpu.py -x -q -m gpu > gpurun_out/t_small.txt 2>&1 || { tail -20 gpurun_out/t_small.txt; exit 1; }
+tail -2 gpurun_out/t_small.txt
+for c in c2 c4 c5; do
+  python bench.py --workload $c --steps 200 --cpu-edges 0 > gpurun_out/x_$c.json 2> gpurun_out/x.err || exit 1
+  echo "$c $(grep 'host enqueue' gpurun_out/x.err)"; python tools/showbench.py gpurun_out/x_$c.json | sed -n 2p
+done

@@ -160,15 +160,28 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     // rows are whole float4s, 16-byte aligned in HBM and in the tile
     const bool vecD = TAB || ((D & 3) == 0 && ((size_t)memory & 15) == 0);
     const bool vecF = vecD && F > 0 && (F & 3) == 0 && ((size_t)efeat & 15) == 0;
-    // cos(dt * w_c) for every (row, frequency); reads only LDS.  Element f = tid + n*256 -> (row g,
-    // frequency c) is advanced incrementally: no division in the loop.
-    const int step_g = AGG_THREADS / (T > 0 ? T : 1), step_c = AGG_THREADS - step_g * T;
+    // cos(dt * w_c) for every (row, frequency); reads only LDS.  A thread keeps ONE frequency in a register and
+    // walks down a block of rows, four dt values per (broadcast) LDS read: no dependent LDS read and no index
+    // arithmetic per element, and the four cosines of a step are independent instructions.
     auto time_encode = [&]() {
-        int g = fastdiv(tid, mT), c = tid - g * T;
-        for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
-            A[g * lda + CM + F + c] = g < rows ? time_cosf(g_dt[g] * tw[c]) : 0.f;      // cos(t*w + 0)
-            g += step_g; c += step_c;
-            if (c >= T) { c -= T; ++g; }
+        if (T > AGG_THREADS || T <= 0) {                                // (not a shape the reference uses)
+            for (int f = tid; f < rows_p * T; f += AGG_THREADS) {
+                const int g = fastdiv(f, mT), c = f - g * T;
+                A[g * lda + CM + F + c] = g < rows ? time_cosf(g_dt[g] * tw[c]) : 0.f;
+            }
+            return;
+        }
+        const int TC = T <= 64 ? 64 : (T <= 128 ? 128 : 256);          // threads per row block
+        const int RG = AGG_THREADS / TC, per = rows_p / RG;             // rows_p is a multiple of 16
+        const int c = tid & (TC - 1), g0 = (tid / TC) * per;
+        if (c >= T) return;
+        const float wc = tw[c];
+        float *dst = A + (size_t)g0 * lda + CM + F + c;
+        for (int i = 0; i < per; i += 4) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(g_dt + g0 + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                dst[(size_t)(i + u) * lda] = (g0 + i + u) < rows ? time_cosf(d4[u] * wc) : 0.f;     // cos(t*w + 0)
         }
     };
     if (vecD) {
@@ -396,6 +409,266 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 }
 
 // ---------------------------------------------------------------------------
+// The same kernel (table path) for the reference's default widths -- memory_dim = time_dim = 100
+// (train.py:33-36) -- and k in {10, 20, 40}: a tile is exactly 80 gathered rows (5 M-tiles), the hidden layer 7
+// N-tiles.  k_fc1_agg<true> spends more SIMD time on vector instructions (index arithmetic, bounds, generic
+// loops: ~2400 per wave and tile) than on its 245 MFMAs; with the widths fixed at compile time the vector
+// work is ~3x smaller:
+//   * every thread owns one time-encoding COLUMN (its frequency stays in a register) and walks down 40 rows,
+//     four dt values per broadcast LDS read; the 28 idle column lanes write the zero padding of the tile;
+//   * the projected rows are fetched with one 64-bit address per row and immediate offsets per column;
+//   * bias / ReLU / weight and the k-reduction use immediate LDS offsets (no divisions anywhere).
+// Waves 0-2 own N-tiles {w, w+4}, wave 3 owns tile 3 only (7 tiles): two instantiations of the MFMA loop.
+// ---------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void d100_mfma(const float *A, int lda, const float *__restrict__ bp, int K1p, int nchunk, int nrem,
+                                          int r16, int g4, f32x4 (&acc)[5][2])
+{
+    // nchunk whole 16-column chunks (one b128 fragment per lane: k = 16 kc + 4 g4 + j), then nrem single MFMA steps
+    // over the last columns (k = 16 nchunk + 4 j + g4, scalar fragments): the contraction is padded to a multiple
+    // of 4 columns, not 16 (F + T = 101 -> 26 steps instead of 28).
+    f32x4 bcur[NB], bnext[NB];
+    float bre[NB][3];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bcur[b] = *reinterpret_cast<const f32x4 *>(bp + (size_t)b * 64 * K1p);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            bre[b][j] = j < nrem ? bp[(size_t)b * 64 * K1p - 4 * g4 + 16 * nchunk + 4 * j + g4] : 0.f;
+    const float *ap = A + (size_t)r16 * lda + 4 * g4;
+    for (int kc = 0; kc < nchunk; ++kc) {
+        if (kc + 1 < nchunk) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bnext[b] = *reinterpret_cast<const f32x4 *>(bp + (size_t)b * 64 * K1p + 16 * (kc + 1));
+        }
+        f32x4 av[5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) av[a] = *reinterpret_cast<const f32x4 *>(ap + (size_t)a * 16 * lda + 16 * kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bcur[b][j], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bcur[b] = bnext[b];
+    }
+    const float *ar = A + (size_t)r16 * lda + 16 * nchunk + g4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j >= nrem) break;
+        float av[5];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) av[a] = ar[(size_t)a * 16 * lda + 4 * j];
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bre[b][j], acc[a][b], 0, 0, 0);
+    }
+}
+
+template <int KK>
+__global__ __launch_bounds__(AGG_THREADS, 4) void k_fc1_agg_d100(
+    const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
+    long long num_edges, int F, long long N, int lda, const int *__restrict__ nbr, const int *__restrict__ eix,
+    const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ W1p, int K1p,
+    const float *__restrict__ b1, float *__restrict__ H, float *__restrict__ S, int *status)
+{
+    constexpr int D = 100, T = 100, DP = 112, ROWS = 80, RQ = ROWS / KK, LDH = DP + 1;
+    static_assert(ROWS % KK == 0, "a tile holds whole query rows");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *A = reinterpret_cast<float *>(smem);                       // [80][lda]: [ef (F) | cos (T) | 0-pad]
+    float *wn = A + (size_t)ROWS * lda;                               // raw T-PPR weights
+    float *wnn = wn + ROWS;                                           // w / sum(w)
+    int *g_nb = reinterpret_cast<int *>(wnn + ROWS);
+    int *g_ei = g_nb + ROWS;
+    float *g_dt = reinterpret_cast<float *>(g_ei + ROWS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int m = blockIdx.y;
+    const long long q0 = (long long)blockIdx.x * RQ;
+    const int nq = (int)((N - q0) < RQ ? (N - q0) : RQ);
+    const int rows = nq * KK;
+    const size_t mb = ((size_t)m * N + q0) * KK;
+#ifdef ZT_AGG_STAMP
+    long long t_prev__ = clock64();
+#endif
+
+    // ---- per-row scalars; a thread's own edge feature (F = 1) and time frequency ride on the same round trip ----
+    float ef1 = 0.f;
+    if (tid < ROWS) {
+        int nb = 0, ei = 0;
+        float d = 0.f, wv = 0.f;
+        if (tid < rows) {
+            nb = nbr[mb + tid]; ei = eix[mb + tid]; d = dt[mb + tid]; wv = w[mb + tid];
+            if (nb < 0 || nb >= num_nodes || ei < 0 || ei >= num_edges) {
+                atomicExch(status, ZT_ERR_RANGE);
+                nb = 0; ei = 0;
+            }
+            if (F == 1) ef1 = efeat[ei];
+        }
+        g_nb[tid] = nb; g_ei[tid] = ei; g_dt[tid] = d; wn[tid] = wv;
+    }
+    const int cc = tid & 127;                                         // this thread's column of the time block
+    const float wc = cc < T ? time_w[cc] : 0.f;
+    const int col0 = wave * 16 + r16;                                 // this lane's output columns: col0, col0 + 64
+    const float bias0 = col0 < D ? b1[col0] : 0.f, bias1 = (wave < 3 && col0 + 64 < D) ? b1[col0 + 64] : 0.f;
+    __syncthreads();
+    AGG_STAMP(0);
+
+    // ---- accumulators start from the projected rows P[nbr[row]][col]: one address per row ----
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const int nb4[4] = {g_nb[a * 16 + g4 * 4 + 0], g_nb[a * 16 + g4 * 4 + 1], g_nb[a * 16 + g4 * 4 + 2], g_nb[a * 16 + g4 * 4 + 3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *pr = P + (size_t)nb4[j] * DP + col0;
+            acc[a][0][j] = pr[0];
+            acc[a][1][j] = pr[wave < 3 ? 64 : 0];                     // wave 3 has no second N-tile: any valid address
+        }
+    }
+    // ---- w / sum(w), 0 where the sum is 0 (:267-270); sum in entry order like torch.sum(dim=1) ----
+    if (tid < ROWS) {
+        const int q = tid / KK;
+        float my_sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < KK; ++j) my_sum += wn[q * KK + j];
+        wnn[tid] = (my_sum == 0.f) ? 0.f : wn[tid] / my_sum;
+        if (tid < rows && tid - q * KK == 0) S[(size_t)m * N + q0 + q] = (my_sum == 0.f) ? 0.f : 1.f;
+    }
+    AGG_STAMP(1);
+    // ---- edge features ----
+    if (F == 1) {
+        if (tid < ROWS) A[(size_t)tid * lda] = ef1;
+    } else if (F > 0) {
+        constexpr int GU = 8;
+        const bool vecF = (F & 3) == 0 && ((size_t)efeat & 15) == 0;
+        if (vecF) {
+            const int F4 = F >> 2;
+            const unsigned mF4 = fastdiv_magic((unsigned)F4);
+            for (int f0 = tid; f0 < ROWS * F4; f0 += AGG_THREADS * GU) {
+                f32x4 v[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF4), c = f - g * F4;
+                    v[u] = (f < ROWS * F4 && g < rows) ? *reinterpret_cast<const f32x4 *>(efeat + (size_t)g_ei[g] * F + 4 * c)
+                                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF4), c = f - g * F4;
+                    if (f < ROWS * F4) *reinterpret_cast<f32x4 *>(A + (size_t)g * lda + 4 * c) = v[u];
+                }
+            }
+        } else {
+            const unsigned mF = fastdiv_magic((unsigned)F);
+            for (int f0 = tid; f0 < ROWS * F; f0 += AGG_THREADS * GU) {
+                float v[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF), c = f - g * F;
+                    v[u] = (f < ROWS * F && g < rows) ? efeat[(size_t)g_ei[g] * F + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int f = f0 + u * AGG_THREADS;
+                    const int g = fastdiv(f, mF), c = f - g * F;
+                    if (f < ROWS * F) A[(size_t)g * lda + c] = v[u];
+                }
+            }
+        }
+    }
+    // ---- time encoding: column cc of rows [40 * (tid / 128), +40); lanes 100..127 write the zero padding ----
+    // The common-range formula of time_cosf runs branch-free; the largest |argument| is tracked on the side and
+    // the (rare: dt * w >= 4e6) columns are redone with the full routine afterwards.
+    {
+        const int g0 = (tid >> 7) * 40;
+        const bool is_cos = cc < T;
+        if (is_cos || F + cc < K1p) {
+            float *dst = A + (size_t)g0 * lda + F + cc;
+            float xmax = 0.f;
+#pragma unroll 2
+            for (int i = 0; i < 40; i += 4) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(g_dt + g0 + i);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float x = d4[u] * wc;
+                    xmax = fmaxf(xmax, fabsf(x));
+                    dst[(size_t)(i + u) * lda] = time_cosf_fast(x);          // cos(t*w + 0); wc = 0 in the padding: 1 -> fixed below
+                }
+            }
+            if (!is_cos) {
+                for (int i = 0; i < 40; ++i) dst[(size_t)i * lda] = 0.f;
+            } else if (!(xmax < 4.0e6f)) {
+                for (int i = 0; i < 40; ++i) dst[(size_t)i * lda] = time_cosf(g_dt[g0 + i] * wc);
+            }
+        }
+    }
+    AGG_STAMP(2);
+    AGG_STAMP(3);
+    __syncthreads();
+    AGG_STAMP(4);
+
+    // ---- fc1 on f32 MFMA ----
+    {
+        const float *bp = W1p + (size_t)col0 * K1p + 4 * g4;
+        const int K4 = (F + T + 3) & ~3, nchunk = K4 >> 4, nrem = (K4 & 15) >> 2;
+        if (wave < 3) d100_mfma<2>(A, lda, bp, K1p, nchunk, nrem, r16, g4, acc);
+        else          d100_mfma<1>(A, lda, bp, K1p, nchunk, nrem, r16, g4, acc);
+    }
+    AGG_STAMP(5);
+    __syncthreads();   // every wave is done reading the A tile: reuse it for the hidden rows
+
+    // ---- bias + ReLU + weight, staged as Hs[g][col] in the A region ----
+    float *Hs = A;
+    {
+        float *hp = Hs + (size_t)(g4 * 4) * LDH + col0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wnn + a * 16 + g4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = acc[a][0][j] + bias0;
+                v = v > 0.f ? v : 0.f;
+                hp[(size_t)(a * 16 + j) * LDH] = v * w4[j];
+            }
+        }
+        if (wave < 3) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wnn + a * 16 + g4 * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v1 = acc[a][1][j] + bias1;
+                    v1 = v1 > 0.f ? v1 : 0.f;
+                    hp[(size_t)(a * 16 + j) * LDH + 64] = v1 * w4[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    AGG_STAMP(6);
+    // ---- reduce over the k neighbours of each query row ----
+    if (cc < D) {
+        for (int q = tid >> 7; q < nq; q += 2) {
+            const float *hq = Hs + (size_t)(q * KK) * LDH + cc;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j) s += hq[(size_t)j * LDH];
+            H[((size_t)m * N + q0 + q) * D + cc] = s;
+        }
+    }
+    AGG_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
 // out[n] = [ fc2s(relu(fc1s(memory[nodes[n]]))) | fc2(H_0[n]) + b2*S_0[n] | ... ]
 // Three small D x D layers on f32 MFMA.  One workgroup per 32 rows; the input
 // rows sit in LDS, weights ([Dp][Dp], zero padded) stream from L2 as b128
@@ -403,6 +676,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 // ---------------------------------------------------------------------------
 constexpr int OUT_ROWS = 32;
 constexpr int OUT_MT = OUT_ROWS / 16;
+constexpr int SG_CH = 8;             // k-steps of weight fragments in flight (small_gemm)
 
 // acc[a][b] = X[a-th 16 rows] * W[b-th owned N-tile]^T   (X in LDS [32][ldx], W padded [Dp][Dp])
 __device__ __forceinline__ void small_gemm(const float *X, int ldx, const float *__restrict__ Wp, int Dp, int NT,
@@ -413,21 +687,36 @@ __device__ __forceinline__ void small_gemm(const float *X, int ldx, const float 
     for (int a = 0; a < OUT_MT; ++a)
 #pragma unroll
         for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < Dp / 16; ++kc) {
-        f32x4 av[OUT_MT];
+    // The weight fragments of SG_CH k-steps are fetched together, before the first MFMA that needs one: a
+    // workgroup has one tile of 32 rows, so nothing else hides the L2 round trip of a load issued per k-step.
+    const int KC = Dp / 16;
+    for (int kc0 = 0; kc0 < KC; kc0 += SG_CH) {
+        f32x4 bv[SG_CH][NTW];
 #pragma unroll
-        for (int a = 0; a < OUT_MT; ++a)
-            av[a] = *reinterpret_cast<const f32x4 *>(X + (size_t)(a * 16 + r16) * ldx + 16 * kc + 4 * g4);
+        for (int c = 0; c < SG_CH; ++c)
 #pragma unroll
-        for (int b = 0; b < NTW; ++b) {
-            const int nt = wave + b * AGG_WAVES;
-            if (nt >= NT) continue;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(Wp + (size_t)(nt * 16 + r16) * Dp + 16 * kc + 4 * g4);
+            for (int b = 0; b < NTW; ++b) {
+                const int nt = wave + b * AGG_WAVES;
+                bv[c][b] = (kc0 + c < KC && nt < NT)
+                               ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)(nt * 16 + r16) * Dp + 16 * (kc0 + c) + 4 * g4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int c = 0; c < SG_CH; ++c) {
+            if (kc0 + c >= KC) break;
+            f32x4 av[OUT_MT];
 #pragma unroll
             for (int a = 0; a < OUT_MT; ++a)
+                av[a] = *reinterpret_cast<const f32x4 *>(X + (size_t)(a * 16 + r16) * ldx + 16 * (kc0 + c) + 4 * g4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bv[j], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) {
+                if (wave + b * AGG_WAVES >= NT) continue;
+#pragma unroll
+                for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bv[c][b][j], acc[a][b], 0, 0, 0);
+            }
         }
     }
 }
@@ -735,8 +1024,28 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds[tab ? 1 : 0] = lds;
     }
+    // the reference's default widths take the specialised kernel (ZT_AGG_GENERIC=1: always the generic one)
+    const bool d100 = tab && D == 100 && T == 100 && p.mt2 == 5 && (k == 10 || k == 20 || k == 40) &&
+                      !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
+    static size_t attr_fast[3] = {0, 0, 0};
+    if (d100 && lds > 48 * 1024) {
+        const int ki = k == 10 ? 0 : (k == 20 ? 1 : 2);
+        if (lds > attr_fast[ki]) {
+            const void *fn = k == 10 ? reinterpret_cast<const void *>(k_fc1_agg_d100<10>)
+                                     : (k == 20 ? reinterpret_cast<const void *>(k_fc1_agg_d100<20>)
+                                                : reinterpret_cast<const void *>(k_fc1_agg_d100<40>));
+            ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_fast[ki] = lds;
+        }
+    }
     ZT_PROF_BEGIN(s, P_FC1_AGG);
-    if (tab) {
+    if (d100) {
+        dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
+#define ZT_D100(KK) k_fc1_agg_d100<KK><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes,     \
+            num_edges, F, N, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
+        if (k == 10) ZT_D100(10); else if (k == 20) ZT_D100(20); else ZT_D100(40);
+#undef ZT_D100
+    } else if (tab) {
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
         k_fc1_agg<true><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
                                                        T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/zebra_amd.h"
 
@@ -20,6 +21,12 @@ enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_A
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, int id);
 void prof_end(hipStream_t s, int id);
+// extra flags for events that only order streams of this device (experiment knob: ZT_EVENT_FLAGS, hex)
+inline unsigned sync_event_flags()
+{
+    static const unsigned f = getenv("ZT_EVENT_FLAGS") ? (unsigned)strtoul(getenv("ZT_EVENT_FLAGS"), nullptr, 16) : 0u;
+    return f;
+}
 #define ZT_PROF_BEGIN(s, id) do { if (zt::g_prof_on) zt::prof_begin((s), (id)); } while (0)
 #define ZT_PROF_END(s, id) do { if (zt::g_prof_on) zt::prof_end((s), (id)); } while (0)
 
@@ -122,6 +129,16 @@ __device__ __noinline__ float time_cosf_large(float x)
     double r = fma(-kd, 1.57079632679489655800e+00, xd);
     r = fma(-kd, 6.12323399573676603587e-17, r);
     return time_cos_poly((float)r, (int)((long long)kd & 3ll));   // |k| < 6.4e14: the quadrant from 64 bits
+}
+
+// the |x| < 4e6 formula of time_cosf alone (callers check the range themselves)
+__device__ __forceinline__ float time_cosf_fast(float x)
+{
+    const float kf = rintf(x * 0.636619772f);
+    float r = fmaf(kf, -1.57079637e+00f, x);
+    r = fmaf(kf, 4.37113883e-08f, r);
+    // quarter revolutions of the quadrant: fract(k / 4) = (k & 3) / 4, also for negative k
+    return __builtin_amdgcn_cosf(fmaf(r, 0.159154943f, __builtin_amdgcn_fractf(kf * 0.25f)));
 }
 
 __device__ __forceinline__ float time_cosf(float x)

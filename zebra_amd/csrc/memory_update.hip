@@ -105,6 +105,7 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 constexpr int GRU_MT = 2;      // 32 rows per workgroup
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
+constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
 
 // Zero-padded gate-major copy: W[3D][K] -> Wp[3][Dp][Kp]
 __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *__restrict__ Wp, int Dp, int Kp)
@@ -175,52 +176,48 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
         live[b] = nt < NT;
         colrow[b] = (live[b] ? nt : 0) * 16 + r16;
     }
-    // message part: gi = W_ih x
-    for (int kc = 0; kc < Xp / 16; ++kc) {
-        f32x4 av[GRU_MT];
+    // Both parts stream their weight fragments from L2; GRU_CH k-steps are fetched together so that one
+    // round trip is paid per chunk rather than per k-step (a workgroup owns one tile, nothing else hides it).
+    auto part = [&](const float *__restrict__ Wp, int Kp, int a_off, bool hidden) {
+        const int KC = Kp / 16;
+        for (int kc0 = 0; kc0 < KC; kc0 += GRU_CH) {
+            f32x4 wr[GRU_CH][GRU_NTW], wz[GRU_CH][GRU_NTW], wn[GRU_CH][GRU_NTW];
 #pragma unroll
-        for (int a = 0; a < GRU_MT; ++a)
-            av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4);
+            for (int c = 0; c < GRU_CH; ++c)
 #pragma unroll
-        for (int b = 0; b < GRU_NTW; ++b) {
-            if (!live[b]) continue;
-            const size_t o = (size_t)colrow[b] * Xp + 16 * kc + 4 * g4;
-            const f32x4 wr = *reinterpret_cast<const f32x4 *>(Wih_p + o);
-            const f32x4 wz = *reinterpret_cast<const f32x4 *>(Wih_p + (size_t)Dp * Xp + o);
-            const f32x4 wn = *reinterpret_cast<const f32x4 *>(Wih_p + (size_t)2 * Dp * Xp + o);
-#pragma unroll
-            for (int a = 0; a < GRU_MT; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[j], ar[a][b], 0, 0, 0);
-                    az[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wz[j], az[a][b], 0, 0, 0);
-                    ani[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[j], ani[a][b], 0, 0, 0);
+                for (int b = 0; b < GRU_NTW; ++b) {
+                    const bool on = live[b] && kc0 + c < KC;
+                    const size_t o = (size_t)colrow[b] * Kp + 16 * (on ? kc0 + c : 0) + 4 * g4;
+                    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+                    wr[c][b] = on ? *reinterpret_cast<const f32x4 *>(Wp + o) : zero;
+                    wz[c][b] = on ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)Dp * Kp + o) : zero;
+                    wn[c][b] = on ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)2 * Dp * Kp + o) : zero;
                 }
-        }
-    }
-    // memory part: gh = W_hh h
-    for (int kc = 0; kc < Hp / 16; ++kc) {
-        f32x4 av[GRU_MT];
 #pragma unroll
-        for (int a = 0; a < GRU_MT; ++a)
-            av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + Xp + 16 * kc + 4 * g4);
+            for (int c = 0; c < GRU_CH; ++c) {
+                if (kc0 + c >= KC) break;
+                f32x4 av[GRU_MT];
 #pragma unroll
-        for (int b = 0; b < GRU_NTW; ++b) {
-            if (!live[b]) continue;
-            const size_t o = (size_t)colrow[b] * Hp + 16 * kc + 4 * g4;
-            const f32x4 wr = *reinterpret_cast<const f32x4 *>(Whh_p + o);
-            const f32x4 wz = *reinterpret_cast<const f32x4 *>(Whh_p + (size_t)Dp * Hp + o);
-            const f32x4 wn = *reinterpret_cast<const f32x4 *>(Whh_p + (size_t)2 * Dp * Hp + o);
+                for (int a = 0; a < GRU_MT; ++a)
+                    av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + a_off + 16 * (kc0 + c) + 4 * g4);
 #pragma unroll
-            for (int a = 0; a < GRU_MT; ++a)
+                for (int b = 0; b < GRU_NTW; ++b) {
+                    if (!live[b]) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[j], ar[a][b], 0, 0, 0);
-                    az[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wz[j], az[a][b], 0, 0, 0);
-                    anh[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[j], anh[a][b], 0, 0, 0);
+                    for (int a = 0; a < GRU_MT; ++a)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[c][b][j], ar[a][b], 0, 0, 0);
+                            az[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wz[c][b][j], az[a][b], 0, 0, 0);
+                            if (hidden) anh[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[c][b][j], anh[a][b], 0, 0, 0);
+                            else        ani[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wn[c][b][j], ani[a][b], 0, 0, 0);
+                        }
                 }
+            }
         }
-    }
+    };
+    part(Wih_p, Xp, 0, false);      // message part: gi = W_ih x
+    part(Whh_p, Hp, Xp, true);      // memory part:  gh = W_hh h
     // gates (torch.nn.GRUCell): r,z = sigmoid(gi+gh); n = tanh(gi_n + r*gh_n); h' = (1-z)*n + z*h
 #pragma unroll
     for (int b = 0; b < GRU_NTW; ++b) {

@@ -132,9 +132,9 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipMalloc(&s.ts3, rows * sizeof(double)));
         ZT_HIP(hipMalloc(&s.on, per * 4)); ZT_HIP(hipMalloc(&s.oe, per * 4));
         ZT_HIP(hipMalloc(&s.od, per * 4)); ZT_HIP(hipMalloc(&s.ow, per * 4));
-        ZT_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
-        ZT_HIP(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming));
-        ZT_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming));
+        ZT_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming | zt::sync_event_flags()));
+        ZT_HIP(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming | zt::sync_event_flags()));
+        ZT_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming | zt::sync_event_flags()));
     }
     ZT_HIP(hipMalloc(&p->sh_on, per * 4)); ZT_HIP(hipMalloc(&p->sh_oe, per * 4));
     ZT_HIP(hipMalloc(&p->sh_od, per * 4)); ZT_HIP(hipMalloc(&p->sh_ow, per * 4));

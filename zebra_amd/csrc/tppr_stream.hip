@@ -1548,8 +1548,8 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         ZT_HIP(hipMemset(P.chain_len, 0, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMemset(P.cnt, 0, (size_t)num_nodes * sizeof(int)));
         ZT_HIP(hipMemset(P.ctl, 0, CTL_WORDS * sizeof(int)));
-        ZT_HIP(hipEventCreateWithFlags(&P.planned, hipEventDisableTiming));
-        ZT_HIP(hipEventCreateWithFlags(&P.consumed, hipEventDisableTiming));
+        ZT_HIP(hipEventCreateWithFlags(&P.planned, hipEventDisableTiming | zt::sync_event_flags()));
+        ZT_HIP(hipEventCreateWithFlags(&P.consumed, hipEventDisableTiming | zt::sync_event_flags()));
         P.used = false;
         P.valid = false;
     }
