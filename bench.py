@@ -380,8 +380,13 @@ def main():
         tr = pmc.get(name, {}).get("traffic")
         if name in ("fc1_agg", "embed_out"):
             ach = ex[name] * bs / shard / us / 1e12
+            # the main stream is confined to the CUs the T-PPR stream does not own (CU masks): the whole-chip peak is
+            # the contract's `peak`; the share of the CUs the kernel can run on is given beside it
+            cus_total = torch.cuda.get_device_properties(device).multi_processor_count
+            cus_used = cus_total - (a.tppr_cus if (not a.no_pipeline and a.tppr_cus > 0) else 0)
             return dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr,
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr, cus=cus_used,
+                        frac_of_own_cus=ach / (MFMA_F32_PEAK_TF * cus_used / cus_total),
                         note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
                              "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
         if name == "tppr_stream":

@@ -337,8 +337,11 @@ def _time_identity_tgn(N, E1, k=4):
     return build_tgn(N, E1, D, F, T, k, [0.1], [0.5], w, efeat).eval()
 
 
-def test_time_encode_through_embed_kernel():
-    """g6_timeencode (the reference TimeEncode's outputs for dt = 0 ... 3e8, 16777217, ...) through zt_embed."""
+@pytest.mark.parametrize("k,table", [(4, False), (4, True), (20, True), (10, True)])
+def test_time_encode_through_embed_kernel(k, table):
+    """g6_timeencode (the reference TimeEncode's outputs for dt = 0 ... 3e8, 16777217, ...) through zt_embed:
+    the generic kernel without and with the projected table, and the kernel specialised for D = T = 100
+    (k = 10, 20: its branch-free cosine and the redo of large-argument columns)."""
     g = golden("g6_timeencode")
     dts = g["dts"].ravel()
     # add the padding-slot value f32(t_now) for t_now as large as SuperUser / the bench stream have
@@ -346,7 +349,7 @@ def test_time_encode_through_embed_kernel():
     tw = g["time_w"]
     all_dt = np.concatenate([dts, extra])
     want = np.concatenate([g["enc"].reshape(-1, 100), np.cos(extra[:, None] * tw[None, :]).astype(np.float32)])
-    n, k = len(all_dt), 4
+    n = len(all_dt)
     tgn = _time_identity_tgn(50, 10, k)
     dev = tgn.device
     nodes = torch.ones(n, dtype=torch.int32, device=dev)
@@ -357,7 +360,8 @@ def test_time_encode_through_embed_kernel():
     od[0, :, 2] = torch.from_numpy(all_dt).to(dev)
     ow = torch.zeros_like(od)
     ow[0, :, 2] = 1.0
-    out = tgn.embedding_module.embed_device(tgn.memory.memory, nodes, on, oe, od, ow).cpu().numpy()
+    out = tgn.embedding_module.embed_device(tgn.memory.memory, nodes, on, oe, od, ow,
+                                            memory_obj=tgn.memory if table else None).cpu().numpy()
     got = out[:, 100:]
     assert np.abs(got[: len(dts)] - want[: len(dts)]).max() <= 2e-6          # vs the reference's own outputs
     # vs float64 cos of the float32 product (what torch.cos approximates); the ocml cos has its own 1e-7
@@ -682,3 +686,37 @@ def test_fused_training_backward_full_dims(F, k):
             assert (d > 1e-4 * scale).mean() <= 0.01, "%s in batch %d: %.3g of the elements differ" % (pn, b, (d > 1e-4 * scale).mean())
             assert np.linalg.norm(ga[pn] - gb[pn]) <= 2e-3 * max(1.0, np.linalg.norm(gb[pn])), "%s in batch %d" % (pn, b)
     assert any(np.abs(res[True][b][1]["memory_updater.memory_updater.weight_ih"]).max() > 0 for b in range(1, 6))
+
+
+@pytest.mark.parametrize("F,k,n", [(1, 20, 1001), (172, 10, 333), (4, 40, 257), (1, 40, 2)])
+def test_specialised_aggregate_equals_generic(F, k, n):
+    """k_fc1_agg_d100 (D = T = 100, k in {10, 20, 40}) against the generic table kernel (ZT_AGG_GENERIC=1) on the
+    same inputs: ragged last tile, empty rows (all-zero weights), time gaps on both sides of the 4e6 switch."""
+    import os
+    D = T = 100
+    N, E1 = 5000, 20000
+    g = torch.Generator().manual_seed(11 + F + k)
+    w = I.model_weights(D, F, T, 2, 77)
+    _, efeat = I.random_tables(N, E1, D, F, 77)
+    tgn = build_tgn(N, E1, D, F, T, k, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
+    dev = tgn.device
+    tgn.memory.memory.copy_(torch.randn((N, D), generator=g).to(dev))
+    nodes = torch.randint(0, N, (n,), generator=g, dtype=torch.int32).to(dev)
+    on = torch.randint(0, N, (2, n, k), generator=g, dtype=torch.int32)
+    oe = torch.randint(0, E1, (2, n, k), generator=g, dtype=torch.int32)
+    od = torch.rand((2, n, k), generator=g) * 3.0e6
+    od[:, ::7] *= 1.0e3                                   # some rows far beyond the fast cosine's range
+    ow = torch.rand((2, n, k), generator=g)
+    ow[:, ::5] = 0.0                                      # rows whose weights sum to 0
+    ow[:, 1::5, k // 2:] = 0.0                            # short dictionaries
+    args = [t.to(dev).contiguous() for t in (on, oe, od.float(), ow.float())]
+    em = tgn.embedding_module
+    fast = em.embed_device(tgn.memory.memory, nodes, *args, memory_obj=tgn.memory).cpu().numpy()
+    os.environ["ZT_AGG_GENERIC"] = "1"
+    try:
+        slow = em.embed_device(tgn.memory.memory, nodes, *args, memory_obj=tgn.memory).cpu().numpy()
+    finally:
+        del os.environ["ZT_AGG_GENERIC"]
+    plain = em.embed_device(tgn.memory.memory, nodes, *args).cpu().numpy()          # no table at all
+    assert np.abs(fast - slow).max() <= 2e-5 * max(1.0, np.abs(slow).max())
+    assert np.abs(fast - plain).max() <= 1e-4 * max(1.0, np.abs(plain).max())
