@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
-                         "(0 = no masks; default: 48 for the streaming strategy, whose update kernel is latency-bound, "
+                         "(0 = no masks; default: whole XCDs -- 64 at bs >= 2048, else 32 -- for the streaming strategy, "
                          "0 for the pruning strategy, whose query kernel wants the whole chip)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
@@ -267,7 +267,9 @@ def main():
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
         if a.tppr_cus < 0:
-            a.tppr_cus = 48 if wl["strategy"] == "streaming" else 0
+            # whole XCDs (32 CUs, one L2 each): a mask that splits an XCD leaves the main stream a straggler XCD.
+            # Two XCDs for the T-PPR stream at C5's batch (its non-hub tasks need the waves), one for small batches.
+            a.tppr_cus = (64 if bs >= 2048 else 32) if wl["strategy"] == "streaming" else 0
         if world > 1 and not rehearsal:
             a.tppr_cus = 0          # RCCL kernels run on the main stream: keep it an ordinary (unmasked) stream
         try:
