@@ -201,6 +201,10 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--profile-every", type=int, default=-1,
+                    help="record HIP events around every n-th launch of each kernel (default: every launch at "
+                         "bs >= 2048; every 4th for small batches, where two event records per kernel are a "
+                         "visible share of a 0.15 ms step)")
     ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
                          "(0 = no masks; default: whole XCDs -- 64 at bs >= 2048, else 32 -- for the streaming strategy, "
@@ -321,7 +325,7 @@ def main():
     run(prefill, a.warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
-        lib.zt_profile_enable(1)
+        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else (1 if bs >= 2048 else 4))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -55,7 +55,8 @@ int zt_stream_destroy(void *stream);
  * the reference's unsynchronised wall-clock accumulators t_tppr etc.,
  * modules/embedding_module.py:73,220-225).  Names: tppr_prepass, tppr_stream,
  * tppr_cleanup, pruned_topk, embed_prep, fc1_agg, embed_out, store_messages,
- * gru_update.  zt_profile_read synchronises the device. */
+ * gru_update.  zt_profile_enable(n): 0 off, 1 every launch, n > 1 every n-th
+ * launch of each kernel (sampling).  zt_profile_read synchronises the device. */
 int zt_profile_enable(int on);
 int zt_profile_reset(void);
 int zt_profile_read(const char *name, int64_t *count, double *total_ms);

@@ -94,7 +94,7 @@ def _worker(rank, world, port, out):
 
 @pytest.mark.parametrize("world", [2])
 def test_exchange_touched_rows_gloo(world):
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
@@ -130,7 +130,7 @@ def _grads_worker(rank, world, port, out):
 def test_allreduce_gradients_gloo():
     """The bucketed gradient all-reduce of data-parallel training (on GPUs: RCCL) with world_size 2 on gloo."""
     import torch.multiprocessing as mp
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
     out = mgr.dict()
     mp.spawn(_grads_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert len(out) == 2

@@ -80,7 +80,7 @@ CFGS = {
 @pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4")])
 def test_sharded_equals_single(world, cfg_name):
     cfg = CFGS[cfg_name]
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
     ref = mgr.dict()
     mp.spawn(_run, args=(1, _free_port(), cfg, ref), nprocs=1, join=True)
     out = mgr.dict()
@@ -170,7 +170,7 @@ def test_data_parallel_training_step_equals_single():
     """two ranks, each embedding and scoring half of the batch's edges, gradients summed with
     the bucketed all-reduce (gloo here, RCCL on a node): loss and all parameter gradients of four dependent
     training steps equal the single-process step; the replicated state stays identical."""
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
     ref, out = mgr.dict(), mgr.dict()
     mp.spawn(_train_run, args=(1, _free_port(), ref), nprocs=1, join=True)
     mp.spawn(_train_run, args=(2, _free_port(), out), nprocs=2, join=True)

@@ -740,53 +740,59 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
     const unsigned mL = fastdiv_magic((unsigned)ldx);
     f32x4 acc[OUT_MT][NTW];
 
-    if (tid < OUT_ROWS) {
-        int nd = 0;
-        if (tid < nr) {
-            nd = nodes[r0 + tid];
-            if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
+    // blockIdx.y = 0: the source path (two dependent layers); 1 + m: fc2 of model m.  The paths are independent,
+    // and the kernel's time is the latency of ONE workgroup (there are fewer workgroups than the chip holds).
+    const int path = blockIdx.y;
+    if (path == 0) {
+        if (tid < OUT_ROWS) {
+            int nd = 0;
+            if (tid < nr) {
+                nd = nodes[r0 + tid];
+                if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
+            }
+            rid[tid] = nd;
         }
-        rid[tid] = nd;
-    }
-    __syncthreads();
-    // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
-    for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
-        const int g = fastdiv(f, mL), c = f - g * ldx;
-        X[f] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
-    }
-    __syncthreads();
-    small_gemm(X, ldx, fc1s_p, Dp, NT, wave, lane, acc);
-#pragma unroll
-    for (int b = 0; b < NTW; ++b) {
-        const int col = (wave + b * AGG_WAVES) * 16 + r16;
-        if (col >= Dp) continue;
-        const float bias = col < D ? fc1s_b[col] : 0.f;
-#pragma unroll
-        for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = acc[a][b][j] + bias;
-                Y[(size_t)(a * 16 + g4 * 4 + j) * ldx + col] = (col < D && v > 0.f) ? v : 0.f;
-            }
-    }
-    __syncthreads();
-    small_gemm(Y, ldx, fc2s_p, Dp, NT, wave, lane, acc);
-#pragma unroll
-    for (int b = 0; b < NTW; ++b) {
-        const int col = (wave + b * AGG_WAVES) * 16 + r16;
-        if (col >= D) continue;
-        const float bias = fc2s_b[col];
-#pragma unroll
-        for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int g = a * 16 + g4 * 4 + j;
-                if (g < nr) out[(size_t)(r0 + g) * OW + col] = acc[a][b][j] + bias;
-            }
-    }
-    // ---- neighbour paths: fc2 on the reduced rows of each model ----
-    for (int m = 0; m < M; ++m) {
         __syncthreads();
+        // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
+        for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
+            const int g = fastdiv(f, mL), c = f - g * ldx;
+            X[f] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+        }
+        __syncthreads();
+        small_gemm(X, ldx, fc1s_p, Dp, NT, wave, lane, acc);
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            const int col = (wave + b * AGG_WAVES) * 16 + r16;
+            if (col >= Dp) continue;
+            const float bias = col < D ? fc1s_b[col] : 0.f;
+#pragma unroll
+            for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[a][b][j] + bias;
+                    Y[(size_t)(a * 16 + g4 * 4 + j) * ldx + col] = (col < D && v > 0.f) ? v : 0.f;
+                }
+        }
+        __syncthreads();
+        small_gemm(Y, ldx, fc2s_p, Dp, NT, wave, lane, acc);
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) {
+            const int col = (wave + b * AGG_WAVES) * 16 + r16;
+            if (col >= D) continue;
+            const float bias = fc2s_b[col];
+#pragma unroll
+            for (int a = 0; a < OUT_MT; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = a * 16 + g4 * 4 + j;
+                    if (g < nr) out[(size_t)(r0 + g) * OW + col] = acc[a][b][j] + bias;
+                }
+        }
+        return;
+    }
+    // ---- neighbour path: fc2 on the reduced rows of model m ----
+    {
+        const int m = path - 1;
         for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
             const int g = fastdiv(f, mL), c = f - g * ldx;
             X[f] = (g < nr && c < D) ? H[((size_t)m * N + r0 + g) * D + c] : 0.f;
@@ -1059,7 +1065,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     ZT_PROF_END(s, P_FC1_AGG);
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
-    k_embed_out<<<(unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), AGG_THREADS, lds2, s>>>(
+    k_embed_out<<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>(
         memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
         out_dev, status_dev);
     ZT_PROF_END(s, P_EMBED_OUT);

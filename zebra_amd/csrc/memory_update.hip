@@ -102,7 +102,8 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
     if (take) rows[base + __popcll(bm & ((1ull << lane) - 1ull))] = v;
 }
 
-constexpr int GRU_MT = 2;      // 32 rows per workgroup
+constexpr int GRU_MT = 1;      // 16 rows per workgroup: the kernel's time is one workgroup's latency (<= 1 per CU),
+                               // so smaller tiles on more CUs win over weight-fragment reuse
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight

@@ -24,7 +24,8 @@ struct zt_pipeline {
     struct Slot {
         int32_t *nodes;        // [3 * max_B]  src | dst | neg
         double *ts3;           // [3 * max_B]  (pruning: the query time of every row)
-        int32_t *on, *oe;      // [M][3 * max_B][k]
+        int32_t *buf;          // 4 x [M][3 * max_B][k]
+        int32_t *on, *oe;      // the current batch's four [M][3B][k] arrays inside buf
         float *od, *ow;
         hipEvent_t ready;      // T-PPR outputs complete (side stream)
         hipEvent_t consumed;   // main stream is done with the slot
@@ -50,20 +51,31 @@ zt_pipeline::Slot *find_slot(zt_pipeline *p, const zt_batch *b)
     return nullptr;
 }
 
-// the slot that batch `b` will live in: ids are copied on stream `st` once the slot's previous user is done
-int fill_slot(zt_pipeline *p, const zt_batch *b, hipStream_t st, zt_pipeline::Slot **out)
+// [src | dst | neg] of a batch into a slot (and, for the pruning strategy, the query time of every row)
+__global__ void k_stage_batch(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const int32_t *__restrict__ neg,
+                              const double *__restrict__ ts, long long B, int32_t *__restrict__ nodes, double *__restrict__ ts3)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    nodes[i] = src[i]; nodes[B + i] = dst[i]; nodes[2 * B + i] = neg[i];
+    if (ts3 != nullptr) { const double t = ts[i]; ts3[i] = t; ts3[B + i] = t; ts3[2 * B + i] = t; }
+}
+
+// the slot that batch `b` will live in: ids are copied on stream `st` once the slot's previous user is done.
+// record = false: the caller records `filled` itself (after the prepass it enqueues behind the copy).
+int fill_slot(zt_pipeline *p, const zt_batch *b, hipStream_t st, zt_pipeline::Slot **out, bool record = true)
 {
     zt_pipeline::Slot &s = p->slot[p->next_slot];
     p->next_slot = (p->next_slot + 1) % 3;
     if (s.used) ZT_HIP(hipStreamWaitEvent(st, s.consumed, 0));
-    const size_t nb = (size_t)b->B * sizeof(int32_t);
-    ZT_HIP(hipMemcpyAsync(s.nodes, b->src, nb, hipMemcpyDeviceToDevice, st));
-    ZT_HIP(hipMemcpyAsync(s.nodes + b->B, b->dst, nb, hipMemcpyDeviceToDevice, st));
-    ZT_HIP(hipMemcpyAsync(s.nodes + 2 * b->B, b->neg, nb, hipMemcpyDeviceToDevice, st));
-    if (p->d.csr != nullptr)
-        for (int r = 0; r < 3; ++r)
-            ZT_HIP(hipMemcpyAsync(s.ts3 + (size_t)r * b->B, b->ts, (size_t)b->B * sizeof(double), hipMemcpyDeviceToDevice, st));
-    ZT_HIP(hipEventRecord(s.filled, st));
+    k_stage_batch<<<(unsigned)((b->B + 255) / 256), 256, 0, st>>>(b->src, b->dst, b->neg, b->ts, b->B, s.nodes,
+                                                                  p->d.csr != nullptr ? s.ts3 : nullptr);
+    ZT_LAUNCH_CHECK();
+    if (record) ZT_HIP(hipEventRecord(s.filled, st));
+    // the four output arrays [M][3B][k] of this batch, back to back in the slot's buffer
+    const size_t per = (size_t)p->d.M * 3 * b->B * p->d.k;
+    s.on = s.buf; s.oe = s.buf + per;
+    s.od = reinterpret_cast<float *>(s.buf + 2 * per); s.ow = reinterpret_cast<float *>(s.buf + 3 * per);
     s.key = b->eidx; s.B = b->B; s.token = 0; s.launched = false; s.used = true;
     *out = &s;
     return ZT_OK;
@@ -81,10 +93,14 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, const zt_batch *b, int64_t
         // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): start from zeros
         const int64_t n = row_hi - row_lo;
         const size_t per = (size_t)d.M * n * d.k;
-        ZT_HIP(hipMemsetAsync(s.on, 0, per * 4, p->side));
-        ZT_HIP(hipMemsetAsync(s.oe, 0, per * 4, p->side));
-        ZT_HIP(hipMemsetAsync(s.od, 0, per * 4, p->side));
-        ZT_HIP(hipMemsetAsync(s.ow, 0, per * 4, p->side));
+        if (n == 3 * b->B) {
+            ZT_HIP(hipMemsetAsync(s.on, 0, 4 * per * 4, p->side));          // the four arrays follow each other (fill_slot)
+        } else {
+            ZT_HIP(hipMemsetAsync(s.on, 0, per * 4, p->side));
+            ZT_HIP(hipMemsetAsync(s.oe, 0, per * 4, p->side));
+            ZT_HIP(hipMemsetAsync(s.od, 0, per * 4, p->side));
+            ZT_HIP(hipMemsetAsync(s.ow, 0, per * 4, p->side));
+        }
         for (int m = 0; m < d.M; ++m) {
             const size_t o = (size_t)m * n * d.k;
             int rc = zt_pruned_topk(d.csr, s.nodes + row_lo, s.ts3 + row_lo, n, d.width, d.depth, d.alpha[m], d.beta[m], d.k,
@@ -130,8 +146,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
     for (auto &s : p->slot) {
         ZT_HIP(hipMalloc(&s.nodes, rows * sizeof(int32_t)));
         ZT_HIP(hipMalloc(&s.ts3, rows * sizeof(double)));
-        ZT_HIP(hipMalloc(&s.on, per * 4)); ZT_HIP(hipMalloc(&s.oe, per * 4));
-        ZT_HIP(hipMalloc(&s.od, per * 4)); ZT_HIP(hipMalloc(&s.ow, per * 4));
+        ZT_HIP(hipMalloc(&s.buf, 4 * per * 4));
         ZT_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming | zt::sync_event_flags()));
@@ -147,8 +162,7 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     if (!p) return ZT_OK;
     (void)hipDeviceSynchronize();
     for (auto &s : p->slot) {
-        (void)hipFree(s.nodes); (void)hipFree(s.ts3); (void)hipFree(s.on); (void)hipFree(s.oe); (void)hipFree(s.od);
-        (void)hipFree(s.ow);
+        (void)hipFree(s.nodes); (void)hipFree(s.ts3); (void)hipFree(s.buf);
         (void)hipEventDestroy(s.ready); (void)hipEventDestroy(s.consumed); (void)hipEventDestroy(s.filled);
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
@@ -206,11 +220,11 @@ extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_ba
     }
     if (plan != nullptr && plan->B > 0 && plan->B <= d.max_B && find_slot(p, plan) == nullptr) {
         zt_pipeline::Slot *q;
-        rc = fill_slot(p, plan, p->plan_s, &q);
+        rc = fill_slot(p, plan, p->plan_s, &q, pruning);          // streaming: `filled` is recorded behind the prepass
         if (rc != ZT_OK) return rc;
         if (!pruning) {
             rc = zt_tppr_plan(d.tppr, q->nodes, plan->eidx, plan->B, 3, -1, &q->token, p->plan_s);
-            if (rc != ZT_OK) return rc;
+            if (rc != ZT_OK) { (void)hipEventRecord(q->filled, p->plan_s); return rc; }
             ZT_HIP(hipEventRecord(q->filled, p->plan_s));
         }
     }

@@ -77,22 +77,26 @@ hipEvent_t prof_event()
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
+int g_prof_every = 1;                 // time every n-th launch of each kernel (zt_profile_enable(n))
+long long g_prof_seen[P_COUNT];
+long long g_prof_open[P_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // index of the open record per kernel
 }  // namespace
 void prof_begin(hipStream_t s, int id)
 {
+    if ((g_prof_seen[id]++ % g_prof_every) != 0) return;      // not sampled: prof_end finds no open record
     ProfRec r{prof_event(), prof_event(), id, true};
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
+    g_prof_open[id] = (long long)g_prof_recs.size();
     g_prof_recs.push_back(r);
 }
 void prof_end(hipStream_t s, int id)
 {
-    for (size_t i = g_prof_recs.size(); i-- > 0;)
-        if (g_prof_recs[i].id == id && g_prof_recs[i].open) {
-            (void)hipEventRecord(g_prof_recs[i].b, s);
-            g_prof_recs[i].open = false;
-            return;
-        }
+    const long long i = g_prof_open[id];
+    if (i < 0 || i >= (long long)g_prof_recs.size() || !g_prof_recs[i].open || g_prof_recs[i].id != id) return;
+    (void)hipEventRecord(g_prof_recs[i].b, s);
+    g_prof_recs[i].open = false;
+    g_prof_open[id] = -1;
 }
 
 }  // namespace zt
@@ -102,6 +106,8 @@ using namespace zt;
 extern "C" int zt_profile_enable(int on)
 {
     g_prof_on = on != 0;
+    g_prof_every = on > 1 ? on : 1;
+    for (int i = 0; i < P_COUNT; ++i) g_prof_seen[i] = 0;
     return ZT_OK;
 }
 
@@ -110,7 +116,7 @@ extern "C" int zt_profile_reset(void)
     (void)hipDeviceSynchronize();
     for (auto &r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
     g_prof_recs.clear();
-    for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; }
+    for (int i = 0; i < P_COUNT; ++i) { g_prof_ms[i] = 0; g_prof_n[i] = 0; g_prof_open[i] = -1; }
     return ZT_OK;
 }
 
@@ -127,6 +133,7 @@ extern "C" int zt_profile_read(const char *name, int64_t *count, double *total_m
         g_prof_pool.push_back(r.b);
     }
     g_prof_recs.clear();
+    for (int i = 0; i < P_COUNT; ++i) g_prof_open[i] = -1;
     for (int i = 0; i < P_COUNT; ++i)
         if (strcmp(name, g_prof_names[i]) == 0) {
             if (count) *count = g_prof_n[i];
@@ -268,10 +275,10 @@ __device__ __forceinline__ void latch_failure(int *latch, int code)
 // K0: a set is planned afresh: the status of the launch it last served is history (the handle's latch keeps it)
 __global__ void k_plan_begin(int *ctl) { if (threadIdx.x == 0) { ctl[2] = 0; ctl[13] = 0; } }
 
-__global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
-                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl, int *latch)
+__device__ __forceinline__ void d_count(int a, const int *__restrict__ nodes, const long long *__restrict__ eidx,
+                                        long long role_stride, int B, int n_roles, long long N, int *cnt, int *slot,
+                                        int *ctl, int *latch)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
     const int r = a / B, i = a % B;
     const int x = nodes[(long long)r * role_stride + i];
@@ -293,11 +300,16 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
     slot[a] = atomicAdd(&cnt[x], 1);
 }
 
-// K2: the first access of each node reserves a contiguous range of `list`.
-__global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
-                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+__global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
+                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl, int *latch)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    d_count(blockIdx.x * blockDim.x + threadIdx.x, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
+}
+
+// K2: the first access of each node reserves a contiguous range of `list`.
+__device__ __forceinline__ void d_reserve(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                          const int *cnt, int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+{
     if (a >= B * n_roles) return;
     if (slot[a] == 0) {
         const int x = nodes[(long long)(a / B) * role_stride + a % B];
@@ -310,11 +322,17 @@ __global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, 
     }
 }
 
-// K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
-__global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of, int *chain_node,
-                             int *chain_len, int max_chains)
+__global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
 {
-    const int t = threadIdx.x;                     // MAX_HOT threads
+    d_reserve(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+}
+
+// K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
+__device__ __forceinline__ void d_hot_select(int t, int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of,
+                                             int *chain_node, int *chain_len, int max_chains)
+{
+    if (t >= MAX_HOT) return;                      // MAX_HOT threads take part
     int nh = ctl[3];
     nh = nh < MAX_HOT ? nh : MAX_HOT;
     if (t < MAX_CHAINS) chain_len[t] = 0;
@@ -331,11 +349,16 @@ __global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, 
     if (t == 0) ctl[4] = nh < max_chains ? nh : max_chains;
 }
 
-// K2c: every edge with a hub endpoint is owned by that hub's chain (the more-touched hub if both are).
-__global__ void k_own(const int *__restrict__ nodes, long long role_stride, int B, const int *cnt, const int *slot,
-                      const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+__global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of, int *chain_node,
+                             int *chain_len, int max_chains)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    d_hot_select(threadIdx.x, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+}
+
+// K2c: every edge with a hub endpoint is owned by that hub's chain (the more-touched hub if both are).
+__device__ __forceinline__ void d_own(int i, const int *__restrict__ nodes, long long role_stride, int B, const int *cnt,
+                                      const int *slot, const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+{
     if (i >= B) return;
     int owner = -1;
     if (slot[i] >= 0 && slot[B + i] != -1) {        // valid edge
@@ -350,6 +373,12 @@ __global__ void k_own(const int *__restrict__ nodes, long long role_stride, int 
         }
     }
     owner_of[i] = owner;
+}
+
+__global__ void k_own(const int *__restrict__ nodes, long long role_stride, int B, const int *cnt, const int *slot,
+                      const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+{
+    d_own(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
 }
 
 // K2d: one wavefront per chain sorts its edges ascending (rank by counting).
@@ -372,24 +401,29 @@ __global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *ch
 }
 
 // K3: scatter accesses into their node's range, encoded (edge << 2) | role.
-__global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
-                       const int *slot, int *list)
+__device__ __forceinline__ void d_fill(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                       const int *off, const int *slot, int *list)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
     const int s = slot[a];
     if (s < 0) return;
     list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = ((a % B) << 2) | (a / B);   // (edge << 2) | role
 }
 
+__global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
+                       const int *slot, int *list)
+{
+    d_fill(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, off, slot, list);
+}
+
 // K4: per access, from its node's group:
 //   wo    = number of writer accesses by earlier edges  (= ordinal of the last earlier writer)
 //   pflag = the latest earlier edge touching the node, if that access was a reader, else -1
 //   nxt   = how many later edges touch the node (the length of the chain waiting for this access)
-__global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
-                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
+__device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                       const int *cnt, const int *off, const int *slot, const int *list, int *wo,
+                                       int *pflag, int *nxt)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= B * n_roles) return;
     if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0; return; }
     const int x = nodes[(long long)(a / B) * role_stride + a % B];
@@ -419,18 +453,75 @@ __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int
     pflag[a] = (best >= 0 && best_role == 2) ? best : -1;
 }
 
-// K5: restore the per-node counters and the control words for the next call.
-__global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
-                          int *cnt, int *ctl, const int *hot_node, int *chain_of)
+__global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    d_deps(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+}
+
+// K5: restore the per-node counters and the control words for the next call.
+__device__ __forceinline__ void d_cleanup(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                          const int *slot, int *cnt, int *ctl, const int *hot_node, int *chain_of)
+{
     if (a < MAX_HOT && a < ctl[3]) chain_of[hot_node[a]] = -1;
     if (a >= B * n_roles) return;
     if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
 }
 
+__global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
+                          int *cnt, int *ctl, const int *hot_node, int *chain_of)
+{
+    d_cleanup(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
+}
+
 // K6: control words back to zero (after k_cleanup has read ctl[3]); ctl[4] = chains stays for k_stream.
 __global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 4 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
+
+// The whole prepass as ONE workgroup, for launches of at most PRE_FUSED_MAX accesses (small batches: there the ten
+// launches above cost more on the host and in launch gaps than the work itself).  Same steps, same arrays, same
+// results; the steps are separated by workgroup barriers instead of kernel boundaries.
+constexpr int PRE_FUSED_MAX = 4096;
+constexpr int PRE_THREADS = 1024;
+__global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
+    const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
+    long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
+    int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
+    int max_chains)
+{
+    __shared__ int e[CH_MAX];
+    const int tid = threadIdx.x, A = B * n_roles;
+    if (tid == 0) { ctl[2] = 0; ctl[13] = 0; }                                   // k_plan_begin
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_count(a, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_reserve(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_fill(a, nodes, role_stride, B, n_roles, off, slot, list);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+    d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+    __syncthreads();
+    for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
+    __syncthreads();
+    const int n_ch = max_chains > 0 ? ctl[4] : 0;                                // k_chain_sort, chain after chain
+    for (int c = 0; c < n_ch; ++c) {
+        int len = chain_len[c];
+        len = len < CH_MAX ? len : CH_MAX;
+        for (int p = tid; p < len; p += PRE_THREADS) e[p] = chain_edges[c * CH_MAX + p];
+        __syncthreads();
+        for (int p = tid; p < len; p += PRE_THREADS) {
+            const int me = e[p];
+            int r = 0;
+            for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
+            chain_edges[c * CH_MAX + r] = me;
+        }
+        __syncthreads();
+    }
+    for (int a = tid; a < (A > MAX_HOT ? A : MAX_HOT); a += PRE_THREADS)
+        d_cleanup(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
+    __syncthreads();
+    if (tid < 4 && tid != 2) ctl[tid] = 0;                                       // k_reset_ctl
+}
 
 // ------------------------------------------------------------- row access ----
 struct Row {
@@ -1678,23 +1769,33 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
     const int n_models = model < 0 ? h->M : 1;
     int grid, max_chains;
     launch_shape(h, h->run_cus > 0 ? h->run_cus : h->n_cu, B, n_models, &grid, &max_chains);
-    ZT_PROF_BEGIN(s, P_PREPASS);
-    k_plan_begin<<<1, 64, 0, s>>>(h->ctl);
-    k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl, h->latch_dev);
-    k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
-    k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
-    k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
-    k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
-                                       max_chains);
-    k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
-                                           h->chain_edges, h->owner_of);
-    if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges);
-    ZT_PROF_END(s, P_PREPASS);
-    // per-node counters and the control words back to their rest state: the set is ready for k_stream
-    ZT_PROF_BEGIN(s, P_CLEANUP);
-    k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
-    k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
-    ZT_PROF_END(s, P_CLEANUP);
+    static const bool fused_ok = !(getenv("ZT_PREPASS_FUSED") && atoi(getenv("ZT_PREPASS_FUSED")) == 0);
+    if (fused_ok && A <= PRE_FUSED_MAX) {
+        ZT_PROF_BEGIN(s, P_PREPASS);
+        k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
+                                                  h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
+                                                  h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
+                                                  max_chains);
+        ZT_PROF_END(s, P_PREPASS);
+    } else {
+        ZT_PROF_BEGIN(s, P_PREPASS);
+        k_plan_begin<<<1, 64, 0, s>>>(h->ctl);
+        k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl, h->latch_dev);
+        k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
+        k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
+        k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
+        k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
+                                           max_chains);
+        k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
+                                               h->chain_edges, h->owner_of);
+        if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges);
+        ZT_PROF_END(s, P_PREPASS);
+        // per-node counters and the control words back to their rest state: the set is ready for k_stream
+        ZT_PROF_BEGIN(s, P_CLEANUP);
+        k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
+        k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
+        ZT_PROF_END(s, P_CLEANUP);
+    }
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.planned, s));
     P.nodes = nodes; P.B = B; P.n_roles = n_roles; P.model = model; P.grid = grid; P.max_chains = max_chains;

@@ -7,6 +7,7 @@ libzebra_amd.so on the GPU; torch is only used for device buffers and the
 current HIP stream.  There is no CPU fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,10 +33,12 @@ class _TpprState:
         check(lib().zt_tppr_create(C.byref(h), C.c_int64(num_nodes), C.c_int32(k), C.c_int32(n_tppr),
                                    ptr(self._alpha), ptr(self._beta)), "zt_tppr_create")
         self.h = h
+        self._pid = os.getpid()
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h:
+        # a fork()ed child inherits the Python object but not the GPU context: the handle is the parent's to free
+        if h and getattr(self, "_pid", None) == os.getpid():
             try:
                 lib().zt_tppr_destroy(h)
             except Exception:
@@ -292,6 +295,7 @@ class NeighborFinder:
 
     def __init__(self, node_to_neighbors, node_to_edge_idxs, node_to_edge_timestamps, _handle=None):
         self._dev = _dev()
+        self._pid = os.getpid()
         if _handle is not None:
             self._h = _handle
         else:
@@ -318,7 +322,7 @@ class NeighborFinder:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and getattr(self, "_pid", None) == os.getpid():      # never from a fork()ed child (see _TpprState)
             try:
                 lib().zt_csr_destroy(h)
             except Exception:
