@@ -21,6 +21,12 @@ enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_A
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, int id);
 void prof_end(hipStream_t s, int id);
+// zt_tppr_stream for callers inside the library (tppr_stream.hip)
+int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B,
+                   int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
+                   float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
+                   hipEvent_t *done_out);
+
 // extra flags for events that only order streams of this device (experiment knob: ZT_EVENT_FLAGS, hex)
 inline unsigned sync_event_flags()
 {

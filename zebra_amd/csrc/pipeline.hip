@@ -28,6 +28,7 @@ struct zt_pipeline {
         int32_t *on, *oe;      // the current batch's four [M][3B][k] arrays inside buf
         float *od, *ow;
         hipEvent_t ready;      // T-PPR outputs complete (side stream)
+        hipEvent_t ready_ev;   // the event to wait on for that: `ready`, or the one the T-PPR update recorded itself
         hipEvent_t consumed;   // main stream is done with the slot
         hipEvent_t filled;     // ids copied in (plan / side stream)
         const int64_t *key;    // the batch it holds (eidx pointer), nullptr = free
@@ -86,9 +87,15 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, const zt_batch *b, int64_t
 {
     const zt_pipeline_desc &d = p->d;
     ZT_HIP(hipStreamWaitEvent(p->side, s.filled, 0));
+    s.ready_ev = s.ready;
     if (d.tppr != nullptr) {
-        int rc = zt_tppr_stream(d.tppr, s.nodes, b->ts, b->eidx, b->B, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side);
+        // `filled` was recorded behind the prepass (when there is one): no second wait; the event the update kernel
+        // records for the plan set doubles as this slot's `ready`
+        hipEvent_t done = nullptr;
+        int rc = zt::tppr_stream_ex(d.tppr, s.nodes, b->ts, b->eidx, b->B, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
+                                    true, &done);
         if (rc != ZT_OK) return rc;
+        if (done != nullptr) { s.ready_ev = done; s.launched = true; return ZT_OK; }
     } else {
         // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): start from zeros
         const int64_t n = row_hi - row_lo;
@@ -205,7 +212,7 @@ extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_ba
     zt_pipeline::Slot *s = find_slot(p, cur);
     if (s == nullptr) { rc = fill_slot(p, cur, p->side, &s); if (rc != ZT_OK) return rc; }
     if (!s->launched) { rc = launch_tppr(p, *s, cur, row_lo, row_hi); if (rc != ZT_OK) return rc; }
-    ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready, 0));
+    ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0));
     // ---- the next batch's query beside this batch's aggregation; the prepass of the one after it ----
     if (next != nullptr && next->B > 0 && next->B <= d.max_B) {
         zt_pipeline::Slot *n = find_slot(p, next);

@@ -769,9 +769,17 @@ struct Front {
 // sits behind them.  The top-k works on these register values (topk_reg: ranks by lane broadcasts, tie
 // test by a DPP OR-reduction, quicksort replay on the compacted ranks only when ties decide).  Compared
 // with merge_pair the candidate list, the selection vector and the gathered result never touch LDS.
+// The scale factors of an update depend on the row's norm only, and along a hub chain the norm follows
+// norm <- norm * beta + beta from hop to hop: a wave works them out (two float64 divisions) for the norm it
+// EXPECTS while it waits for the mailbox; merge_front takes them if the norm that arrives is that one.
+struct PreScale {
+    double norm, scale_s1, scale_s2;
+    bool valid;
+};
+
 __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
                                    const Row &r2, u64 newkey, double newts, Front &F, int pre = 0,
-                                   int g_stamp_i = -1)
+                                   int g_stamp_i = -1, const PreScale *ps = nullptr)
 {
     STAMP2(0);
     int n1;
@@ -779,6 +787,10 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     if (r1.norm == 0.0) {                       // :514-519
         n1 = 0;
         scale_s2 = 1.0 - alpha;
+    } else if (ps != nullptr && ps->valid && ps->norm == r1.norm) {
+        n1 = __builtin_amdgcn_readfirstlane(r1.len);
+        scale_s1 = ps->scale_s1;                // the same expressions on the same norm, evaluated ahead
+        scale_s2 = ps->scale_s2;
     } else {                                    // :520-527
         n1 = __builtin_amdgcn_readfirstlane(r1.len);        // row headers are wave-uniform: say so
         const double new_norm = r1.norm * beta + beta;
@@ -1159,8 +1171,14 @@ __device__ inline bool wait_seq(const int *p, int want, int *status, int what, i
 
 // Apply edge i of the launch for emitted model mo.  mail != nullptr: this wave belongs to the chain
 // workgroup of node `hub`; prev_edge = the chain's previous edge (or -1).
+// what a chain wave remembers from its previous hop: the hub's norm after it, and the chain position
+struct ChainHint {
+    double norm_out;
+    int tpos;
+};
+
 __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
-                                    long long hub, int prev_edge, int next_edge, int tpos)
+                                    long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint = nullptr)
 {
     const int k = h.k, B = A.B, n_roles = A.n_roles;
     const int m = A.m_lo + mo;
@@ -1240,6 +1258,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     u64 hub_alt = 0ull;                         // (this lane's, if lane < hub_nalt)
     bool hub_final = true;                      // stage 1 was already the dictionary order
     const bool hub_is_u = u == hub;
+    PreScale pre_scale;
+    pre_scale.valid = false;
+    int free_seen = -1;                         // seq_free of my ring slot as read with the row (-1: not read)
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
         WL(0, 6);
@@ -1259,18 +1280,32 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 wave_sync();
             }
         }
+        // ... and the scale factors for the norm the hub will have if the hops since my last one were ordinary
+        if (hint != nullptr && hint->tpos >= 0 && tpos - hint->tpos <= 16) {
+            double pn = hint->norm_out;
+            for (int q = hint->tpos + 1; q < tpos; ++q) pn = pn * beta + beta;
+            if (pn != 0.0) {
+                const double nn = pn * beta + beta;
+                pre_scale.norm = pn;
+                pre_scale.scale_s1 = pn / nn * beta;
+                pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
+                pre_scale.valid = true;
+            }
+        }
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
 #ifdef ZT_STAMP
         { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(6); }
 #endif
+        // one batch of LDS reads: the row, its provisional marks, and whether my own ring slot is free again
         Row rm;
         rm.len = in_slot->len; rm.norm = in_slot->norm;
         rm.key = in_slot->key[lane & 31]; rm.ts = in_slot->ts[lane & 31]; rm.w = in_slot->w[lane & 31];
-        if (hub_is_u) ru = rm; else rv = rm;
         hub_unc = in_slot->unc;
         hub_munc = in_slot->munc;
         hub_nalt = in_slot->n_alt;
         hub_alt = in_slot->alt_key[lane & 31];
+        free_seen = lds_load_seq(&out_slot->seq_free);
+        if (hub_is_u) ru = rm; else rv = rm;
         hub_ordered = hub_unc == 0u && hub_munc == 0;   // nothing provisional: the arrangement is the dictionary order
         hub_final = hub_ordered;
     }
@@ -1326,8 +1361,10 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         // a slot of the ring is reused every MAIL_R positions: wait until the reader of its previous content
         // (chain position tpos - MAIL_R + 1) has let go of it
         auto ring_free = [&]() {
-            if (tpos >= MAIL_R)
-                if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
+            if (tpos >= MAIL_R) {
+                if (free_seen == tpos - MAIL_R + 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                else if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
+            }
         };
         auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u, int munc = 0, int n_alt = 0) {
             if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
@@ -1350,6 +1387,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             }
             const double new_norm = a.norm * beta + beta;
             if (mail != nullptr && xa == hub) {
+                if (hint != nullptr) { hint->norm_out = new_norm; hint->tpos = tpos; }
                 ring_free();
                 publish_set(c.slot, n, new_norm);
                 if (c.slot >= 0) out_slot->pos[c.slot] = c.slot;
@@ -1366,6 +1404,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             // ---- the hub's update on a row that may still be in its provisional arrangement ----
             const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)x2;
             const double new_norm = r1.norm * beta + beta;
+            if (hint != nullptr) { hint->norm_out = new_norm; hint->tpos = tpos; }
             Front F;
             bool settled = hub_final;                                    // the row is known to be the dictionary
             if (!settled && hub_munc > 0) {
@@ -1375,7 +1414,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
                 if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
             }
-            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1);
+            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale);
             if (!settled) {
                 // a key match (or the new key) on an entry whose slot is provisional: the weights by position would
                 // depend on identities.  Likewise a picked member of a straddling run that would be kept: whether it
@@ -1555,11 +1594,14 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         int len = h.chain_len[c];
         len = len < CH_MAX ? len : CH_MAX;
         const int *edges = h.chain_edges + c * CH_MAX;
+        ChainHint hint;
+        hint.norm_out = 0.0; hint.tpos = -1;
         for (;;) {
             int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= len) break;
-            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t);
+            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t,
+                         &hint);
         }
     }
 
@@ -1805,7 +1847,8 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
 // k_stream over plan set q (planned on any stream), on stream s.
 static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, const long long *eidx,
                      long long role_stride, int B, int n_roles, int emit, int model, long long out_rows, int32_t *on,
-                     int32_t *oe, float *od, float *ow, hipStream_t s)
+                     int32_t *oe, float *od, float *ow, hipStream_t s, bool plan_ordered = false,
+                     hipEvent_t *done_out = nullptr)
 {
     zt_tppr::PlanSet &P = h->set[q];
     if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
@@ -1814,7 +1857,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
         h->epoch = 0;
     }
     h->epoch += 1;
-    ZT_HIP(hipStreamWaitEvent(s, P.planned, 0));
+    if (!plan_ordered) ZT_HIP(hipStreamWaitEvent(s, P.planned, 0));      // (the caller has ordered s behind the plan already)
     use_set(h, q);
     h->run_cus = stream_cus(h, s);
     // The plan sized the grid for the CUs it expected.  If THIS stream offers fewer (a CU mask the plan did
@@ -1845,6 +1888,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.consumed, s));
+    if (done_out) *done_out = P.consumed;
     P.used = true;
     P.valid = false;
     return ZT_OK;
@@ -1883,11 +1927,16 @@ extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t 
     return ZT_OK;
 }
 
-extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev,
-                              int64_t B, int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev,
-                              int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev, uint64_t plan_token,
-                              void *stream)
+// zt_tppr_stream with two extras for callers inside the library (pipeline.hip): plan_ordered = `stream` already
+// waits for the stream that made the plan (no second wait packet); *done_out = the event recorded behind the
+// (last) update kernel, so that the caller need not record one of its own.  Every packet between two update
+// kernels on the T-PPR stream costs ~5 us of the step.
+int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B,
+                       int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
+                       float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
+                       hipEvent_t *done_out)
 {
+    if (done_out) *done_out = nullptr;
     if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M) {
         set_error("zt_tppr_stream: bad argument");
         return ZT_ERR_ARG;
@@ -1912,7 +1961,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
                     return ZT_ERR_ARG;
                 }
                 return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
-                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s);
+                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s, plan_ordered, done_out);
             }
         }
         // the plan is gone (reset / copy / import, or two newer plans): fall through to an inline prepass
@@ -1929,10 +1978,19 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
         if (rc != ZT_OK) return rc;
         rc = run_chunk(h, q, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
                        (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr, emit ? out_eidx_dev + oo : nullptr,
-                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s);
+                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s, true, done_out);   // planned on s itself
         if (rc != ZT_OK) return rc;
     }
     return ZT_OK;
+}
+
+extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev,
+                              int64_t B, int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev,
+                              int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev, uint64_t plan_token,
+                              void *stream)
+{
+    return zt::tppr_stream_ex(h, nodes_dev, ts_dev, eidx_dev, B, n_roles, emit, model, out_nodes_dev, out_eidx_dev,
+                              out_dt_dev, out_w_dev, plan_token, stream, false, nullptr);
 }
 
 #ifdef ZT_STAMP

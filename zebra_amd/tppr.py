@@ -38,7 +38,7 @@ class _TpprState:
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
         # a fork()ed child inherits the Python object but not the GPU context: the handle is the parent's to free
-        if h and getattr(self, "_pid", None) == os.getpid():
+        if h and os is not None and getattr(self, "_pid", None) == os.getpid():     # (os is None at interpreter exit)
             try:
                 lib().zt_tppr_destroy(h)
             except Exception:
@@ -322,7 +322,7 @@ class NeighborFinder:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h and getattr(self, "_pid", None) == os.getpid():      # never from a fork()ed child (see _TpprState)
+        if h and os is not None and getattr(self, "_pid", None) == os.getpid():      # never from a fork()ed child
             try:
                 lib().zt_csr_destroy(h)
             except Exception:
