@@ -27,7 +27,8 @@ def main():
     fetch, write, last, workload = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, w = per_kernel(fetch, "FETCH_SIZE", last), per_kernel(write, "WRITE_SIZE", last)
     out = {"workload": workload, "launches_averaged": last, "unit": "bytes per launch", "kernels": {}}
-    names = {"k_stream": "tppr_stream", "k_fc1_agg<true>": "fc1_agg", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
+    names = {"k_stream": "tppr_stream", "k_fc1_agg_d100<20>": "fc1_agg", "k_fc1_agg_d100<40>": "fc1_agg", "k_fc1_agg_d100<10>": "fc1_agg",
+             "k_fc1_agg<true>": "fc1_agg_generic", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
              "k_gru": "gru_update", "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass",
              "k_project_rows": "project_rows"}
     for k, n in names.items():
