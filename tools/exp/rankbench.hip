@@ -68,6 +68,33 @@ __device__ __forceinline__ int rank_c(double vc, u64 live, double *buf)
     __builtin_amdgcn_wave_barrier();
     return (l0 + l1) + (l2 + l3);
 }
+// mate: 0 none; 1 = waves 4-7 (the SIMD mates of waves 0-3) run a float64 FMA loop at equal priority;
+// 2 = the mates run it at priority 0 while waves 0-3 are at priority 3
+__global__ void k2(int mate, int iters, double *out, long long *cyc)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const u64 live = ((1ull << 20) - 1ull) | (((1ull << 21) - 1ull) << 32);
+    if (wave >= 4) {
+        if (mate == 0) return;
+        if (mate == 2) __builtin_amdgcn_s_setprio(0);
+        double a = lane * 1e-3, b = 1.0000001, c = 0.5;
+        for (int it = 0; it < iters * 60; ++it) { a = a * b + c; b = b * 0.9999999 + 1e-9; c = c * b + a; }
+        out[threadIdx.x] = a + b + c;
+        return;
+    }
+    if (mate == 2) __builtin_amdgcn_s_setprio(3);
+    double v = (double)((lane * 37) % 64) * 0.125 + 1.0;
+    int acc = 0;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        const int r = rank_a(v, live);
+        acc += r;
+        v += (double)(r & 1) * 1e-9;
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    out[threadIdx.x] = v + acc;
+    if (threadIdx.x == 0) cyc[3 + mate] = t1 - t0;
+}
 __global__ void k(int mode, int iters, double *out, long long *cyc)
 {
     __shared__ double buf[64];
@@ -90,12 +117,15 @@ __global__ void k(int mode, int iters, double *out, long long *cyc)
 }
 int main()
 {
-    double *out; long long *cyc, h[3];
-    hipMalloc(&out, 64 * 8); hipMalloc(&cyc, 3 * 8);
+    double *out; long long *cyc, h[6];
+    hipMalloc(&out, 512 * 8); hipMalloc(&cyc, 6 * 8);
     const int iters = 2000;
     for (int m = 0; m < 3; ++m) { k<<<1, 64>>>(m, 10, out, cyc); hipDeviceSynchronize(); k<<<1, 64>>>(m, iters, out, cyc); hipDeviceSynchronize(); }
-    hipMemcpy(h, cyc, 24, hipMemcpyDeviceToHost);
+    for (int m = 0; m < 3; ++m) { k2<<<1, 512>>>(m, 10, out, cyc); hipDeviceSynchronize(); k2<<<1, 512>>>(m, iters, out, cyc); hipDeviceSynchronize(); }
+    hipMemcpy(h, cyc, 48, hipMemcpyDeviceToHost);
     const char *names[3] = {"f64 compare vs readlane pair", "u64 compare vs readlane pair", "LDS broadcast b128"};
     for (int m = 0; m < 3; ++m) printf("%-32s %8.1f ticks / rank pass (s_memtime ticks; 48 comparisons)\n", names[m], (double)h[m] / iters);
+    const char *n2[3] = {"8-wave WG, mates idle", "mates busy, equal priority", "mates busy at prio 0, ranker at prio 3"};
+    for (int m = 0; m < 3; ++m) printf("%-40s %8.1f cycles / rank pass\n", n2[m], (double)h[3 + m] / iters);
     return 0;
 }

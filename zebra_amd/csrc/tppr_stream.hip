@@ -1292,7 +1292,13 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 pre_scale.valid = true;
             }
         }
+        // From here to the publication of the new kept set this wave IS the chain: it shares its SIMD with a wave that
+        // is busy with the off-chain half of an earlier hop (replay, partner's update, emission), and at equal
+        // priority the two alternate issue slots.
+        // (Only once the row is there: a wave that SPINS at high priority starves the off-chain work of its SIMD
+        // mate, and later hops wait for that work's results.)
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
+        __builtin_amdgcn_s_setprio(3);
 #ifdef ZT_STAMP
         { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(6); }
 #endif
@@ -1392,6 +1398,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 publish_set(c.slot, n, new_norm);
                 if (c.slot >= 0) out_slot->pos[c.slot] = c.slot;
                 publish_seq(true, true);
+                __builtin_amdgcn_s_setprio(0);
             }
             if (hub_to_memory || xa != hub) store_row_scatter(h, m, xa, lane, n, c, new_norm, tag_base | (unsigned)(oa + 1));
         };
@@ -1505,6 +1512,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                     trueslot = provslot;
                 }
                 publish_seq(true, final_out);                            // the successor can start
+                __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
             }
 #ifdef ZT_STAMP
             { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(7); }
@@ -1528,6 +1536,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                     publish_set(provslot, n_new, new_norm, 0u);
                     if (provslot >= 0) out_slot->pos[provslot] = provslot;
                     publish_seq(true, true);
+                    __builtin_amdgcn_s_setprio(0);
                 } else {
                     if (provslot >= 0) out_slot->pos[provslot] = trueslot;
                     publish_seq(false, true);
@@ -1594,12 +1603,16 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         int len = h.chain_len[c];
         len = len < CH_MAX ? len : CH_MAX;
         const int *edges = h.chain_edges + c * CH_MAX;
+        // (Four waves per chain instead of eight: 835 us -- a wave's whole hop, off-chain half included, is ~16 us.)
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
+        // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
+        // hops away -- was measured: the hops then run strictly one after the other, 10x slower.)
         for (;;) {
             int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= len) break;
+            if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
             process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t,
                          &hint);
         }
