@@ -209,6 +209,9 @@ def main():
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
                          "(0 = no masks; default: whole XCDs -- 64 at bs >= 2048, else 32 -- for the streaming strategy, "
                          "0 for the pruning strategy, whose query kernel wants the whole chip)")
+    ap.add_argument("--group", type=int, default=-1,
+                    help="consecutive batches whose streaming T-PPR update runs as ONE launch (zt_pipeline_set_group); "
+                         "default: as many as fit a launch (<= 8192 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     a = ap.parse_args()
@@ -268,6 +271,8 @@ def main():
     else:
         step = tgn.step_device
 
+    if a.group < 1:
+        a.group = max(1, min(4, 8192 // bs)) if wl["strategy"] == "streaming" else 1
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
         if a.tppr_cus < 0:
@@ -277,11 +282,11 @@ def main():
         if world > 1 and not rehearsal:
             a.tppr_cus = 0          # RCCL kernels run on the main stream: keep it an ordinary (unmasked) stream
         try:
-            tgn.enable_pipeline(tppr_cus=a.tppr_cus)
+            tgn.enable_pipeline(tppr_cus=a.tppr_cus, group=a.group)
         except Exception as exc:                       # no CU-mask support: plain streams
             sys.stderr.write("[bench] CU-masked streams unavailable (%s); using plain streams\n" % exc)
             a.tppr_cus = 0
-            tgn.enable_pipeline(tppr_cus=0)
+            tgn.enable_pipeline(tppr_cus=0, group=a.group)
     main_stream = getattr(tgn, "main_stream", None)
 
     # views of every batch, made once: slicing tensors is host work that is not part of the path
@@ -291,14 +296,15 @@ def main():
     def batch(b):
         return batches[b]
 
+    look = 3 * a.group - 1                      # batches in sight: the rest of this group, the next group, the one after
+
     def run(b0, nb):
-        # exactly nb steps; nothing of step b0+nb is enqueued (no prefetch on the last one)
+        # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)
         ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
         with ctx:
             for b in range(b0, b0 + nb):
-                nxt = batch(b + 1) if (not a.no_pipeline and b + 1 < b0 + nb) else None
-                nxt2 = batch(b + 2) if (not a.no_pipeline and b + 2 < b0 + nb) else None
-                step(*batch(b), prefetch=nxt, plan=nxt2)
+                ahead = [] if a.no_pipeline else batches[b + 1: min(b + 1 + look, b0 + nb)]
+                step(*batch(b), ahead=ahead)
 
     lib = _capi.lib()
     run(0, prefill)
@@ -444,7 +450,8 @@ def main():
                                "prefill %d + warmup %d batches" % (a.workload, "bipartite" if wl["bipartite"] else
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],
                                                                    wl["beta"], wl["strategy"], F, prefill, a.warmup),
-                   "global_batch": bs, "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
+                   "global_batch": bs, "tppr_launch_group": a.group,
+                   "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
         "roofline": roof,
         "roofline_throughput_kernel": roof2,
         "cpu_baseline": cpu,

@@ -386,6 +386,16 @@ int zt_pipeline_update(zt_pipeline *p, const zt_pipeline_desc *desc, int32_t wei
  * synchronisation; errors of the device side are latched (zt_tppr_status, desc.status). */
 int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, const zt_batch *plan,
                      int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
+/* The same step with a longer view of the stream: ahead[0 .. n_ahead) are the batches that follow `cur`, in order.
+ * With zt_pipeline_set_group(p, g), g <= 4, the streaming T-PPR update of g consecutive batches runs as ONE launch
+ * (edges applied in order across them, exactly as in separate calls; every batch's output rows form their own
+ * block), which pays a launch's fixed costs once per group; the pipeline then queries the group after the current
+ * one and plans the one after that, so 3 g - 1 batches in sight keep it full (fewer: smaller groups).  Batches of
+ * a group are equally long (the last may be shorter) and together at most 8192 edges.  zt_pipeline_step is this
+ * call with ahead = {next, plan}.  The pruning strategy carries no state between batches: its group is 1. */
+int zt_pipeline_set_group(zt_pipeline *p, int32_t group);
+int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *ahead, int32_t n_ahead,
+                           int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
 
 /* ------------------------------------------------------------------------ */
 /* TemporalAttentionLayer.forward -- model/temporal_attention.py:7-68        */

@@ -174,6 +174,51 @@ def test_pipelined_step_matches_sequential(tppr_cus, strategy):
             assert np.array_equal(outs["seq"][2][kk], outs[mode][2][kk])
 
 
+@pytest.mark.parametrize("group,look,ragged", [(2, 5, False), (3, 8, True), (4, 11, False), (2, 2, False), (3, 1, True)])
+def test_grouped_tppr_launches_match_sequential(group, look, ragged):
+    """zt_pipeline_set_group: the streaming T-PPR update of `group` consecutive batches as ONE launch (edges in
+    order across the batches, every batch's rows in its own block) must not change any result -- whole batches and
+    row shards, a full view ahead (3 * group - 1 batches), a short one (smaller groups come out), and a stream
+    whose last batch is shorter."""
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    n_e = E - (bs // 3 if ragged else 0)
+    cuts = list(range(0, n_e, bs)) + [n_e]
+    batches = [tuple(x[a:b] for x in t) for a, b in zip(cuts[:-1], cuts[1:])]
+    outs = {}
+    for mode in ("seq", "grouped", "grouped_rows"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode != "seq":
+            tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=group)
+        embs = []
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            for b, cur in enumerate(batches):
+                B = cur[0].numel()
+                rows = (B // 2, 3 * B - 5) if mode == "grouped_rows" else None
+                ahead = batches[b + 1: b + 1 + look] if mode != "seq" else None
+                embs.append(tgn.step_device(*cur, rows=rows, ahead=ahead).clone())
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        outs[mode] = ([e.cpu().numpy() for e in embs], tgn.memory.memory.cpu().numpy(),
+                      tgn.embedding_module.tppr_finder.export_state(0), tgn.embedding_module.tppr_finder.export_state(1))
+        tgn.enable_pipeline(False)
+    for b, cur in enumerate(batches):
+        B = cur[0].numel()
+        assert np.array_equal(outs["seq"][0][b], outs["grouped"][0][b]), "batch %d" % b
+        assert np.array_equal(outs["seq"][0][b][B // 2: 3 * B - 5], outs["grouped_rows"][0][b]), "batch %d (rows)" % b
+    for mode in ("grouped", "grouped_rows"):
+        assert np.array_equal(outs["seq"][1], outs[mode][1])
+        for m in (2, 3):
+            for kk in outs["seq"][m]:
+                assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
+
+
 def test_full_size_step_properties():
     """The whole eval step at BASELINE.json's full-size configuration (C5: 10 M nodes, bs=4096, k=20,
     D=T=100, F=1), checked through size-independent properties: (1) the pipelined schedule (T-PPR one

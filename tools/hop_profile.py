@@ -54,3 +54,28 @@ d = lambda a: np.percentile(a[okm], [10, 50, 90]).round(2)
 print("set chain: publish(t) - publish(t-1):", d(pub[1:] - pub[:-1]), "mean %.2f" % (pub[1:] - pub[:-1])[okm].mean())
 print("  publish(t-1) -> seen(t):", d(seen[1:] - pub[:-1]), " seen -> merge start:", d(st[1:] - seen[1:]),
       " merge start -> rank pass end:", d(rk[1:] - st[1:]), " rank pass end -> publish:", d(pub[1:] - rk[1:]))
+
+# ---- slow hops: what was the hub waiting for? ----
+hop_full = np.diff(x1)
+slow = np.where(hop_full > 6.0)[0] + 1           # hop index (in idx) whose arrival was late
+print("slow hops (> 6 us):", len(slow), "of", len(idx), " extra time %.1f us" % (hop_full[hop_full > 6.0] - np.median(hop_full)).sum())
+last_writer = {}
+deg = np.bincount(np.concatenate([u, v]), minlength=1)
+for i in range(B):
+    pass
+prev_touch = {}
+writer_of = np.full((B, 2), -1)
+for i in range(B):
+    for r, x in enumerate((u[i], v[i])):
+        writer_of[i, r] = prev_touch.get(x, -1)
+    prev_touch[u[i]] = i; prev_touch[v[i]] = i
+for s_i in slow[:12]:
+    e = idx[s_i]
+    partner = v[e] if u[e] == hub else u[e]
+    r = 1 if u[e] == hub else 0
+    j = writer_of[e, r]
+    msg = "edge %d partner %d (deg %d in batch)" % (e, partner, deg[partner] if partner < len(deg) else -1)
+    if j >= 0:
+        msg += "  last writer edge %d: deq %.1f rows %.1f x1 %.1f end %.1f" % (j, t[j, 0], t[j, 1], t[j, 2], t[j, 3])
+    msg += "  | me: deq %.1f rows %.1f x1 %.1f ; prev hub x1 %.1f" % (t[e, 0], t[e, 1], t[e, 2], t[idx[s_i - 1], 2])
+    print(msg)

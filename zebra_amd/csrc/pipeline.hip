@@ -5,38 +5,53 @@
 // Mirrors TGN.compute_temporal_embeddings with train=False (reference model/tgn_model.py:124-174) for
 // device-resident batches; the reference issues the same steps from Python on one stream
 // (train.py:145-146).  The streams:
-//   side  the T-PPR query of batch b+1 (streaming: k_stream, CU-masked to a few compute units because it is
-//         latency-bound; pruning: k_pruned_topk) -- the T-PPR state depends only on the edge stream, never
-//         on the node memory, so it runs one batch ahead;
-//   plan  the dependency prepass of batch b+2 (reads only ids);
-//   main  aggregate + messages + GRU of batch b (the remaining compute units).
-// Three batch slots (ids + the four T-PPR output arrays each) rotate through plan -> query -> consume.
+//   side  the T-PPR query of the batches AFTER the current group (streaming: k_stream, CU-masked to a few
+//         compute units because it is latency-bound; pruning: k_pruned_topk) -- the T-PPR state depends only
+//         on the edge stream, never on the node memory, so it runs ahead;
+//   plan  the dependency prepass of the group after that (reads only ids);
+//   main  aggregate + messages + GRU of the current batch (the remaining compute units).
+// Three slots (ids + the four T-PPR output arrays each) rotate through plan -> query -> consume.
+//
+// GROUPS.  A slot holds a GROUP of up to `group` consecutive batches (zt_pipeline_set_group; default 1) whose
+// streaming T-PPR update runs as ONE launch: edges are applied in order across the batches exactly as in
+// separate calls (the reference's loop has no state between calls other than the dictionaries), each batch's
+// output rows form their own block (StreamArgs::sub_B), and the fixed cost of a launch -- the packets between
+// two kernels on the T-PPR stream, the kernel's start and tail, its cold instruction cache -- is paid once per
+// group.  The caller shows the batches that follow (zt_pipeline_step_ahead); with fewer than 3 * group - 1 of
+// them in sight the groups simply come out smaller.  The pruning strategy has no state to carry: group = 1.
 #include "common.hpp"
 
 #include <cstring>
 
 using namespace zt;
 
+constexpr int MAX_GROUP = 4;
+
 struct zt_pipeline {
     zt_pipeline_desc d;
     hipStream_t side, main_s, plan_s;
-    bool own_streams;
+    int group;                 // batches per T-PPR launch (streaming)
     struct Slot {
-        int32_t *nodes;        // [3 * max_B]  src | dst | neg
-        double *ts3;           // [3 * max_B]  (pruning: the query time of every row)
-        int32_t *buf;          // 4 x [M][3 * max_B][k]
-        int32_t *on, *oe;      // the current batch's four [M][3B][k] arrays inside buf
+        int32_t *nodes;        // [3 * cap]   src of every member | dst ... | neg ...   (role stride = Btot)
+        int32_t *nodes_m;      // [3 * cap]   per member: [src | dst | neg] of that batch (what zt_embed / the GRU read)
+        double *ts;            // [3 * cap]   streaming: ts of every member, concatenated; pruning: query time of every row
+        int64_t *eidx;         // [cap]       concatenated
+        int32_t *buf;          // 4 x [M][3 * cap][k]
+        int32_t *on, *oe;      // the group's four output arrays inside buf ([member][M][3 * B][k] each)
         float *od, *ow;
         hipEvent_t ready;      // T-PPR outputs complete (side stream)
         hipEvent_t ready_ev;   // the event to wait on for that: `ready`, or the one the T-PPR update recorded itself
         hipEvent_t consumed;   // main stream is done with the slot
-        hipEvent_t filled;     // ids copied in (plan / side stream)
-        const int64_t *key;    // the batch it holds (eidx pointer), nullptr = free
-        int64_t B;
+        hipEvent_t filled;     // ids copied in (and, streaming, the prepass made)
+        const int64_t *key[MAX_GROUP];   // the batches it holds (eidx pointers); n = 0: free
+        int64_t B[MAX_GROUP];
+        int n, n_done;
+        int64_t Btot;
         uint64_t token;        // zt_tppr_plan token, 0 = none
-        bool launched, used, filled_on_plan;
+        bool launched, used;
     } slot[3];
     int next_slot;
+    int64_t cap;               // edges a slot can hold
     // compact copies of a row shard's T-PPR outputs (sharded streaming runs only)
     int32_t *sh_on, *sh_oe;
     float *sh_od, *sh_ow;
@@ -45,45 +60,99 @@ struct zt_pipeline {
 
 namespace {
 
-zt_pipeline::Slot *find_slot(zt_pipeline *p, const zt_batch *b)
+struct GroupPtrs {
+    const int32_t *src[MAX_GROUP], *dst[MAX_GROUP], *neg[MAX_GROUP];
+    const double *ts[MAX_GROUP];
+    const int64_t *eidx[MAX_GROUP];
+    long long B[MAX_GROUP], off[MAX_GROUP];
+    int n;
+    long long Btot;
+};
+
+// ids of a group into a slot: role-major over the whole group (what the T-PPR launch reads), batch-major per
+// member (what the aggregation reads), the concatenated edge ids and times; ts3 = 1: the query time of every row
+__global__ void k_stage_group(GroupPtrs g, int32_t *__restrict__ nodes, int32_t *__restrict__ nodes_m,
+                              double *__restrict__ ts, long long *__restrict__ eidx, int ts3)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= g.Btot) return;
+    int m = 0;
+    while (m + 1 < g.n && t >= g.off[m + 1]) ++m;
+    const long long i = t - g.off[m], B = g.B[m];
+    const int32_t s = g.src[m][i], d = g.dst[m][i], n = g.neg[m][i];
+    nodes[t] = s; nodes[g.Btot + t] = d; nodes[2 * g.Btot + t] = n;
+    int32_t *nm = nodes_m + 3 * g.off[m];
+    nm[i] = s; nm[B + i] = d; nm[2 * B + i] = n;
+    const double tt = g.ts[m][i];
+    eidx[t] = g.eidx[m][i];
+    if (ts3) { double *q = ts + 3 * g.off[m]; q[i] = tt; q[B + i] = tt; q[2 * B + i] = tt; }
+    else ts[t] = tt;
+}
+
+bool same_batch(const zt_batch *a, const int64_t *key, int64_t B) { return a->eidx == key && a->B == B; }
+
+zt_pipeline::Slot *find_slot(zt_pipeline *p, const zt_batch *b, int *member)
 {
     for (auto &s : p->slot)
-        if (s.key != nullptr && s.key == b->eidx && s.B == b->B) return &s;
+        for (int j = 0; j < s.n; ++j)
+            if (same_batch(b, s.key[j], s.B[j])) { *member = j; return &s; }
     return nullptr;
 }
 
-// [src | dst | neg] of a batch into a slot (and, for the pruning strategy, the query time of every row)
-__global__ void k_stage_batch(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const int32_t *__restrict__ neg,
-                              const double *__restrict__ ts, long long B, int32_t *__restrict__ nodes, double *__restrict__ ts3)
+bool valid_batch(const zt_pipeline *p, const zt_batch *b)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    nodes[i] = src[i]; nodes[B + i] = dst[i]; nodes[2 * B + i] = neg[i];
-    if (ts3 != nullptr) { const double t = ts[i]; ts3[i] = t; ts3[B + i] = t; ts3[2 * B + i] = t; }
+    return b != nullptr && b->src && b->dst && b->neg && b->ts && b->eidx && b->B > 0 && b->B <= p->d.max_B;
 }
 
-// the slot that batch `b` will live in: ids are copied on stream `st` once the slot's previous user is done.
-// record = false: the caller records `filled` itself (after the prepass it enqueues behind the copy).
-int fill_slot(zt_pipeline *p, const zt_batch *b, hipStream_t st, zt_pipeline::Slot **out, bool record = true)
+// A new group from `first` and up to want - 1 of the batches that follow it (equal sizes, the last may be shorter;
+// one T-PPR launch must cover it), staged on stream `st` once the slot's previous user is done.
+// record = false: the caller records `filled` itself (behind the prepass it enqueues after the copy).
+int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int n_more, int want, hipStream_t st,
+               zt_pipeline::Slot **out, bool record)
 {
-    zt_pipeline::Slot &s = p->slot[p->next_slot];
-    p->next_slot = (p->next_slot + 1) % 3;
+    // a slot whose group is used up, else the next in turn (its `consumed` event orders the reuse)
+    int pick = -1;
+    for (int q = 0; q < 3; ++q) {
+        const int c = (p->next_slot + q) % 3;
+        if (p->slot[c].n == 0) { pick = c; break; }
+    }
+    if (pick < 0) pick = p->next_slot;
+    p->next_slot = (pick + 1) % 3;
+    zt_pipeline::Slot &s = p->slot[pick];
+    GroupPtrs g;
+    memset(&g, 0, sizeof(g));
+    auto add = [&](const zt_batch *b) {
+        g.src[g.n] = b->src; g.dst[g.n] = b->dst; g.neg[g.n] = b->neg; g.ts[g.n] = b->ts; g.eidx[g.n] = b->eidx;
+        g.B[g.n] = b->B; g.off[g.n] = g.Btot; g.Btot += b->B; ++g.n;
+    };
+    add(first);
+    const bool streaming = p->d.tppr != nullptr;
+    if (want > MAX_GROUP) want = MAX_GROUP;
+    for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
+        const zt_batch *b = more + q;
+        // members are equally long, except that the last one may be shorter; everything fits one launch and the slot
+        if (!valid_batch(p, b) || g.B[g.n - 1] != first->B || b->B > first->B || g.Btot + b->B > TPPR_MAX_LAUNCH ||
+            g.Btot + b->B > p->cap)
+            break;
+        add(b);
+    }
     if (s.used) ZT_HIP(hipStreamWaitEvent(st, s.consumed, 0));
-    k_stage_batch<<<(unsigned)((b->B + 255) / 256), 256, 0, st>>>(b->src, b->dst, b->neg, b->ts, b->B, s.nodes,
-                                                                  p->d.csr != nullptr ? s.ts3 : nullptr);
+    k_stage_group<<<(unsigned)((g.Btot + 255) / 256), 256, 0, st>>>(g, s.nodes, s.nodes_m, s.ts,
+                                                                     reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1);
     ZT_LAUNCH_CHECK();
     if (record) ZT_HIP(hipEventRecord(s.filled, st));
-    // the four output arrays [M][3B][k] of this batch, back to back in the slot's buffer
-    const size_t per = (size_t)p->d.M * 3 * b->B * p->d.k;
+    // the four output arrays of the group, back to back in the slot's buffer
+    const size_t per = (size_t)p->d.M * 3 * g.Btot * p->d.k;
     s.on = s.buf; s.oe = s.buf + per;
     s.od = reinterpret_cast<float *>(s.buf + 2 * per); s.ow = reinterpret_cast<float *>(s.buf + 3 * per);
-    s.key = b->eidx; s.B = b->B; s.token = 0; s.launched = false; s.used = true;
+    for (int j = 0; j < g.n; ++j) { s.key[j] = g.eidx[j]; s.B[j] = g.B[j]; }
+    s.n = g.n; s.n_done = 0; s.Btot = g.Btot; s.token = 0; s.launched = false; s.used = true;
     *out = &s;
     return ZT_OK;
 }
 
-// the T-PPR query of the slot's batch on the side stream; rows [row_lo, row_hi) only for the pruning strategy
-int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, const zt_batch *b, int64_t row_lo, int64_t row_hi)
+// the T-PPR query of the slot's group on the side stream; rows [row_lo, row_hi) only for the pruning strategy
+int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t row_hi)
 {
     const zt_pipeline_desc &d = p->d;
     ZT_HIP(hipStreamWaitEvent(p->side, s.filled, 0));
@@ -92,16 +161,16 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, const zt_batch *b, int64_t
         // `filled` was recorded behind the prepass (when there is one): no second wait; the event the update kernel
         // records for the plan set doubles as this slot's `ready`
         hipEvent_t done = nullptr;
-        int rc = zt::tppr_stream_ex(d.tppr, s.nodes, b->ts, b->eidx, b->B, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
-                                    true, &done);
+        int rc = zt::tppr_stream_ex(d.tppr, s.nodes, s.ts, s.eidx, s.Btot, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
+                                    true, &done, s.n > 1 ? (int32_t)s.B[0] : 0);
         if (rc != ZT_OK) return rc;
         if (done != nullptr) { s.ready_ev = done; s.launched = true; return ZT_OK; }
     } else {
         // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): start from zeros
         const int64_t n = row_hi - row_lo;
         const size_t per = (size_t)d.M * n * d.k;
-        if (n == 3 * b->B) {
-            ZT_HIP(hipMemsetAsync(s.on, 0, 4 * per * 4, p->side));          // the four arrays follow each other (fill_slot)
+        if (n == 3 * s.Btot) {
+            ZT_HIP(hipMemsetAsync(s.on, 0, 4 * per * 4, p->side));          // the four arrays follow each other (make_group)
         } else {
             ZT_HIP(hipMemsetAsync(s.on, 0, per * 4, p->side));
             ZT_HIP(hipMemsetAsync(s.oe, 0, per * 4, p->side));
@@ -110,7 +179,7 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, const zt_batch *b, int64_t
         }
         for (int m = 0; m < d.M; ++m) {
             const size_t o = (size_t)m * n * d.k;
-            int rc = zt_pruned_topk(d.csr, s.nodes + row_lo, s.ts3 + row_lo, n, d.width, d.depth, d.alpha[m], d.beta[m], d.k,
+            int rc = zt_pruned_topk(d.csr, s.nodes_m + row_lo, s.ts + row_lo, n, d.width, d.depth, d.alpha[m], d.beta[m], d.k,
                                     s.on + o, s.oe + o, s.od + o, s.ow + o, d.status, p->side);
             if (rc != ZT_OK) return rc;
         }
@@ -133,6 +202,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
     zt_pipeline *p = new zt_pipeline();
     memset(p, 0, sizeof(*p));
     p->d = *desc;
+    p->group = 1;
     if (tppr_cus > 0) {
         hipDeviceProp_t prop;
         int dev = 0;
@@ -148,18 +218,22 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
     }
     ZT_HIP(hipStreamCreateWithFlags(&p->plan_s, hipStreamNonBlocking));
-    p->own_streams = true;
-    const size_t rows = (size_t)3 * desc->max_B, per = (size_t)desc->M * rows * desc->k;
+    // a slot holds one batch of max_B edges, or a group of smaller ones up to what one T-PPR launch covers
+    p->cap = desc->max_B > TPPR_MAX_LAUNCH ? desc->max_B : TPPR_MAX_LAUNCH;
+    const size_t rows = (size_t)3 * p->cap, per = (size_t)desc->M * rows * desc->k;
     for (auto &s : p->slot) {
         ZT_HIP(hipMalloc(&s.nodes, rows * sizeof(int32_t)));
-        ZT_HIP(hipMalloc(&s.ts3, rows * sizeof(double)));
+        ZT_HIP(hipMalloc(&s.nodes_m, rows * sizeof(int32_t)));
+        ZT_HIP(hipMalloc(&s.ts, rows * sizeof(double)));
+        ZT_HIP(hipMalloc(&s.eidx, (size_t)p->cap * sizeof(int64_t)));
         ZT_HIP(hipMalloc(&s.buf, 4 * per * 4));
         ZT_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming | zt::sync_event_flags()));
     }
-    ZT_HIP(hipMalloc(&p->sh_on, per * 4)); ZT_HIP(hipMalloc(&p->sh_oe, per * 4));
-    ZT_HIP(hipMalloc(&p->sh_od, per * 4)); ZT_HIP(hipMalloc(&p->sh_ow, per * 4));
+    const size_t per1 = (size_t)desc->M * 3 * desc->max_B * desc->k;
+    ZT_HIP(hipMalloc(&p->sh_on, per1 * 4)); ZT_HIP(hipMalloc(&p->sh_oe, per1 * 4));
+    ZT_HIP(hipMalloc(&p->sh_od, per1 * 4)); ZT_HIP(hipMalloc(&p->sh_ow, per1 * 4));
     *out = p;
     return ZT_OK;
 }
@@ -169,7 +243,7 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     if (!p) return ZT_OK;
     (void)hipDeviceSynchronize();
     for (auto &s : p->slot) {
-        (void)hipFree(s.nodes); (void)hipFree(s.ts3); (void)hipFree(s.buf);
+        (void)hipFree(s.nodes); (void)hipFree(s.nodes_m); (void)hipFree(s.ts); (void)hipFree(s.eidx); (void)hipFree(s.buf);
         (void)hipEventDestroy(s.ready); (void)hipEventDestroy(s.consumed); (void)hipEventDestroy(s.filled);
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
@@ -180,6 +254,13 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
 
 extern "C" void *zt_pipeline_main_stream(zt_pipeline *p) { return p ? (void *)p->main_s : nullptr; }
 
+extern "C" int zt_pipeline_set_group(zt_pipeline *p, int32_t group)
+{
+    if (!p || group < 1 || group > MAX_GROUP) { set_error("zt_pipeline_set_group: 1 <= group <= %d", MAX_GROUP); return ZT_ERR_ARG; }
+    p->group = group;
+    return ZT_OK;
+}
+
 extern "C" int zt_pipeline_update(zt_pipeline *p, const zt_pipeline_desc *desc, int32_t weights_changed)
 {
     if (!p) return ZT_ERR_ARG;
@@ -189,16 +270,16 @@ extern "C" int zt_pipeline_update(zt_pipeline *p, const zt_pipeline_desc *desc, 
             return ZT_ERR_ARG;
         }
         p->d = *desc;
-        for (auto &s : p->slot) if (!s.launched) { s.key = nullptr; }      // plans against the old state are void
+        for (auto &s : p->slot) if (!s.launched) { s.n = 0; }      // plans against the old state are void
     }
     if (weights_changed) { p->embed_ready = false; p->gru_ready = false; }
     return ZT_OK;
 }
 
-extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, const zt_batch *plan,
-                                int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev)
+extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *ahead, int32_t n_ahead,
+                                      int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev)
 {
-    if (!p || !cur || !cur->src || !cur->dst || !cur->neg || !cur->ts || !cur->eidx || cur->B <= 0 || cur->B > p->d.max_B ||
+    if (!p || !valid_batch(p, cur) || n_ahead < 0 || (n_ahead > 0 && !ahead) ||
         !out_emb_dev || row_lo < 0 || row_hi > 3 * cur->B || row_lo > row_hi || pos_lo < 0 || pos_hi > 2 * cur->B || pos_lo > pos_hi) {
         set_error("zt_pipeline_step: bad argument");
         return ZT_ERR_ARG;
@@ -207,48 +288,63 @@ extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_ba
     const int64_t B = cur->B, n_rows = row_hi - row_lo;
     const bool pruning = d.csr != nullptr;
     const bool whole = row_lo == 0 && row_hi == 3 * B;
-    int rc;
-    // ---- this batch's T-PPR query: made ahead by the previous step, or now ----
-    zt_pipeline::Slot *s = find_slot(p, cur);
-    if (s == nullptr) { rc = fill_slot(p, cur, p->side, &s); if (rc != ZT_OK) return rc; }
-    if (!s->launched) { rc = launch_tppr(p, *s, cur, row_lo, row_hi); if (rc != ZT_OK) return rc; }
+    const int want = pruning ? 1 : p->group;
+    // the shard of a LATER batch is the same fraction of its rows (callers shard every batch alike)
+    auto shard_of = [&](int64_t Bn, int64_t *lo, int64_t *hi) {
+        *lo = Bn == B ? row_lo : (row_lo * 3 * Bn) / (3 * B);
+        *hi = Bn == B ? row_hi : (row_hi * 3 * Bn) / (3 * B);
+    };
+    int rc, j = 0;
+    // ---- this batch's T-PPR query: made ahead by an earlier step, or now (with as many followers as allowed) ----
+    zt_pipeline::Slot *s = find_slot(p, cur, &j);
+    if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, want, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
+    if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
     ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0));
-    // ---- the next batch's query beside this batch's aggregation; the prepass of the one after it ----
-    if (next != nullptr && next->B > 0 && next->B <= d.max_B) {
-        zt_pipeline::Slot *n = find_slot(p, next);
-        if (n == nullptr) { rc = fill_slot(p, next, p->side, &n); if (rc != ZT_OK) return rc; }
-        if (!n->launched) {
-            // the shard of the NEXT step is the same fraction of its rows (callers shard every batch alike)
-            const int64_t nlo = next->B == B ? row_lo : (row_lo * 3 * next->B) / (3 * B);
-            const int64_t nhi = next->B == B ? row_hi : (row_hi * 3 * next->B) / (3 * B);
-            rc = launch_tppr(p, *n, next, nlo, nhi);
+    // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
+    int a = s->n - 1 - j;                     // ahead[0 .. a) are the rest of this group
+    if (a < n_ahead && valid_batch(p, ahead + a)) {
+        int jn = 0;
+        zt_pipeline::Slot *n = find_slot(p, ahead + a, &jn);
+        if (n == nullptr) {
+            rc = make_group(p, ahead + a, ahead + a + 1, n_ahead - a - 1, want, p->side, &n, true);
             if (rc != ZT_OK) return rc;
         }
-    }
-    if (plan != nullptr && plan->B > 0 && plan->B <= d.max_B && find_slot(p, plan) == nullptr) {
-        zt_pipeline::Slot *q;
-        rc = fill_slot(p, plan, p->plan_s, &q, pruning);          // streaming: `filled` is recorded behind the prepass
-        if (rc != ZT_OK) return rc;
-        if (!pruning) {
-            rc = zt_tppr_plan(d.tppr, q->nodes, plan->eidx, plan->B, 3, -1, &q->token, p->plan_s);
-            if (rc != ZT_OK) { (void)hipEventRecord(q->filled, p->plan_s); return rc; }
-            ZT_HIP(hipEventRecord(q->filled, p->plan_s));
+        if (!n->launched) {
+            int64_t nlo, nhi;
+            shard_of(n->B[0], &nlo, &nhi);
+            rc = launch_tppr(p, *n, nlo, nhi);
+            if (rc != ZT_OK) return rc;
+        }
+        a += n->n - jn;                       // ahead[a] now follows that group
+        if (a < n_ahead && valid_batch(p, ahead + a) && find_slot(p, ahead + a, &jn) == nullptr) {
+            zt_pipeline::Slot *q;
+            rc = make_group(p, ahead + a, ahead + a + 1, n_ahead - a - 1, want, p->plan_s, &q, pruning);   // streaming: `filled`
+            if (rc != ZT_OK) return rc;                                                              // follows the prepass
+            if (!pruning) {
+                rc = zt_tppr_plan(d.tppr, q->nodes, q->eidx, q->Btot, 3, -1, &q->token, p->plan_s);
+                if (rc != ZT_OK) { (void)hipEventRecord(q->filled, p->plan_s); return rc; }
+                ZT_HIP(hipEventRecord(q->filled, p->plan_s));
+            }
         }
     }
-    // ---- P2: gather + aggregate for rows [row_lo, row_hi) ----
-    const int32_t *on = s->on, *oe = s->oe;
-    const float *od = s->od, *ow = s->ow;
+    // ---- P2: gather + aggregate for rows [row_lo, row_hi) of member j ----
+    size_t mo = 0;                            // first element of member j's block in each output array
+    int64_t off = 0;
+    for (int q = 0; q < j; ++q) { mo += (size_t)d.M * 3 * s->B[q] * d.k; off += s->B[q]; }
+    const int32_t *nodes_cur = s->nodes_m + 3 * off;
+    const int32_t *on = s->on + mo, *oe = s->oe + mo;
+    const float *od = s->od + mo, *ow = s->ow + mo;
     if (!pruning && !whole) {
         // streaming T-PPR emits all 3B rows of every model: bring this shard's rows together
-        const size_t w = (size_t)n_rows * d.k * 4, pitch = (size_t)3 * B * d.k * 4, off = (size_t)row_lo * d.k;
-        ZT_HIP(hipMemcpy2DAsync(p->sh_on, w, s->on + off, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
-        ZT_HIP(hipMemcpy2DAsync(p->sh_oe, w, s->oe + off, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
-        ZT_HIP(hipMemcpy2DAsync(p->sh_od, w, s->od + off, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
-        ZT_HIP(hipMemcpy2DAsync(p->sh_ow, w, s->ow + off, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
+        const size_t w = (size_t)n_rows * d.k * 4, pitch = (size_t)3 * B * d.k * 4, o2 = (size_t)row_lo * d.k;
+        ZT_HIP(hipMemcpy2DAsync(p->sh_on, w, on + o2, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
+        ZT_HIP(hipMemcpy2DAsync(p->sh_oe, w, oe + o2, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
+        ZT_HIP(hipMemcpy2DAsync(p->sh_od, w, od + o2, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
+        ZT_HIP(hipMemcpy2DAsync(p->sh_ow, w, ow + o2, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
         on = p->sh_on; oe = p->sh_oe; od = p->sh_od; ow = p->sh_ow;
     }
     if (n_rows > 0) {
-        rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, s->nodes + row_lo, n_rows, d.M, d.k, on, oe,
+        rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                       od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
@@ -259,7 +355,7 @@ extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_ba
                                  d.scratch, nullptr, nullptr, d.status, p->main_s);
     if (rc != ZT_OK) return rc;
     const int msg_dim = 2 * d.D + d.F + d.T;
-    rc = zt_gru_update(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, s->nodes, 2 * B,
+    rc = zt_gru_update(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
                        nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, p->main_s);
     if (rc != ZT_OK) return rc;
     p->gru_ready = true;
@@ -270,7 +366,20 @@ extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_ba
                                p->main_s);
         if (rc != ZT_OK) return rc;
     }
-    ZT_HIP(hipEventRecord(s->consumed, p->main_s));
-    s->key = nullptr;
+    // the member is used up; with the last one the slot is free again
+    s->key[j] = nullptr;
+    if (++s->n_done >= s->n) {
+        ZT_HIP(hipEventRecord(s->consumed, p->main_s));
+        s->n = 0;
+    }
     return ZT_OK;
+}
+
+extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, const zt_batch *plan,
+                                int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev)
+{
+    zt_batch ahead[2];
+    int n = 0;
+    if (next != nullptr) { ahead[n++] = *next; if (plan != nullptr) ahead[n++] = *plan; }
+    return zt_pipeline_step_ahead(p, cur, ahead, n, row_lo, row_hi, pos_lo, pos_hi, out_emb_dev);
 }

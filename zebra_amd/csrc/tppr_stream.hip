@@ -153,6 +153,7 @@ constexpr int HDR = 4;                 // header granules: len, norm lo, norm hi
 constexpr int ORD_BITS = 14;           // writer ordinal inside one launch
 constexpr int MAX_CHUNK = 8192;        // edges per launch (ordinals must fit ORD_BITS)
 constexpr unsigned EPOCH_MAX = (1u << (32 - ORD_BITS)) - 1;
+static_assert(MAX_CHUNK == zt::TPPR_MAX_LAUNCH, "common.hpp: TPPR_MAX_LAUNCH");
 // hub chains: the nodes touched most often in a launch get a workgroup of their own
 constexpr int HOT_MIN = 24;            // accesses in one launch that make a node a chain candidate
 constexpr int MAX_HOT = 128;           // candidates kept
@@ -1144,6 +1145,8 @@ struct StreamArgs {
     int *out_nodes, *out_eidx;
     float *out_dt, *out_w;
     unsigned epoch;
+    int sub_B;         // > 0: the launch covers several consecutive batches of sub_B edges (the last may be shorter); the
+                       // output rows of batch g form their own [n_models][n_roles][B_g][k] block, blocks back to back
 };
 
 __device__ __forceinline__ int lds_load_seq(const int *p)
@@ -1554,15 +1557,19 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
 
     // ---- emission is off the critical path (utils/util.py:504-506) ----
     if (A.emit) {
-        const long long ob = (long long)mo * A.out_rows * k;
-        emit_row(ru, k, lane, tnow, A.out_nodes + ob + (long long)i * k, A.out_eidx + ob + (long long)i * k,
-                 A.out_dt + ob + (long long)i * k, A.out_w + ob + (long long)i * k);
-        const long long rv_o = ob + (role_stride + i) * k;
-        emit_row(rv, k, lane, tnow, A.out_nodes + rv_o, A.out_eidx + rv_o, A.out_dt + rv_o, A.out_w + rv_o);
-        if (n_roles == 3) {
-            const long long rg_o = ob + (2 * role_stride + i) * k;
-            emit_row(rg, k, lane, tnow, A.out_nodes + rg_o, A.out_eidx + rg_o, A.out_dt + rg_o, A.out_w + rg_o);
+        long long ou, ov, og;                      // first element of the three output rows of this edge
+        if (A.sub_B > 0) {
+            const int g = i / A.sub_B, ii = i - g * A.sub_B;
+            const int Bg = (B - g * A.sub_B) < A.sub_B ? (B - g * A.sub_B) : A.sub_B;
+            const long long base = ((long long)g * A.n_models * n_roles * A.sub_B + (long long)mo * n_roles * Bg) * k;
+            ou = base + (long long)ii * k; ov = base + (long long)(Bg + ii) * k; og = base + (long long)(2 * Bg + ii) * k;
+        } else {
+            const long long ob = (long long)mo * A.out_rows * k;
+            ou = ob + (long long)i * k; ov = ob + (role_stride + i) * k; og = ob + (2 * role_stride + i) * k;
         }
+        emit_row(ru, k, lane, tnow, A.out_nodes + ou, A.out_eidx + ou, A.out_dt + ou, A.out_w + ou);
+        emit_row(rv, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
+        if (n_roles == 3) emit_row(rg, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
     }
     STAMP(3);
     WL(4, wall_clock64() >> 7); WL(0, 9);
@@ -1861,7 +1868,7 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
 static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, const long long *eidx,
                      long long role_stride, int B, int n_roles, int emit, int model, long long out_rows, int32_t *on,
                      int32_t *oe, float *od, float *ow, hipStream_t s, bool plan_ordered = false,
-                     hipEvent_t *done_out = nullptr)
+                     hipEvent_t *done_out = nullptr, int sub_B = 0)
 {
     zt_tppr::PlanSet &P = h->set[q];
     if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
@@ -1888,6 +1895,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.nodes = nodes; sa.tsv = ts; sa.eidx = eidx; sa.role_stride = role_stride; sa.B = B; sa.n_roles = n_roles;
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
+    sa.sub_B = sub_B;
 #ifdef ZT_WAITLOG
     {
         void *wl = nullptr;
@@ -1947,9 +1955,13 @@ extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t 
 int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B,
                        int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                        float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
-                       hipEvent_t *done_out)
+                       hipEvent_t *done_out, int32_t sub_B)
 {
     if (done_out) *done_out = nullptr;
+    if (sub_B < 0 || (sub_B > 0 && (B > MAX_CHUNK || sub_B > B))) {
+        set_error("zt_tppr_stream: a launch over several batches must fit one chunk (%d edges)", MAX_CHUNK);
+        return ZT_ERR_ARG;
+    }
     if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M) {
         set_error("zt_tppr_stream: bad argument");
         return ZT_ERR_ARG;
@@ -1974,7 +1986,7 @@ int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_de
                     return ZT_ERR_ARG;
                 }
                 return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
-                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s, plan_ordered, done_out);
+                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s, plan_ordered, done_out, sub_B);
             }
         }
         // the plan is gone (reset / copy / import, or two newer plans): fall through to an inline prepass
@@ -1991,7 +2003,7 @@ int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_de
         if (rc != ZT_OK) return rc;
         rc = run_chunk(h, q, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
                        (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr, emit ? out_eidx_dev + oo : nullptr,
-                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s, true, done_out);   // planned on s itself
+                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s, true, done_out, sub_B);   // planned on s itself
         if (rc != ZT_OK) return rc;
     }
     return ZT_OK;
@@ -2003,7 +2015,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
                               void *stream)
 {
     return zt::tppr_stream_ex(h, nodes_dev, ts_dev, eidx_dev, B, n_roles, emit, model, out_nodes_dev, out_eidx_dev,
-                              out_dt_dev, out_w_dev, plan_token, stream, false, nullptr);
+                              out_dt_dev, out_w_dev, plan_token, stream, false, nullptr, 0);
 }
 
 #ifdef ZT_STAMP

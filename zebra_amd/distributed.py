@@ -186,7 +186,7 @@ class ShardedTGN:
         return loss.detach()
 
     @torch.no_grad()
-    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None):
+    def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None, ahead=None):
         tgn = self.tgn
         B = src_d.numel()
         r0, r1 = shard_range(3 * B, self.rank, self.world)
@@ -197,7 +197,7 @@ class ShardedTGN:
             # P1 streaming: whole batch on every rank (replicas stay bit-identical); P1 pruning, P2: rows [r0, r1);
             # P3: winners at positions [p0, p1) -- only this rank's winners are flagged, the GRU compacts them
             emb = tgn.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=check_status, prefetch=prefetch,
-                                  plan=plan, rows=(r0, r1), positions=(p0, p1))
+                                  plan=plan, rows=(r0, r1), positions=(p0, p1), ahead=ahead)
             rows, count = tgn.memory_updater.last_rows()
             m = tgn.memory
             got = exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,

@@ -101,11 +101,13 @@ class TGN(torch.nn.Module):
         return B
 
     # -- the step as ONE native call (csrc/pipeline.hip): P1 of batch b+1 on a side stream beside P2 + P3 of batch b
-    def enable_pipeline(self, on=True, tppr_cus=0, max_batch=8192):
+    def enable_pipeline(self, on=True, tppr_cus=0, max_batch=8192, group=1):
         """Create (or drop) the native step pipeline.  ``tppr_cus`` > 0 pins the T-PPR stream to the first
         tppr_cus compute units (CU mask) and everything else to the rest; callers run their own work on
         ``self.main_stream``.  With it, ``step_device`` takes ``prefetch`` (the NEXT batch: its T-PPR query is
-        issued at once -- it must be the batch of the next call) and ``plan`` (the one after it)."""
+        issued at once -- it must be the batch of the next call) and ``plan`` (the one after it), or ``ahead`` = the
+        list of batches that follow, in order.  ``group`` > 1 (streaming strategy): the T-PPR update of that many
+        consecutive batches runs as one launch (zt_pipeline_set_group); 3 * group - 1 batches of ``ahead`` keep it full."""
         if getattr(self, "_pipe", None) is not None:
             torch.cuda.synchronize(self.device)
             check(lib().zt_pipeline_destroy(self._pipe))
@@ -117,6 +119,7 @@ class TGN(torch.nn.Module):
         if not on:
             return
         self._pipe_args = (int(tppr_cus), int(max_batch))
+        self._pipe_group = int(group)
         self._pipe_refresh(create=True)
 
     def _pipe_signature(self):
@@ -171,6 +174,8 @@ class TGN(torch.nn.Module):
             h = C.c_void_p()
             check(lib().zt_pipeline_create(C.byref(h), C.byref(d), C.c_int32(tppr_cus)), "zt_pipeline_create")
             self._pipe = h
+            if getattr(self, "_pipe_group", 1) > 1:
+                check(lib().zt_pipeline_set_group(h, C.c_int32(self._pipe_group)), "zt_pipeline_set_group")
             self.main_stream = torch.cuda.ExternalStream(lib().zt_pipeline_main_stream(h), device=self.device)
         else:
             check(lib().zt_pipeline_update(self._pipe, C.byref(d), C.c_int32(1)), "zt_pipeline_update")
@@ -194,19 +199,35 @@ class TGN(torch.nn.Module):
         cache[key] = (batch[4], b)
         return b
 
-    def _pipe_step(self, batch, prefetch, plan, rows=None, positions=None):
-        """zt_pipeline_step; returns the embeddings of ``rows`` (valid on the caller's current stream)."""
+    def _pipe_step(self, batch, prefetch, plan, rows=None, positions=None, ahead=None):
+        """zt_pipeline_step_ahead; returns the embeddings of ``rows`` (valid on the caller's current stream)."""
+        if ahead is None:
+            ahead = [b for b in (prefetch, plan if prefetch is not None else None) if b is not None]
         caller = torch.cuda.current_stream(self.device)
         if caller.cuda_stream == self.main_stream.cuda_stream:
-            return self._pipe_step_main(batch, prefetch, plan, rows, positions)
+            return self._pipe_step_main(batch, ahead, rows, positions)
         self.main_stream.wait_stream(caller)            # inputs produced on the caller's stream
         with torch.cuda.stream(self.main_stream):
-            out = self._pipe_step_main(batch, prefetch, plan, rows, positions)
+            out = self._pipe_step_main(batch, ahead, rows, positions)
         caller.wait_stream(self.main_stream)
         out.record_stream(caller)
         return out
 
-    def _pipe_step_main(self, batch, prefetch, plan, rows, positions):
+    def _ahead_array(self, ahead):
+        """ctypes array of zt_batch for the batches that follow; remembered by the identity of its members."""
+        key = tuple(id(b[4]) for b in ahead)
+        hit = self._batch_cache.get(key)
+        if hit is not None and all(x is b[4] for x, b in zip(hit[0], ahead)):
+            return hit[1]
+        arr = (_capi.Batch * max(1, len(ahead)))()
+        for q, b in enumerate(ahead):
+            arr[q] = self._batch_struct(b)
+        if len(self._batch_cache) > 64:
+            self._batch_cache.clear()
+        self._batch_cache[key] = ([b[4] for b in ahead], arr)
+        return arr
+
+    def _pipe_step_main(self, batch, ahead, rows, positions):
         self._pipe_refresh()
         B = batch[0].numel()
         r0, r1 = rows if rows is not None else (0, 3 * B)
@@ -214,29 +235,28 @@ class TGN(torch.nn.Module):
         em = self.embedding_module
         out = torch.empty((r1 - r0, self.embedding_dimension * (em.n_tppr + 1)), dtype=torch.float32, device=self.device)
         cur = self._batch_struct(batch)
-        nxt = self._batch_struct(prefetch) if prefetch is not None else None
-        pln = self._batch_struct(plan) if plan is not None else None
-        check(lib().zt_pipeline_step(self._pipe, C.byref(cur), C.byref(nxt) if nxt is not None else None,
-                                     C.byref(pln) if pln is not None else None, C.c_int64(r0), C.c_int64(r1),
-                                     C.c_int64(p0), C.c_int64(p1), ptr(out)), "zt_pipeline_step")
+        arr = self._ahead_array(ahead)
+        check(lib().zt_pipeline_step_ahead(self._pipe, C.byref(cur), arr, C.c_int32(len(ahead)), C.c_int64(r0),
+                                           C.c_int64(r1), C.c_int64(p0), C.c_int64(p1), ptr(out)), "zt_pipeline_step")
         return out
 
     @torch.no_grad()
     def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None,
-                    stats=False, rows=None, positions=None):
+                    stats=False, rows=None, positions=None, ahead=None):
         """One eval-mode batch (tgn_model.py:124-174 with train=False), inputs
         int32/int32/int32/float64/int64 CUDA tensors, no host sync unless
         ``check_status``.  Returns the [3B, D*(n_tppr+1)] embeddings (or those of ``rows`` = (lo, hi);
         ``positions`` = (lo, hi) restricts the memory update to winners at those batch positions: the two
         are how a multi-GPU run shards a batch).  With ``enable_pipeline``: ``prefetch`` = the next batch's
-        five tensors (queried at once), ``plan`` = the one after it; call from ``self.main_stream``."""
+        five tensors (queried at once), ``plan`` = the one after it -- or ``ahead`` = the list of the batches that
+        follow (see ``enable_pipeline(group=)``); call from ``self.main_stream``."""
         if not self.test_mode:
             self.update_memory_in_test(self.memory)
             self.test_mode = True
         em = self.embedding_module
         B = src_d.numel()
         if getattr(self, "_pipe", None) is not None and not stats:
-            emb = self._pipe_step((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, plan, rows, positions)
+            emb = self._pipe_step((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, plan, rows, positions, ahead)
         else:
             nodes_d = torch.cat([src_d, dst_d, neg_d])
             ts3 = ts_d if em.tppr_strategy == "streaming" else torch.cat([ts_d, ts_d, ts_d])
