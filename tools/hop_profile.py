@@ -79,3 +79,11 @@ for s_i in slow[:12]:
         msg += "  last writer edge %d: deq %.1f rows %.1f x1 %.1f end %.1f" % (j, t[j, 0], t[j, 1], t[j, 2], t[j, 3])
     msg += "  | me: deq %.1f rows %.1f x1 %.1f ; prev hub x1 %.1f" % (t[e, 0], t[e, 1], t[e, 2], t[idx[s_i - 1], 2])
     print(msg)
+
+# ---- the chain's first hops, phase by phase (stamps: 6 seen, 0 merge start, 1 matched, 2 laid out, 4 ranked, 7 published) ----
+print("first hops: [publish(t-1)->seen, seen->merge, scales+match, layout, rank pass, ->publish] us")
+for q in range(1, 14):
+    e, ep = idx[q], idx[q - 1]
+    a = s2[e] * 0.01
+    print("  hop %2d edge %4d: %5.2f %5.2f %5.2f %5.2f %5.2f %5.2f   total %.2f" % (
+        q, e, a[6] - s2[ep, 7] * 0.01, a[0] - a[6], a[1] - a[0], a[2] - a[1], a[4] - a[3], a[7] - a[4], (s2[e, 7] - s2[ep, 7]) * 0.01))

@@ -1168,7 +1168,7 @@ __device__ inline bool wait_seq(const int *p, int want, int *status, int what, i
             if (launch_failed(status)) return false;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("" ::: "memory");      // LDS only, in program order behind the load that has just returned (see publish_seq)
     return true;
 }
 
@@ -1371,7 +1371,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         // (chain position tpos - MAIL_R + 1) has let go of it
         auto ring_free = [&]() {
             if (tpos >= MAIL_R) {
-                if (free_seen == tpos - MAIL_R + 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (free_seen == tpos - MAIL_R + 1) asm volatile("" ::: "memory");
                 else if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
             }
         };
@@ -1380,7 +1380,10 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt; }
         };
         auto publish_seq = [&](bool set, bool ord) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // The mailbox lives in LDS and a wave's LDS instructions execute in program order: the sequence word, issued
+            // after the data, becomes visible after it -- no wait.  (A workgroup-scope release fence would also drain this
+            // wave's global stores, vmcnt(0), and wait for the LDS writes to finish: ~100 cycles on the chain.)
+            asm volatile("" ::: "memory");
             if (lane == 0 && set) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0 && ord) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
