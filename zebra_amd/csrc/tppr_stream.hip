@@ -1300,6 +1300,18 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         // priority the two alternate issue slots.
         // (Only once the row is there: a wave that SPINS at high priority starves the off-chain work of its SIMD
         // mate, and later hops wait for that work's results.)
+        // (Poll and read as ONE batch of LDS instructions -- sequence word first, in-order execution makes that safe --
+        // was measured: the seven waiting waves then issue ten LDS reads per poll, and the hop gets 6 % slower.)
+        // Waves whose turn is two or more hops away doze (the hop before their predecessor's has not been published):
+        // seven waves polling every ~200 cycles take LDS and issue slots from the one that works.
+        if (tpos >= 2) {
+            const int *far = &mail->slot[(tpos - 2) % MAIL_R].seq_set;
+            unsigned spins = 0;
+            while (lds_load_seq(far) != tpos - 1 && lds_load_seq(&in_slot->seq_set) != tpos) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 1023u) == 0 && launch_failed(h.ctl + 2)) break;
+            }
+        }
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
         __builtin_amdgcn_s_setprio(3);
 #ifdef ZT_STAMP
