@@ -297,7 +297,9 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     int rc, j = 0;
     // ---- this batch's T-PPR query: made ahead by an earlier step, or now (with as many followers as allowed) ----
     zt_pipeline::Slot *s = find_slot(p, cur, &j);
-    if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, want, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
+    // (a batch nobody has queried ahead is queried ALONE: the aggregation waits for this launch, and a group would
+    //  make it wait for the followers' updates as well; they form the next group, which runs beside this batch)
+    if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, 1, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
     if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
     ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0));
     // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
