@@ -402,7 +402,10 @@ def main():
                         note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
                              "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
         if name == "tppr_stream":
-            byts = ab["p1"] * M * bs                       # one k_stream launch covers all M models
+            # one k_stream launch covers all M models and `group` batches (fewer at the ends of the region)
+            every = a.profile_every if a.profile_every > 0 else (1 if bs >= 2048 else 4)
+            per_launch = (a.steps * bs / kern[name]["launches"]) if every == 1 else a.group * bs
+            byts = ab["p1"] * M * per_launch
             note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
                     "per-node chains; the binding resource is hops x hop latency, not HBM")
         elif name == "pruned_topk":
@@ -415,8 +418,11 @@ def main():
             byts = ab["p3"] * bs / shard
             note = None
         ach = byts / us / 1e9
-        return dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=tr, note=note)
+        out_r = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                     traffic=tr, note=note)
+        if name == "tppr_stream":
+            out_r["edges_per_launch"] = per_launch
+        return out_r
 
     # dominant kernel = the one with the largest total time in the timed region
     roof = roof2 = None
