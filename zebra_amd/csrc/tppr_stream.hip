@@ -1571,6 +1571,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
 
     // ---- emission is off the critical path (utils/util.py:504-506) ----
+    // (Leaving the emission of hub edges out -- as if other compute units did it -- does not make the chain faster.)
     if (A.emit) {
         long long ou, ov, og;                      // first element of the three output rows of this edge
         if (A.sub_B > 0) {
