@@ -1,0 +1,41 @@
+# Length of the critical section of a hub hop in core clocks (register-held readings, -DZT_CRIT build).
+import sys, ctypes as C
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from zebra_amd import _capi
+_capi.LIB_PATH = '/root/repo/tools/out/libzebra_crit.so'
+from zebra_amd import tppr, synth
+lib = _capi.lib()
+wl = synth.WORKLOADS["c5"]; B = 4096; NB = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], NB * B, seed=2020)
+neg = synth.negatives(dst, len(src), seed=2021)
+f = tppr.tppr_finder(wl["n_nodes"] + 1, 20, 2, [0.1, 0.1], [0.5, 0.95])
+d = torch.device('cuda')
+sd, dd, nd = [torch.from_numpy(x).to(d) for x in (src, dst, neg)]
+td, ed = torch.from_numpy(ts).to(d), torch.from_numpy(eidx).to(d)
+lib.zt_profile_reset(); lib.zt_profile_enable(1)
+for b in range(NB):
+    s, e = b * B, (b + 1) * B
+    f.stream_device(torch.cat([sd[s:e], dd[s:e], nd[s:e]]), td[s:e], ed[s:e], 3, True, -1, check_status=False)
+f.check_status()
+n, ms = C.c_int64(), C.c_double(); lib.zt_profile_read(b"tppr_stream", C.byref(n), C.byref(ms))
+print("avg k_stream us: %.1f" % (1e3 * ms.value / n.value))
+c = np.zeros((B, 8), np.int64)
+lib.zt_debug_crit(c.ctypes.data_as(C.c_void_p), C.c_int(B))
+s0 = (NB - 1) * B
+u, v = src[s0:s0 + B], dst[s0:s0 + B]
+hub = np.bincount(np.concatenate([u, v])).argmax()
+idx = np.where((u == hub) | (v == hub))[0]
+cc = c[idx]
+ok = (cc[:, 0] > 0) & (cc[:, 3] > 0)
+cc = cc[ok]
+p = lambda a: np.percentile(a, [10, 50, 90]).round(0)
+print("hub edges %d, split hops with readings %d" % (len(idx), len(cc)))
+print("core clocks 10/50/90 %%: row arrived -> front half done %s ; -> ready to publish %s ; publication %s ; whole section %s" % (
+    p(cc[:, 1] - cc[:, 0]), p(cc[:, 2] - cc[:, 1]), p(cc[:, 3] - cc[:, 2]), p(cc[:, 3] - cc[:, 0])))
+print("inside the front half: arrival -> merge_front entered %s ; scales + matching + new key %s ; layout %s ; rank pass %s ; return %s" % (
+    p(cc[:, 4] - cc[:, 0]), p(cc[:, 5] - cc[:, 4]), p(cc[:, 6] - cc[:, 5]), p(cc[:, 7] - cc[:, 6]), p(cc[:, 1] - cc[:, 7])))
+arr = c[idx][:, 0]; pub = c[idx][:, 3]
+g = (arr[1:] > 0) & (pub[:-1] > 0)
+print("publication(t-1) -> row arrived(t) [clocks of two different waves, same CU]: %s" % p((arr[1:] - pub[:-1])[g]))
+print("publication(t) - publication(t-1): %s   mean %.0f" % (p(np.diff(pub)[(pub[1:] > 0) & (pub[:-1] > 0)]), np.diff(pub)[(pub[1:] > 0) & (pub[:-1] > 0)].mean()))

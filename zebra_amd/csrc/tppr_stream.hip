@@ -225,6 +225,21 @@ constexpr int CAP = 128;          // candidates per merge: 2k+1 <= 127
 constexpr int WAVES_PER_WG = 8;
 constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
+// -DZT_CRIT (diagnostic build, tools/crit_profile.py): core-clock readings at four points of a hub hop, kept in
+// registers and written out at the end of the hop -- the chain itself is not disturbed by stores
+#ifdef ZT_CRIT
+__device__ long long g_crit[8192 * 8];     // per hub edge (model 0): see tools/crit_profile.py
+#define CRIT(j) do { crit_t[j] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CRITP(j) do { if (crit_p) crit_p[j] = (long long)__builtin_readcyclecounter(); } while (0)
+#define CRIT_ARG , long long *crit_p = nullptr
+#define CRIT_PASS , crit_t
+#else
+#define CRIT(j) do { } while (0)
+#define CRITP(j) do { } while (0)
+#define CRIT_ARG
+#define CRIT_PASS
+#endif
+
 #ifdef ZT_STAMP
 __device__ int g_paths[8];
 __device__ long long g_stamps[8192 * 4];
@@ -780,9 +795,10 @@ struct PreScale {
 
 __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, double beta, const Row &r1,
                                    const Row &r2, u64 newkey, double newts, Front &F, int pre = 0,
-                                   int g_stamp_i = -1, const PreScale *ps = nullptr)
+                                   int g_stamp_i = -1, const PreScale *ps = nullptr CRIT_ARG)
 {
     STAMP2(0);
+    CRITP(4);
     int n1;
     double scale_s1 = 0.0, scale_s2;
     if (r1.norm == 0.0) {                       // :514-519
@@ -887,6 +903,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     touched |= __ballot(h1);
     const double w2 = h2 ? v : add;
     STAMP2(1);
+    CRITP(5);
     // candidates: lanes [0, n1) s1's entries, lanes 32 + j s2's unmatched entries, lane 32 + len2 the new key.
     // v_permlane32_swap(a, b) exchanges a[32..63] with b[0..31]: the first result is [a's low half | b's low half].
     u64 ck;
@@ -920,7 +937,9 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     const bool mine = (live >> lane) & 1ull;
     if (n <= k) { F.mode = FR_NOPRUNE; return; }          // :549-551
     if (__ballot(mine && cw != cw) != 0ull) { F.mode = FR_NAN; return; }
+    CRITP(6);
     F.mode = rank_pass(cw, live, n, k, &F.lt, &F.keep, &F.claimed);    // :553-559 (first half)
+    CRITP(7);
 #ifdef ZT_STAMP
     if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : (F.mode == FR_TIES ? 4 : 5)], 1);
 #endif
@@ -1189,6 +1208,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     unsigned *done = h.done + (long long)m * MAX_CHUNK;
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS;
     const long long role_stride = A.role_stride;
+#ifdef ZT_CRIT
+    long long crit_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     STAMP(0);
     WL(0, 1); WL(1, blockIdx.x * WAVES_PER_WG + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
     int wl_fail = 0;
@@ -1314,6 +1336,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         }
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
         __builtin_amdgcn_s_setprio(3);
+        CRIT(0);
 #ifdef ZT_STAMP
         { const int g_stamp_i = mo == 0 ? i : -1; STAMP2(6); }
 #endif
@@ -1439,7 +1462,8 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
                 if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
             }
-            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale);
+            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale CRIT_PASS);
+            CRIT(1);
             if (!settled) {
                 // a key match (or the new key) on an entry whose slot is provisional: the weights by position would
                 // depend on identities.  Likewise a picked member of a straddling run that would be kept: whether it
@@ -1529,7 +1553,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                     if (provslot >= 0) out_slot->pos[provslot] = provslot;
                     trueslot = provslot;
                 }
+                CRIT(2);
                 publish_seq(true, final_out);                            // the successor can start
+                CRIT(3);
                 __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
             }
 #ifdef ZT_STAMP
@@ -1587,6 +1613,10 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         emit_row(rv, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
         if (n_roles == 3) emit_row(rg, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
     }
+#ifdef ZT_CRIT
+    if (lane == 0 && mo == 0 && mail != nullptr && i < 8192)
+        for (int q = 0; q < 8; ++q) g_crit[i * 8 + q] = crit_t[q];
+#endif
     STAMP(3);
     WL(4, wall_clock64() >> 7); WL(0, 9);
     (void)wl_fail;
@@ -2034,6 +2064,14 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
                               out_dt_dev, out_w_dev, plan_token, stream, false, nullptr, 0);
 }
 
+#ifdef ZT_CRIT
+extern "C" int zt_debug_crit(long long *host, int n)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_crit), sizeof(long long) * n * 8));
+    return ZT_OK;
+}
+#endif
 #ifdef ZT_STAMP
 extern "C" int zt_debug_stamps(long long *host, int n)
 {
