@@ -254,13 +254,17 @@ int zt_project_memory(const float *memory_dev, int64_t num_nodes, int32_t D,
  *   backward: from dH_dev [M][N][D] ACCUMULATES (+=) dW1_dev [D][D+F+T], db1_dev [D] and d_overlay_dev [U][D]
  *             (the gradient wrt the overlay rows; stored memory rows carry none)
  * fc2 and transform_source act on [N, D] matrices and stay plain GEMMs outside.
+ * drop_p > 0: the reference's training dropout of the hidden layer (nn.Dropout(0.1) between fc1's ReLU and fc2,
+ *   modules/embedding_module.py:89,323-326) inside the kernels: the keep-mask is a hash of (drop_seed, element),
+ *   regenerated by the backward from the same seed -- pass the forward's values.
  * workspaces: zt_embed_workspace_bytes(N, ...) / zt_agg_backward_workspace_bytes(D, F, T). */
 int zt_agg_train_forward(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
                          const float *efeat_dev, int64_t num_nodes, int64_t num_edges, int32_t D,
                          int32_t F, int32_t T, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev,
                          const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                          const zt_embed_weights *weights, float *H_dev, float *S_dev,
-                         void *workspace_dev, int32_t *status_dev, void *stream);
+                         void *workspace_dev, int32_t *status_dev, float drop_p, uint64_t drop_seed,
+                         void *stream);
 int64_t zt_agg_backward_workspace_bytes(int32_t D, int32_t F, int32_t T);
 int zt_agg_train_backward(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
                           const float *efeat_dev, const float *time_w_dev, int64_t num_nodes,
@@ -268,7 +272,7 @@ int zt_agg_train_backward(const float *memory_dev, const float *overlay_dev, con
                           int32_t k, const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev,
                           const float *w_dev, const float *fc1_w_dev, const float *fc1_b_dev,
                           const float *dH_dev, float *dW1_dev, float *db1_dev, float *d_overlay_dev,
-                          void *workspace_dev, void *stream);
+                          void *workspace_dev, float drop_p, uint64_t drop_seed, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Memory: last-message store + GRU update                                   */

@@ -733,6 +733,73 @@ def test_fused_training_backward_full_dims(F, k):
     assert any(np.abs(res[True][b][1]["memory_updater.memory_updater.weight_ih"]).max() > 0 for b in range(1, 6))
 
 
+@pytest.mark.parametrize("F,k", [(1, 20), (4, 10)])
+def test_fused_training_dropout(F, k):
+    """The reference trains with nn.Dropout(0.1) between fc1's ReLU and fc2 (modules/embedding_module.py:89,
+    323-326).  The fused kernels draw the keep-mask from a hash of (seed, element): forward values and all
+    gradients must equal the torch composition multiplied by that very mask (zebra_amd.modules.dropout_mask is
+    the hash in numpy), the mask must keep ~90 % and differ from seed to seed, and p = 0 must be the old path."""
+    from zebra_amd.modules import _NeighbourAggregate, dropout_mask
+    D = T = 100
+    N, E1, n, M, p = 700, 3000, 257, 2, 0.1
+    g = torch.Generator().manual_seed(41 + F)
+    w = I.model_weights(D, F, T, M, 55)
+    _, efeat = I.random_tables(N, E1, D, F, 55)
+    tgn = build_tgn(N, E1, D, F, T, k, [0.1, 0.1], [0.5, 0.95], w, efeat)
+    em = tgn.embedding_module
+    dev = tgn.device
+    mem = torch.randn((N, D), generator=g).to(dev)
+    U = 40
+    ids = torch.randperm(N, generator=g)[:U].to(dev)
+    overlay = torch.randn((U, D), generator=g).to(dev).requires_grad_(True)
+    row_map = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    row_map[ids] = torch.arange(U, dtype=torch.int32, device=dev)
+    on = torch.randint(0, N, (M, n, k), generator=g, dtype=torch.int32).to(dev)
+    oe = torch.randint(0, E1, (M, n, k), generator=g, dtype=torch.int32).to(dev)
+    od = (torch.rand((M, n, k), generator=g) * 1e5).to(dev)
+    ow = torch.rand((M, n, k), generator=g)
+    ow[:, ::6] = 0.0
+    ow = ow.to(dev)
+    G = torch.randn((M, n, D), generator=g).to(dev)
+    fc1_w = em.fc1.weight.detach().clone().requires_grad_(True)
+    fc1_b = em.fc1.bias.detach().clone().requires_grad_(True)
+
+    def fused(seed, pp):
+        for t in (overlay, fc1_w, fc1_b):
+            t.grad = None
+        em.fc1.weight.data.copy_(fc1_w.data); em.fc1.bias.data.copy_(fc1_b.data)
+        H, S = _NeighbourAggregate.apply(overlay, fc1_w, fc1_b, em, mem, row_map, ids.to(torch.int32), on, oe, od, ow, pp, seed)
+        (H * G).sum().backward()
+        row_map[ids] = torch.arange(U, dtype=torch.int32, device=dev)       # (the backward resets the shared map)
+        return H.detach().cpu().numpy(), [t.grad.detach().cpu().numpy().copy() for t in (overlay, fc1_w, fc1_b)]
+
+    def composed(mask):
+        for t in (overlay, fc1_w, fc1_b):
+            t.grad = None
+        rows = torch.where((row_map[on.long()] >= 0).unsqueeze(-1), overlay[row_map[on.long()].long().clamp(min=0)], mem[on.long()])
+        x = torch.cat([rows, em.edge_features[oe.long()], em.time_encoder(od.reshape(M * n, k)).reshape(M, n, k, T)], dim=-1)
+        h = torch.relu(torch.nn.functional.linear(x, fc1_w, fc1_b)) * mask
+        ws = ow.sum(dim=2, keepdim=True)
+        wn = torch.where(ws == 0, torch.zeros_like(ow), ow / ws)
+        H = (h * wn.unsqueeze(-1)).sum(dim=2)
+        (H * G).sum().backward()
+        return H.detach().cpu().numpy(), [t.grad.detach().cpu().numpy().copy() for t in (overlay, fc1_w, fc1_b)]
+
+    seed = 0x1234567811223344
+    mask = dropout_mask(seed, p, (M, n, k), D)
+    assert abs((mask > 0).mean() - (1 - p)) < 0.005 and np.allclose(mask[mask > 0], 1 / (1 - p))
+    assert (dropout_mask(seed + 1, p, (M, n, k), D) != mask).mean() > 0.1
+    Hf, gf = fused(seed, p)
+    Hc, gc = composed(torch.from_numpy(mask).to(dev))
+    assert np.abs(Hf - Hc).max() <= 2e-5 * max(1.0, np.abs(Hc).max())
+    for a, b in zip(gf, gc):
+        assert np.linalg.norm(a - b) <= 2e-4 * max(1.0, np.linalg.norm(b))
+    H0, g0 = fused(0, 0.0)
+    H1, g1 = composed(torch.ones((M, n, k, D), device=dev))
+    assert np.abs(H0 - H1).max() <= 2e-5 * max(1.0, np.abs(H1).max())
+    assert np.abs(Hf - H0).max() > 1e-3                                       # the mask does something
+
+
 @pytest.mark.parametrize("F,k,n", [(1, 20, 1001), (172, 10, 333), (4, 40, 257), (1, 40, 2)])
 def test_specialised_aggregate_equals_generic(F, k, n):
     """k_fc1_agg_d100 (D = T = 100, k in {10, 20, 40}) against the generic table kernel (ZT_AGG_GENERIC=1) on the

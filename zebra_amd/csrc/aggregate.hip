@@ -72,7 +72,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const int *__restrict__ nbr, const int *__restrict__ eix, const float *__restrict__ dt,
     const float *__restrict__ w, const float *__restrict__ W1p, int K1p, const float *__restrict__ b1,
     float *__restrict__ H, float *__restrict__ S, int *status, int Dout, const int *__restrict__ row_map,
-    const float *__restrict__ overlay)
+    const float *__restrict__ overlay, unsigned drop_lo = 0u, unsigned drop_hi = 0u, unsigned drop_thr = 0u,
+    float drop_inv = 1.f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);                       // [mt*16][lda]
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
                 const int g = a * 16 + g4 * 4 + j;
                 float v = acc[a][b][j] + bias;
                 v = v > 0.f ? v : 0.f;
+                if (drop_thr != 0u) v *= drop_scale(drop_lo, drop_hi, drop_thr, drop_inv, (unsigned long long)(mb + g) * Dout + col);
                 Hs[(size_t)g * ldh + col] = v * wn[g];
             }
         }
@@ -1083,10 +1085,10 @@ extern "C" int zt_agg_train_forward(const float *memory_dev, const float *overla
                                     int32_t T, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev,
                                     const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                                     const zt_embed_weights *wt, float *H_dev, float *S_dev, void *workspace_dev,
-                                    int32_t *status_dev, void *stream)
+                                    int32_t *status_dev, float drop_p, uint64_t drop_seed, void *stream)
 {
     if (!memory_dev || !efeat_dev || !wt || !status_dev || !H_dev || !S_dev || !workspace_dev || N < 0 || D <= 0 || F < 0 ||
-        T < 0 || M <= 0 || k <= 0 || (row_map_dev != nullptr && !overlay_dev)) {
+        T < 0 || M <= 0 || k <= 0 || (row_map_dev != nullptr && !overlay_dev) || !(drop_p >= 0.f && drop_p < 1.f)) {
         set_error("zt_agg_train_forward: bad argument");
         return ZT_ERR_ARG;
     }
@@ -1109,7 +1111,9 @@ extern "C" int zt_agg_train_forward(const float *memory_dev, const float *overla
     k_fc1_agg<false><<<grid, AGG_THREADS, p.lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N, k,
                                                     p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev,
                                                     reinterpret_cast<const float *>(ws + p.off_w1p), p.K1p, wt->fc1_b, H_dev,
-                                                    S_dev, status_dev, D, row_map_dev, overlay_dev);
+                                                    S_dev, status_dev, D, row_map_dev, overlay_dev, (unsigned)drop_seed,
+                                                    (unsigned)(drop_seed >> 32), zt::drop_threshold(drop_p),
+                                                    1.f / (1.f - drop_p));
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -44,6 +44,8 @@ struct BwdArgs {
     int mt;                            // 16-row tiles per step (<= BW_MT)
     int kt_lo, kt_hi;                  // this launch accumulates dW1 column tiles [kt_lo, kt_hi)
     int first;                         // 1: this launch also accumulates db1 and d_overlay
+    unsigned drop_lo, drop_hi, drop_thr;   // training dropout of the hidden layer (common.hpp: drop_scale); thr = 0: none
+    float drop_inv;
 };
 
 __global__ __launch_bounds__(BW_THREADS) void k_fc1_agg_bwd(BwdArgs a)
@@ -154,8 +156,12 @@ __global__ __launch_bounds__(BW_THREADS) void k_fc1_agg_bwd(BwdArgs a)
                     if (x >= mt) continue;
                     const int g = x * 16 + g4 * 4 + j;
                     float dp = 0.f;
-                    if (g < rows && col < D && acc[x][b][j] + bias > 0.f)
+                    if (g < rows && col < D && acc[x][b][j] + bias > 0.f) {
                         dp = wn[g] * a.dH[((size_t)m * a.N + q0 + g / k) * D + col];
+                        if (a.drop_thr != 0u)
+                            dp *= drop_scale(a.drop_lo, a.drop_hi, a.drop_thr, a.drop_inv,
+                                             (unsigned long long)(((size_t)m * a.N + q0) * k + g) * D + col);
+                    }
                     P[(size_t)g * ldp + col] = dp;
                 }
         }
@@ -258,7 +264,8 @@ extern "C" int zt_agg_train_backward(const float *memory_dev, const float *overl
                                      int32_t D, int32_t F, int32_t T, int64_t N, int32_t M, int32_t k,
                                      const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                                      const float *fc1_w_dev, const float *fc1_b_dev, const float *dH_dev, float *dW1_dev,
-                                     float *db1_dev, float *d_overlay_dev, void *workspace_dev, void *stream)
+                                     float *db1_dev, float *d_overlay_dev, void *workspace_dev, float drop_p,
+                                     uint64_t drop_seed, void *stream)
 {
     if (!memory_dev || !efeat_dev || !time_w_dev || !nbr_dev || !eix_dev || !dt_dev || !w_dev || !fc1_w_dev || !fc1_b_dev ||
         !dH_dev || !dW1_dev || !db1_dev || !workspace_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0 ||
@@ -284,6 +291,9 @@ extern "C" int zt_agg_train_backward(const float *memory_dev, const float *overl
     k_pad<<<(Dp * K1p + 255) / 256, 256, 0, s>>>(fc1_w_dev, D, K1, W1p, Dp, K1p);
     BwdArgs a;
     a.memory = memory_dev; a.overlay = overlay_dev; a.row_map = row_map_dev; a.efeat = efeat_dev; a.time_w = time_w_dev;
+    a.drop_lo = (unsigned)drop_seed; a.drop_hi = (unsigned)(drop_seed >> 32);
+    a.drop_thr = (drop_p > 0.f && drop_p < 1.f) ? zt::drop_threshold(drop_p) : 0u;
+    a.drop_inv = a.drop_thr ? 1.f / (1.f - drop_p) : 1.f;
     a.num_nodes = num_nodes; a.num_edges = num_edges; a.N = N;
     a.D = D; a.F = F; a.T = T; a.k = k; a.M = M; a.rq = rq; a.lda = K1p + 4; a.ldp = Dp + 4; a.K1p = K1p; a.Dp = Dp;
     a.nbr = nbr_dev; a.eix = eix_dev; a.dt = dt_dev; a.w = w_dev; a.W1p = W1p; a.b1 = fc1_b_dev; a.dH = dH_dev;

@@ -161,6 +161,28 @@ __device__ __forceinline__ float time_cosf(float x)
     return __builtin_amdgcn_cosf(fmaf(r, 0.159154943f, 0.25f * (float)q));
 }
 
+// Training dropout of the hidden layer (nn.Dropout(0.1) between fc1's ReLU and fc2, modules/embedding_module.py:89,
+// 323-326): the keep-mask of element idx = (gathered row) * D + column is a hash of (seed, idx), so the backward
+// kernel regenerates it instead of reading it back.  thr = p * 2^32; returns 1 / (1 - p) for a kept element, else 0.
+// (zebra_amd/modules.py: dropout_mask is the same arithmetic in numpy, for the tests.)
+__device__ __forceinline__ float drop_scale(unsigned seed_lo, unsigned seed_hi, unsigned thr, float inv_keep,
+                                            unsigned long long idx)
+{
+    unsigned h = ((unsigned)idx * 0x9E3779B1u) ^ seed_lo;
+    h ^= ((unsigned)(idx >> 32) * 0x85EBCA77u) + seed_hi;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;      // murmur3 finaliser
+    return h >= thr ? inv_keep : 0.f;
+}
+
+#endif  // __HIPCC__
+// p -> threshold of drop_scale (0 = no dropout); host side
+inline unsigned drop_threshold(float p)
+{
+    if (!(p > 0.f)) return 0u;
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+}
+#if defined(__HIPCC__)
 // floor(f / d) for small f via a precomputed multiplier m = fastdiv_magic(d); exact for f*d < 2^32.
 __device__ __forceinline__ unsigned fastdiv_magic(unsigned d) { return d <= 1u ? 0u : 0xFFFFFFFFu / d + 1u; }   // 0 = divide by 1
 __device__ __forceinline__ int fastdiv(int f, unsigned m) { return m == 0u ? f : (int)__umulhi((unsigned)f, m); }

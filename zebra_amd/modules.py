@@ -233,7 +233,7 @@ class _NeighbourAggregate(torch.autograd.Function):
     memory' = overlay rows where row_map says so (zt_agg_train_forward / zt_agg_train_backward)."""
 
     @staticmethod
-    def forward(ctx, overlay, fc1_w, fc1_b, em, memory_t, row_map, ids32, on, oe, od, ow):
+    def forward(ctx, overlay, fc1_w, fc1_b, em, memory_t, row_map, ids32, on, oe, od, ow, drop_p=0.0, drop_seed=0):
         M, N, k = on.shape
         D, F, T = em.embedding_dimension, em.n_edge_features, em.n_time_features
         need = lib().zt_embed_workspace_bytes(C.c_int64(N), C.c_int32(D), C.c_int32(F), C.c_int32(T), C.c_int32(M),
@@ -252,16 +252,16 @@ class _NeighbourAggregate(torch.autograd.Function):
                                          C.c_int64(em.edge_features.shape[0]), C.c_int32(D), C.c_int32(F), C.c_int32(T),
                                          C.c_int64(N), C.c_int32(M), C.c_int32(k), ptr(on), ptr(oe), ptr(od), ptr(ow),
                                          C.byref(em._embed_weights()), ptr(H), ptr(S), ptr(ws), ptr(em._status),
-                                         stream_ptr()), "zt_agg_train_forward")
+                                         C.c_float(drop_p), C.c_uint64(drop_seed), stream_ptr()), "zt_agg_train_forward")
         ctx.save_for_backward(ov, fc1_w, fc1_b)
-        ctx.misc = (em, memory_t, row_map, ids32, on, oe, od, ow)
+        ctx.misc = (em, memory_t, row_map, ids32, on, oe, od, ow, float(drop_p), int(drop_seed))
         ctx.mark_non_differentiable(S)
         return H, S
 
     @staticmethod
     def backward(ctx, dH, dS):
         ov, fc1_w, fc1_b = ctx.saved_tensors
-        em, memory_t, row_map, ids32, on, oe, od, ow = ctx.misc
+        em, memory_t, row_map, ids32, on, oe, od, ow, drop_p, drop_seed = ctx.misc
         M, N, k = on.shape
         D, F, T = em.embedding_dimension, em.n_edge_features, em.n_time_features
         dW1 = torch.zeros_like(fc1_w)
@@ -279,10 +279,27 @@ class _NeighbourAggregate(torch.autograd.Function):
                                           C.c_int32(F), C.c_int32(T), C.c_int64(N), C.c_int32(M), C.c_int32(k), ptr(on),
                                           ptr(oe), ptr(od), ptr(ow), ptr(w1), ptr(fc1_b.detach()),
                                           ptr(dH.contiguous()), ptr(dW1), ptr(db1), ptr(d_ov) if use_map else None,
-                                          ptr(ws), stream_ptr()), "zt_agg_train_backward")
+                                          ptr(ws), C.c_float(drop_p), C.c_uint64(drop_seed), stream_ptr()),
+              "zt_agg_train_backward")
         if use_map:
             row_map[ids32.long()] = -1
-        return d_ov, dW1, db1, None, None, None, None, None, None, None, None
+        return d_ov, dW1, db1, None, None, None, None, None, None, None, None, None, None
+
+
+def dropout_mask(seed, p, shape_mnk, D):
+    """The keep-mask the fused training kernels derive from (seed, element) -- csrc/common.hpp drop_scale in numpy:
+    float32 [M, N, k, D] of 1 / (1 - p) and 0.  For tests (the kernels never materialise it)."""
+    M, N, k = shape_mnk
+    idx = np.arange(M * N * k * D, dtype=np.uint64)
+    lo, hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        h = ((idx & np.uint64(0xFFFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779B1)) ^ lo
+        h = h ^ ((idx >> np.uint64(32)).astype(np.uint32) * np.uint32(0x85EBCA77) + hi)
+        h ^= h >> np.uint32(16); h *= np.uint32(0x85EBCA6B); h ^= h >> np.uint32(13); h *= np.uint32(0xC2B2AE35); h ^= h >> np.uint32(16)
+    t = float(np.float32(p)) * 4294967296.0
+    thr = np.uint32(4294967295 if t >= 4294967295.0 else int(t))
+    keep = h >= thr
+    return (keep.astype(np.float32) * np.float32(1.0 / (1.0 - float(np.float32(p))))).reshape(M, N, k, D)
 
 
 class GraphDiffusionEmbedding(nn.Module):
@@ -548,11 +565,15 @@ class GraphDiffusionEmbedding(nn.Module):
             m = row_map[nodes_d.long()].long()
             src_rows = torch.where((m >= 0).unsqueeze(1), overlay[m.clamp(min=0)], src_rows)
         embeddings = self.transform_source(src_rows)
-        fused = (getattr(self, "fused_training", True) and not (self.training and self.drop.p > 0)
-                 and self.embedding_dimension <= 128)
+        fused = getattr(self, "fused_training", True) and self.embedding_dimension <= 128
         if fused:
+            # the dropout of the hidden layer (self.drop, active in train mode) runs inside the kernels: a seed from
+            # torch's CPU generator (reproducible under torch.manual_seed), the mask is never materialised
+            drop_p = float(self.drop.p) if self.training else 0.0
+            drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0 else 0
+            self._last_drop_seed = drop_seed
             H, S = _NeighbourAggregate.apply(overlay, self.fc1.weight, self.fc1.bias, self, memory.memory, row_map,
-                                             ids32 if U else None, on, oe, od, ow)
+                                             ids32 if U else None, on, oe, od, ow, drop_p, drop_seed)
             if U:
                 row_map[ids] = -1
             for m_ in range(self.n_tppr):
