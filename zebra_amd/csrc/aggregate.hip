@@ -421,6 +421,8 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 //   * the projected rows are fetched with one 64-bit address per row and immediate offsets per column;
 //   * bias / ReLU / weight and the k-reduction use immediate LDS offsets (no divisions anywhere).
 // Waves 0-2 own N-tiles {w, w+4}, wave 3 owns tile 3 only (7 tiles): two instantiations of the MFMA loop.
+// (Splitting the 35 (M, N) tile pairs 9 / 9 / 9 / 8 instead of 10 / 10 / 10 / 5 was measured: no difference -- the
+// kernel is bound by the latency of a workgroup's serial phases at 4 workgroups per CU, not by MFMA issue.)
 // ---------------------------------------------------------------------------
 template <int NB>
 __device__ __forceinline__ void d100_mfma(const float *A, int lda, const float *__restrict__ bp, int K1p, int nchunk, int nrem,
