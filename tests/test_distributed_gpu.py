@@ -40,6 +40,7 @@ def _run(rank, world, port, cfg, out):
     try:
         N, E, D, F, T, k, al, be, seed, bs = cfg[:10]
         strategy = cfg[10] if len(cfg) > 10 else "streaming"
+        group = cfg[11] if len(cfg) > 11 else 0                # > 0: through the native pipeline, T-PPR launches over `group` batches
         src, dst, neg, ts, eidx = I.make_stream("bipartite" if strategy == "streaming" else "general", N, E, seed)
         w = I.model_weights(D, F, T, len(al), seed)
         _, efeat = I.random_tables(N, E + 1, D, F, seed)
@@ -53,10 +54,19 @@ def _run(rank, world, port, cfg, out):
         dev = torch.device("cuda")
         t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
         embs = []
-        for b in range(E // bs):
-            cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
-            embs.append(runner.step_device(*cur).cpu().numpy())
+        batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(E // bs)]
+        if group and world > 1:
+            tgn.enable_pipeline(tppr_cus=0, max_batch=bs, group=group)
+        main = (getattr(tgn, "main_stream", None) if group and world > 1 else None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            for b, cur in enumerate(batches):
+                if group and world > 1:
+                    embs.append(runner.step_device(*cur, ahead=batches[b + 1: b + 3 * group]).cpu().numpy())
+                else:
+                    embs.append(runner.step_device(*cur).cpu().numpy())
         torch.cuda.synchronize()
+        if group and world > 1:
+            tgn.enable_pipeline(False)
         state = {}
         if strategy == "streaming":
             tgn.embedding_module.tppr_finder.check_status()
@@ -74,10 +84,14 @@ CFGS = {
     "streaming": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200),
     # config C4's shape (SuperUser: pruning T-PPR, k=40, F=1, width 10, depth 2), 4-GPU config in BASELINE.json
     "pruning_c4": (900, 3000, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 302, 500, "pruning"),
+    # the bench's multi-GPU path: ShardedTGN over the native pipeline, T-PPR launches over two batches
+    "streaming_pipe": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200, "streaming", 2),
+    "streaming_pipe1": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200, "streaming", 1),
 }
 
 
-@pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4")])
+@pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4"),
+                                            (2, "streaming_pipe1"), (2, "streaming_pipe")])
 def test_sharded_equals_single(world, cfg_name):
     cfg = CFGS[cfg_name]
     mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
