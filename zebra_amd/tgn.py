@@ -129,6 +129,7 @@ class TGN(torch.nn.Module):
         em, m, g = self.embedding_module, self.memory, self.memory_updater.memory_updater
         tables = (id(m.memory), m.memory._version, id(m.last_update), id(m.messages), id(m.timestamps), id(m._flag_buf),
                   id(self.edge_raw_features), getattr(em, "_proj_serial", 0),
+                  id(em._proj["table"]) if em._proj is not None else 0, id(em._status),
                   id(em._ws), id(self.memory_updater._ws),      # the workspaces the descriptor points into (they are
                                                                 # replaced when a call outside the pipeline needs more)
                   id(em.tppr_finder._live) if em.tppr_strategy == "streaming" else id(em.neighbor_finder))
