@@ -219,6 +219,51 @@ def test_grouped_tppr_launches_match_sequential(group, look, ragged):
                 assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
 
 
+def test_pipeline_follows_backup_and_restore():
+    """The native pipeline holds raw pointers to the memory tables, the T-PPR handle and the workspaces: replacing
+    any of them between steps (restore_memory / restore_tppr of the epoch protocol, train.py:296-306, a call
+    outside the pipeline that grows a workspace) must be noticed -- same results as without the pipeline."""
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(E // bs)]
+    outs = {}
+    for pipe in (False, True):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if pipe:
+            tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=2)
+        em = tgn.embedding_module
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        embs = []
+
+        def steps(lo, hi):
+            with torch.cuda.stream(main):
+                for b in range(lo, hi):
+                    ahead = batches[b + 1: min(hi, b + 6)] if pipe else None
+                    embs.append(tgn.step_device(*batches[b], ahead=ahead).clone())
+            torch.cuda.synchronize()
+
+        steps(0, 4)
+        mem_bak = tgn.memory.backup_memory()
+        tppr_bak = em.backup_tppr()
+        steps(4, 8)
+        tgn.memory.restore_memory(mem_bak)              # new tensors behind the same names
+        em.restore_tppr(tppr_bak)
+        tgn.memory_updater.update_memory_in_test(tgn.memory)      # a call outside the pipeline (grows the GRU workspace)
+        steps(4, 9)
+        outs[pipe] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(), em.tppr_finder.export_state(0))
+        if pipe:
+            tgn.enable_pipeline(False)
+    assert np.array_equal(outs[False][0], outs[True][0])
+    assert np.array_equal(outs[False][1], outs[True][1])
+    for kk in outs[False][2]:
+        assert np.array_equal(outs[False][2][kk], outs[True][2][kk])
+
+
 def test_full_size_step_properties():
     """The whole eval step at BASELINE.json's full-size configuration (C5: 10 M nodes, bs=4096, k=20,
     D=T=100, F=1), checked through size-independent properties: (1) the pipelined schedule (T-PPR one
