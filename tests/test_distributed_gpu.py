@@ -87,11 +87,12 @@ CFGS = {
     # the bench's multi-GPU path: ShardedTGN over the native pipeline, T-PPR launches over two batches
     "streaming_pipe": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200, "streaming", 2),
     "streaming_pipe1": (600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200, "streaming", 1),
+    "pruning_pipe": (900, 3000, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 302, 500, "pruning", 1),
 }
 
 
 @pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4"),
-                                            (2, "streaming_pipe1"), (2, "streaming_pipe")])
+                                            (2, "streaming_pipe1"), (2, "streaming_pipe"), (3, "pruning_pipe")])
 def test_sharded_equals_single(world, cfg_name):
     cfg = CFGS[cfg_name]
     mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
