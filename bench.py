@@ -279,8 +279,12 @@ def main():
             # whole XCDs (32 CUs, one L2 each): a mask that splits an XCD leaves the main stream a straggler XCD.
             # Two XCDs for the T-PPR stream at C5's batch (its non-hub tasks need the waves), one for small batches.
             a.tppr_cus = (64 if bs >= 2048 else 32) if wl["strategy"] == "streaming" else 0
-        if world > 1 and not rehearsal:
-            a.tppr_cus = 0          # RCCL kernels run on the main stream: keep it an ordinary (unmasked) stream
+        # Several ranks: the same masks.  torch.distributed runs the RCCL kernel of the row exchange on a stream of
+        # its own (ProcessGroupNCCL orders it against the current stream with events), so the masks neither confine nor
+        # block it; without them the T-PPR kernel shares CUs with the aggregation (N = 1: 0.665 instead of 0.585
+        # ms/step).  ZT_BENCH_NO_MASKS=1 switches them off.
+        if os.environ.get("ZT_BENCH_NO_MASKS") == "1":
+            a.tppr_cus = 0
         try:
             tgn.enable_pipeline(tppr_cus=a.tppr_cus, group=a.group)
         except Exception as exc:                       # no CU-mask support: plain streams

@@ -199,3 +199,55 @@ def test_data_parallel_training_step_equals_single():
                     assert not ga[pn].any(), pn
                     continue
                 assert np.linalg.norm(ga[pn] - gb[pn]) <= 2e-3 * max(1e-3, np.linalg.norm(gb[pn])), "%s step %d" % (pn, b)
+
+
+def _nccl_run(rank, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here, os.path.join(here, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from helpers import build_tgn
+    from zebra_amd.distributed import ShardedTGN
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        N, E, D, F, T, k, al, be, seed, bs = 600, 2400, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 301, 200
+        src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, seed)
+        w = I.model_weights(D, F, T, 2, seed)
+        _, efeat = I.random_tables(N, E + 1, D, F, seed)
+        dev = torch.device("cuda")
+        t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+        batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(E // bs)]
+        res = {}
+        for mode in ("plain", "sharded"):
+            tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+            embs = []
+            if mode == "plain":
+                for cur in batches:
+                    embs.append(tgn.step_device(*cur).cpu().numpy())
+            else:
+                tgn.enable_pipeline(tppr_cus=64, max_batch=bs, group=2)
+                runner = ShardedTGN(tgn, 0, 1)
+                with torch.cuda.stream(tgn.main_stream):
+                    for b, cur in enumerate(batches):
+                        embs.append(runner.step_device(*cur, ahead=batches[b + 1:b + 6]).cpu().numpy())
+                torch.cuda.synchronize()
+                tgn.enable_pipeline(False)
+            res[mode] = (embs, tgn.memory.memory.cpu().numpy())
+        out[0] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_exchange_on_cu_masked_streams():
+    """What one GPU can show of the multi-GPU bench path WITH RCCL: a process group of one rank over the "nccl"
+    backend, ShardedTGN over the native pipeline on CU-masked streams (the all-gather of touched rows runs on
+    torch.distributed's own stream, ordered against the masked main stream by events).  Equals the plain run."""
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_run, args=(_free_port(), out), nprocs=1, join=True)
+    a, b = out[0]["plain"], out[0]["sharded"]
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
+    assert np.array_equal(a[1], b[1])
