@@ -300,7 +300,8 @@ def main():
     def batch(b):
         return batches[b]
 
-    look = 3 * a.group - 1                      # batches in sight: the rest of this group, the next group, the one after
+    look = 3 * a.group                          # batches in sight: the rest of this group, the next group, the one after
+                                                # it, and one more (a group is only full while a follower is in sight)
 
     def run(b0, nb):
         # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)

@@ -17,7 +17,7 @@
 // separate calls (the reference's loop has no state between calls other than the dictionaries), each batch's
 // output rows form their own block (StreamArgs::sub_B), and the fixed cost of a launch -- the packets between
 // two kernels on the T-PPR stream, the kernel's start and tail, its cold instruction cache -- is paid once per
-// group.  The caller shows the batches that follow (zt_pipeline_step_ahead); with fewer than 3 * group - 1 of
+// group.  The caller shows the batches that follow (zt_pipeline_step_ahead); with fewer than 3 * group of
 // them in sight the groups simply come out smaller.  The pruning strategy has no state to carry: group = 1.
 #include "common.hpp"
 
@@ -128,6 +128,10 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     add(first);
     const bool streaming = p->d.tppr != nullptr;
     if (want > MAX_GROUP) want = MAX_GROUP;
+    // Leave a follower in sight: the aggregation of a group's FIRST batch waits for the whole launch, so where the
+    // view ahead ends (the end of a stream, or of a timed region) the last batches are queried one by one and the
+    // aggregation of each runs beside the update of the next.
+    if (n_more < want) want = n_more >= 1 ? n_more : 1;
     for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
         const zt_batch *b = more + q;
         // members are equally long, except that the last one may be shorter; everything fits one launch and the slot
@@ -308,8 +312,15 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         int jn = 0;
         zt_pipeline::Slot *n = find_slot(p, ahead + a, &jn);
         if (n == nullptr) {
-            rc = make_group(p, ahead + a, ahead + a + 1, n_ahead - a - 1, want, p->side, &n, true);
+            // not planned by an earlier step (the start of a stream): its prepass goes to the plan stream all the same,
+            // beside the current batch's update, not behind it on the T-PPR stream
+            rc = make_group(p, ahead + a, ahead + a + 1, n_ahead - a - 1, want, p->plan_s, &n, pruning);
             if (rc != ZT_OK) return rc;
+            if (!pruning) {
+                rc = zt_tppr_plan(d.tppr, n->nodes, n->eidx, n->Btot, 3, -1, &n->token, p->plan_s);
+                if (rc != ZT_OK) { (void)hipEventRecord(n->filled, p->plan_s); return rc; }
+                ZT_HIP(hipEventRecord(n->filled, p->plan_s));
+            }
         }
         if (!n->launched) {
             int64_t nlo, nhi;
