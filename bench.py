@@ -10,12 +10,18 @@ pruning) T-PPR update + row emission, gather/TimeEncode/transform/weighted
 sum for the 3B rows x n_tppr models, last-message store and GRU memory update.
 All inputs are resident in HBM when the timed region starts.
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): T-PPR
-state and memory are replicated, every rank applies the whole batch's T-PPR
-update (bit-identical replicas, no communication), the 3B embedding rows and
-the touched-endpoint memory updates are sharded, and the touched memory rows
-are exchanged with one all-gather per batch.  Total work per
-step is fixed ("strong" scaling).
+N > 1 runs one rank per GPU over RCCL.  Either a launcher starts the ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE in the environment), or `python bench.py --gpus N`
+starts them itself: the parent -- BEFORE it has touched the GPU -- runs that
+launcher as a child process, lets rank 0's JSON line through and exits with
+the children's status.  T-PPR state and memory are replicated, every rank
+applies the whole batch's T-PPR update (bit-identical replicas, no
+communication), the 3B embedding rows and the touched-endpoint memory updates
+are sharded, and the touched memory rows are exchanged with one all-gather per
+batch.  Total work per step is fixed ("strong" scaling).
+`--dry-run` stops after the rendezvous (no GPU needed: the CPU-side test of the
+launch path).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with the
 `roofline` of the dominant kernel and the `cpu_baseline` (oracle timed on the
@@ -73,9 +79,10 @@ def executed_flops(k, F, M, D=100, T=100, projected=True):
                 project_rows=M * 2 * 2 * D * D if projected else 0)
 
 
-def make_stream(wl, n_edges, seed=2020):
+def make_stream(wl, n_edges, seed=2020, perm_seed=None):
     from zebra_amd import synth
-    src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], n_edges, bipartite=wl["bipartite"], seed=seed)
+    src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], n_edges, bipartite=wl["bipartite"], seed=seed,
+                                                perm_seed=perm_seed)
     neg = synth.negatives(dst, n_edges, seed=seed + 1)
     return src, dst, neg, ts, eidx
 
@@ -134,11 +141,15 @@ def model_weights(tgn):
 
 def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
     """Oracle ("port") on the host cores: the eval-mode protocol on the first timed batches of the same
-    stream, started from the GPU run's warm state.  The T-PPR loop runs single-threaded like the
-    reference's Numba loop for the first half of the sample and with one thread per T-PPR model for
-    the second half (the N-thread P1 variant, N = n_tppr); aggregation / GRU on n_threads OpenMP threads."""
+    stream, started from the GPU run's warm state.  SURVEY.md 8(d): P1 = the C restatement, single-threaded
+    like the reference's Numba loop, P2 / P3 = the build's torch-CPU module (oracle/torch_cpu.py: the torch
+    ops the reference runs, torch.get_num_threads() threads) -- that is `value`, first half of the sample.
+    Second half, reported beside it: P1 with one thread per T-PPR model and P2 / P3 by the C port on
+    n_threads OpenMP threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
+    import torch
+    torch.set_num_threads(n_threads)
     bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
     D = T = 100
     N = wl["n_nodes"] + 1
@@ -165,6 +176,7 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
     single = p.tppr.streaming_topk if p.tppr is not None else None
     for b, (src, dst, neg, ts, eidx) in enumerate(batches):
         part = 0 if b < half else 1
+        p.p23 = "torch" if part == 0 else "c"
         if p.tppr is not None:
             p.tppr.streaming_topk = single if part == 0 else p.tppr.streaming_topk_threads
         t0 = time.perf_counter()
@@ -178,17 +190,42 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
         n_e[part] += len(src)
     if p.tppr is not None:
         p.tppr.streaming_topk = single
-    out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=n_threads, kind="port",
+    out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=torch.get_num_threads(), kind="port",
+               host_cpus=os.cpu_count(), torch_num_threads=torch.get_num_threads(),
+               value_is="P1: C port on 1 thread; P2/P3: torch-CPU ops (oracle/torch_cpu.py)",
                p1_edges_per_s_1thread=n_e[0] / max(t_p1[0], 1e-9),
+               p23_edges_per_s_torch_cpu=n_e[0] / max(t_all[0] - t_p1[0], 1e-9),
                sample="%d batches (%d edges) of the same stream starting from the GPU run's state after the prefill "
-                      "(where its warm-up steps start); value = first "
-                      "%d batches with the T-PPR loop on 1 thread (as the reference's Numba loop); aggregation / "
-                      "GRU / scorer on %d OpenMP threads" % (len(batches), n_e[0] + n_e[1], half, n_threads))
+                      "(where its warm-up steps start); value = first %d batches: T-PPR loop (C port) on 1 thread as "
+                      "the reference's Numba loop, aggregation / messages / GRU as torch-CPU ops on %d threads; the other "
+                      "batches: T-PPR with one thread per model, aggregation / GRU by the C port on %d OpenMP threads"
+                      % (len(batches), n_e[0] + n_e[1], half, torch.get_num_threads(), n_threads))
     if n_e[1]:
-        out["value_p1_threads"] = n_e[1] / t_all[1]
+        out["value_c_port"] = n_e[1] / t_all[1]
+        out["c_port_threads"] = n_threads
         out["p1_threads"] = M if wl["strategy"] == "streaming" else 1
         out["p1_edges_per_s_threads"] = n_e[1] / max(t_p1[1], 1e-9)
+        out["p23_edges_per_s_c_port"] = n_e[1] / max(t_all[1] - t_p1[1], 1e-9)
     return out
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as a CHILD process (the
+    torch.distributed launcher) before this process has made any GPU call, let their output through
+    (rank 0 prints the JSON line) and exit with their status.  Never exec: a process that has initialised
+    the GPU must not be replaced, and this one stays clear of the GPU altogether."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ZT_BENCH_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.stderr.write("[bench] --gpus %d: starting %d ranks: %s\n" % (n, n, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -214,16 +251,44 @@ def main():
                          "default: as many as fit a launch (<= 8192 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
+    ap.add_argument("--perm-seed", type=int, default=7,
+                    help="shuffle which node id carries which popularity rank (hot rows of the per-node tables are then "
+                         "scattered, not contiguous); -1 = id == rank as in rounds 1-2")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (gloo, no GPU): checks that --gpus N really starts N ranks")
     a = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from zebra_amd import _capi, synth
-    import ctypes as C
-
+    # ---- --gpus N without a launcher: this process becomes the parent of N ranks and never touches the GPU ----
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+
+    if a.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        n_seen = 1
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            n_seen = int(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (rendezvous only)", "value": None, "n_gpus": world, "ranks_seen": n_seen,
+                              "dry_run": True, "launched_by": "bench.py" if os.environ.get("ZT_BENCH_LAUNCHED") else "launcher"}))
+        return
+
+    from zebra_amd import _capi, synth
+    import ctypes as C
+
     # rehearsal on a one-GPU box: ZT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
     rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -250,7 +315,7 @@ def main():
     if n_edges > wl["n_edges"]:
         raise SystemExit("stream of %d edges is shorter than prefill+warmup+steps" % wl["n_edges"])
 
-    src, dst, neg, ts, eidx = make_stream(wl, n_edges)
+    src, dst, neg, ts, eidx = make_stream(wl, n_edges, perm_seed=None if a.perm_seed < 0 else a.perm_seed)
     n_edge_rows = (wl["n_edges"] if F == 1 else n_edges) + 1      # F=1: the full |E|+1 zero table is cheap
     tgn = build_model(wl, device, n_edge_rows)
     if wl["strategy"] == "pruning":
@@ -423,8 +488,10 @@ def main():
             byts = ab["p3"] * bs / shard
             note = None
         ach = byts / us / 1e9
-        out_r = dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                     traffic=tr, note=note)
+        # the streaming T-PPR kernel is bound by (hops of the longest per-node chain) x (latency of one hop), not by
+        # HBM: `achieved` / `peak` / `frac` are still its algorithmic bytes against the HBM peak, for the record
+        out_r = dict(kernel=name, bound="latency" if name == "tppr_stream" else "hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, note=note)
         if name == "tppr_stream":
             out_r["edges_per_launch"] = per_launch
         return out_r
@@ -461,18 +528,25 @@ def main():
                                "prefill %d + warmup %d batches" % (a.workload, "bipartite" if wl["bipartite"] else
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],
                                                                    wl["beta"], wl["strategy"], F, prefill, a.warmup),
-                   "global_batch": bs, "tppr_launch_group": a.group,
+                   "global_batch": bs, "tppr_launch_group": a.group, "tppr_cus": a.tppr_cus,
+                   "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
                    "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
+        "rccl_ranks": world if (world > 1 and not rehearsal) else 0,
         "roofline": roof,
         "roofline_throughput_kernel": roof2,
         "cpu_baseline": cpu,
         "row_fill": fill,
+        # flops_per_edge: SURVEY.md 8(d)'s figure = the REFERENCE's formulation (fc2 per neighbour, W_m memory per
+        # gathered row, scorer included); executed_flops_per_edge: what the step's kernels execute (no scorer: the
+        # timed step ends with the embeddings, as TGN.compute_temporal_embeddings does)
         "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
-                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"] + af["scorer"],
+                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"],
                         "hbm_gbs_at_value": ab["total"] * value / 1e9,
                         "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
-                        "mfma_tflops_at_value": af["total"] * value / 1e12,
-                        "mfma_frac_at_value": af["total"] * value / 1e12 / MFMA_F32_PEAK_TF},
+                        "reference_formulation_tflops_at_value": af["total"] * value / 1e12,
+                        "reference_formulation_mfma_frac_at_value": af["total"] * value / 1e12 / MFMA_F32_PEAK_TF,
+                        "executed_mfma_frac_at_value": (ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"])
+                                                       * value / 1e12 / MFMA_F32_PEAK_TF},
         "kernels": kern,
     }
     print(json.dumps(out))

@@ -325,11 +325,15 @@ typedef struct {
  *   bytes are cleared with 32-bit atomics).
  *   workspace_dev: zt_gru_workspace_bytes(max_rows, D, msg_dim) bytes, where
  *   max_rows = n_ids (or num_nodes when ids_dev == NULL).  On return its first
- *   int32 holds the number of rows updated and the int32 array at byte 256
- *   their ids (duplicates in ids_dev are updated once).
+ *   int32 holds the number of rows updated and the int32 array at byte
+ *   zt_gru_rows_offset(D, msg_dim) their ids (duplicates in ids_dev are updated
+ *   once).  The packed weights sit between the two, so their place does not
+ *   depend on max_rows.
  *   weights_ready: 0 = pack the GRU weights into the workspace first; 1 = the
- *   workspace already holds them (same workspace, same max_rows, same weights). */
+ *   workspace already holds them (same workspace, same weights; max_rows may
+ *   differ from call to call). */
 int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t msg_dim);
+int64_t zt_gru_rows_offset(int32_t D, int32_t msg_dim);
 int zt_gru_update(float *memory_dev, float *last_update_dev,
                   const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D,
@@ -398,6 +402,14 @@ int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, 
  * a group are equally long (the last may be shorter) and together at most 8192 edges.  zt_pipeline_step is this
  * call with ahead = {next, plan}.  The pruning strategy carries no state between batches: its group is 1. */
 int zt_pipeline_set_group(zt_pipeline *p, int32_t group);
+/* embedding_module.average_topk (modules/embedding_module.py:232-233): with a non-NULL device float, every step
+ * over a whole batch also writes the mean over the 2B rows of [src | dst] of the sum of model 0's T-PPR weights
+ * there (main stream).  NULL switches it off. */
+int zt_pipeline_set_stats(zt_pipeline *p, float *avg_topk_dev);
+/* Batches whose T-PPR query was launched ahead of their step and that no step has consumed yet.  While it is
+ * non-zero the streaming T-PPR state is AHEAD of the last step: a caller must not query or update the state
+ * through zt_tppr_stream (or leave the announced order) before those batches have been stepped. */
+int zt_pipeline_outstanding(const zt_pipeline *p);
 int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *ahead, int32_t n_ahead,
                            int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
 

@@ -292,6 +292,8 @@ class ProtocolOracle:
         self.finder = finder
         self.init_memory()
         self.test_mode = False
+        self.p23 = "c"                            # "torch": P2 / P3 through oracle/torch_cpu.py (same state arrays)
+        self._t23 = None
 
     def init_memory(self):                       # Memory.__init_memory__ (modules/memory.py:19-25)
         self.mem = MemoryOracle(self.N, self.D, 2 * self.D + self.F + self.T)
@@ -313,9 +315,29 @@ class ProtocolOracle:
                 o.append(x)
         return outs
 
+    def _torch_batch(self, src, dst, neg, ts, eidx, topk_out):
+        """The eval-mode batch with P2 / P3 on torch-CPU ops (bench.py's cpu_baseline)."""
+        if self._t23 is None or self._t23.mem is not self.mem:
+            from torch_cpu import TorchCpuP23
+            self._t23 = TorchCpuP23(self.mem, self.w, self.efeat, self.tw, self.n_threads)
+        t, B = self._t23, len(src)
+        nodes = np.concatenate([src, dst, neg]).astype(np.int32)
+        positives = np.unique(np.concatenate([src, dst]))
+        if not self.test_mode:
+            t.gru_update(None)
+            self.test_mode = True
+        on, oe, od, ow = topk_out if topk_out is not None else self.topk(nodes, ts, eidx)
+        emb = t.embed(nodes, on, oe, od, ow)
+        t.store_messages(src, dst, ts, eidx)
+        t.gru_update(positives)
+        self.average_topk = float(np.mean(np.sum(ow[0][:2 * B], axis=1)))
+        return emb, None
+
     def batch(self, src, dst, neg, ts, eidx, train, topk_out=None):
         """-> (embeddings [3B, D*(M+1)], probabilities [2B]).  ``topk_out``: this batch's T-PPR query if the
         caller has run (and timed) it already."""
+        if self.p23 == "torch" and not train:
+            return self._torch_batch(src, dst, neg, ts, eidx, topk_out)
         mem, B = self.mem, len(src)
         nodes = np.concatenate([src, dst, neg]).astype(np.int32)
         positives = np.unique(np.concatenate([src, dst]))

@@ -134,3 +134,27 @@ def test_allreduce_gradients_gloo():
     out = mgr.dict()
     mp.spawn(_grads_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert len(out) == 2
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it, the form the driver uses for N = 1) must start two
+    ranks itself -- the parent as a plain child-process launcher that never touches the GPU -- and rank 0's
+    line must say n_gpus = 2 (round-2 review: --gpus was parsed and never read).  --dry-run: rendezvous
+    over gloo only, so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["launched_by"] == "bench.py"
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent 1-GPU run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0

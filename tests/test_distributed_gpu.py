@@ -251,3 +251,23 @@ def test_rccl_exchange_on_cu_masked_streams():
     a, b = out[0]["plain"], out[0]["sharded"]
     assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
     assert np.array_equal(a[1], b[1])
+
+
+def test_bench_gpus_2_rehearsal():
+    """`python bench.py --gpus 2` end to end on ONE GPU (ZT_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo instead
+    of RCCL, no hub chains): the parent starts the two ranks, the sharded pipeline runs, rank 0's line says
+    n_gpus = 2.  (What the driver's scaling run does with RCCL on separate GPUs.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ZT_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "6",
+                        "--warmup", "2", "--prefill-steps", "20", "--cpu-edges", "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0

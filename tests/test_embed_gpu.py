@@ -219,6 +219,141 @@ def test_grouped_tppr_launches_match_sequential(group, look, ragged):
                 assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
 
 
+def test_pipeline_batch_size_change_keeps_packed_weights():
+    """A pipelined stream whose LAST batch is shorter by enough to move round_up(4 * 2B, 256) -- bs = 64 then 20 --
+    (round-2 advisor finding: the GRU's packed weights used to sit behind the row list of the workspace, whose
+    length follows the batch; the shorter batch then read them from the wrong place).  Results must equal the
+    sequential path bit for bit: embeddings of every batch, the whole memory, pending messages."""
+    N, D, F, T, k, al, be, seed, bs = 300, 100, 1, 100, 20, [0.1, 0.1], [0.5, 0.95], 57, 64
+    E = 5 * bs + 20
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    cuts = list(range(0, E, bs)) + [E]
+    batches = [tuple(x[a:b] for x in t) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert batches[-1][0].numel() == 20
+    outs = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode == "pipe":
+            tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=2)
+        embs = []
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            for b, cur in enumerate(batches):
+                embs.append(tgn.step_device(*cur, ahead=batches[b + 1: b + 6] if mode == "pipe" else None).clone())
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        outs[mode] = ([e.cpu().numpy() for e in embs], tgn.memory.memory.cpu().numpy(), tgn.memory.messages.cpu().numpy(),
+                      tgn.memory.last_update.cpu().numpy())
+        tgn.enable_pipeline(False)
+    for b in range(len(batches)):
+        assert np.array_equal(outs["seq"][0][b], outs["pipe"][0][b]), "batch %d" % b
+    for q in (1, 2, 3):
+        assert np.array_equal(outs["seq"][q], outs["pipe"][q])
+
+
+def test_pipeline_refuses_to_drop_an_applied_group():
+    """Leaving the announced order: three groups whose T-PPR update has been launched are waiting, the caller
+    presents a batch none of them holds.  The streaming state already contains those edges -- dropping a group
+    would apply them twice later -- so the step must fail instead (round-2 advisor finding)."""
+    N, D, F, T, k, al, be, seed, bs = 300, 100, 1, 100, 20, [0.1, 0.1], [0.5, 0.95], 58, 16
+    E = 12 * bs
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(E // bs)]
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=1)
+    with torch.cuda.stream(tgn.main_stream):
+        tgn.step_device(*batches[0], ahead=batches[1:3])          # 1 is queried ahead, 2 planned
+        assert tgn.pipeline_outstanding() == 1
+        tgn.step_device(*batches[5], ahead=batches[6:8])          # out of order: 5 queried now, 6 ahead -> 1, 6 launched
+        with pytest.raises(ValueError):
+            for b in (8, 9, 10):                                  # sooner or later no slot is left that may be dropped
+                tgn.step_device(*batches[b], ahead=batches[b + 1: b + 2])
+    torch.cuda.synchronize()
+    tgn.enable_pipeline(False)
+
+
+@pytest.mark.parametrize("perm", [None, 9])
+def test_bench_path_vs_oracle(oracle, perm):
+    """What bench.py times -- TGN.step_device through the native pipeline with CU-masked streams (T-PPR on 64 CUs),
+    grouped T-PPR launches (two batches per launch), hub chains active, the specialised aggregation kernel and the
+    projected memory table, at bench.py's batch size -- against the CPU oracle's protocol DIRECTLY (round-2 review:
+    this path was only ever compared with the sequential HIP path).  Power-law stream over 100 K nodes, bs = 4096,
+    a short fill, then 12 checked batches: embeddings of every batch <= 1e-4, then the T-PPR state bit-exact and
+    memory / last_update / messages / flags."""
+    from zebra_amd import synth
+    N, D, F, T, k, bs = 100_000, 100, 1, 100, 20, 4096
+    al, be = [0.1, 0.1], [0.5, 0.95]
+    fill, nb = 6, 12
+    E = (fill + nb) * bs
+    src, dst, ts, eidx = synth.power_law_stream(N, E, seed=301, perm_seed=perm)
+    neg = synth.negatives(dst, E, seed=302)
+    w = I.model_weights(D, F, T, len(al), 303)
+    efeat = synth.edge_features(E + 1, F, seed=304)
+    tw = I.time_encode_weights(T)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(fill + nb)]
+    tgn = build_tgn(N + 1, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    tgn.enable_pipeline(tppr_cus=64, group=2)
+    p = oracle.ProtocolOracle(N + 1, D, F, T, k, al, be, w, efeat, tw, n_threads=8)
+    embs = []
+    with torch.cuda.stream(tgn.main_stream):
+        for b, cur in enumerate(batches):
+            e = tgn.step_device(*cur, ahead=batches[b + 1: b + 7])
+            if b >= fill:
+                embs.append(e.clone())
+    torch.cuda.synchronize()
+    tgn.embedding_module.tppr_finder.check_status()
+    worst = 0.0
+    for b in range(fill + nb):
+        s, e = b * bs, (b + 1) * bs
+        ref, _ = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        if b >= fill:
+            worst = max(worst, float(np.abs(embs[b - fill].cpu().numpy() - ref).max()))
+    assert worst <= TOL, "embeddings differ from the oracle by %g" % worst
+    f = tgn.embedding_module.tppr_finder
+    for m in range(len(al)):
+        a, bb = f.export_state(m), p.tppr.export(m)
+        for kk in a:
+            assert np.array_equal(a[kk], bb[kk]), "T-PPR state %s of model %d differs from the oracle" % (kk, m)
+    assert np.abs(tgn.memory.memory.cpu().numpy() - p.mem.memory).max() <= TOL
+    assert np.array_equal(tgn.memory.last_update.cpu().numpy(), p.mem.last_update)
+    assert np.abs(tgn.memory.messages.cpu().numpy() - p.mem.messages).max() <= TOL
+    assert np.array_equal(tgn.memory.nodes.astype(np.uint8), p.mem.flags)
+    tgn.enable_pipeline(False)
+
+
+def test_reference_surface_reaches_the_pipeline(oracle):
+    """compute_temporal_embeddings (numpy batches, the reference's surface) runs through the native pipeline once it
+    is enabled -- average_topk then comes from the slot's weights (zt_pipeline_set_stats) -- with the oracle's
+    results."""
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    tgn.enable_pipeline(tppr_cus=0, max_batch=64)
+    p = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T))
+    for b in range(E // bs):
+        s, e = b * bs, (b + 1) * bs
+        with torch.no_grad():
+            se, de, ne = tgn.compute_temporal_embeddings(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], 10, False)
+        ref, _ = p.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        assert np.abs(torch.cat([se, de, ne]).cpu().numpy() - ref).max() <= TOL
+        assert abs(tgn.embedding_module.average_topk - p.average_topk) < 1e-6
+    assert tgn.pipeline_outstanding() == 0
+    tgn.enable_pipeline(False)
+
+
 def test_pipeline_follows_backup_and_restore():
     """The native pipeline holds raw pointers to the memory tables, the T-PPR handle and the workspaces: replacing
     any of them between steps (restore_memory / restore_tppr of the epoch protocol, train.py:296-306, a call

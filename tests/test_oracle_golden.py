@@ -275,3 +275,40 @@ def test_epoch_protocol(oracle, name):
     w = I.model_weights(D, F, T, len(al), seed)
     _, efeat = I.random_tables(N, E + 1, D, F, seed)
     epoch_protocol(_OracleEpochAdapter(oracle, case, w, efeat), g, case, streams, make_checker(g, EMB_TOL))
+
+
+def test_torch_cpu_p23_equals_c_port(oracle):
+    """oracle/torch_cpu.py (torch-CPU ops: bench.py's cpu_baseline for P2 / P3) against the C port on the same
+    stream: embeddings, memory, messages within 1e-5; last_update and flags exact."""
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES["d100_f172"]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tw = I.time_encode_weights(T)
+    a = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, tw)
+    b = oracle.ProtocolOracle(N, D, F, T, k, al, be, w, efeat, tw, n_threads=2)
+    b.p23 = "torch"
+    for q in range(E // bs):
+        s, e = q * bs, (q + 1) * bs
+        ea, _ = a.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        eb, _ = b.batch(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], False)
+        assert np.abs(ea - eb).max() <= 1e-5, "batch %d" % q
+    assert np.abs(a.mem.memory - b.mem.memory).max() <= 1e-5
+    assert np.abs(a.mem.messages - b.mem.messages).max() <= 1e-5
+    assert np.array_equal(a.mem.last_update, b.mem.last_update)
+    assert np.array_equal(a.mem.flags, b.mem.flags)
+
+
+def test_oracle_under_sanitizers():
+    """SURVEY.md section 5 (race detection / sanitizers): the C oracle built with -fsanitize=address,undefined
+    (`make -C oracle sanitize`) and driven through every entry point -- hubs, ties, self-loops, duplicate
+    timestamps, empty rows, rejected out-of-range ids, OpenMP paths -- must finish without a report.  (GPU
+    AddressSanitizer is not available on this pool; the host-side checker is what can be sanitized.)"""
+    import os
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.run(["make", "-C", root, "sanitize"], check=True, stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(root, "_san", "sanitize_driver")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "sanitize_driver: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr

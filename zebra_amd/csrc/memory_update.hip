@@ -259,10 +259,12 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.lds = (size_t)GRU_MT * 16 * p.lda * 4 + GRU_MT * 16 * 4;   // A tile + node ids
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    // the packed weights come BEFORE the row list: their place does not depend on max_rows, so a workspace whose
+    // weights are packed (weights_ready) stays valid when the next call has a different number of ids
     p.off_cnt = take(256);
-    p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
     p.off_wih = take((size_t)3 * p.Hp * p.Xp * 4);
     p.off_whh = take((size_t)3 * p.Hp * p.Hp * 4);
+    p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
     p.total = o;
 }
 
@@ -381,6 +383,14 @@ extern "C" int64_t zt_gru_workspace_bytes(int64_t max_rows, int32_t D, int32_t m
     return (int64_t)p.total;
 }
 
+extern "C" int64_t zt_gru_rows_offset(int32_t D, int32_t msg_dim)
+{
+    if (D <= 0 || msg_dim <= 0) return -1;
+    GruPlan p;
+    gru_plan(1, D, msg_dim, p);
+    return (int64_t)p.off_rows;
+}
+
 extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const float *messages_dev,
                              const float *msg_ts_dev, uint8_t *flags_dev, int64_t num_nodes, int32_t D,
                              int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids, const int32_t *n_ids_dev,
@@ -407,7 +417,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     ZT_PROF_BEGIN(s, P_GRU);
     k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
                                                                       rows, cnt);
-    if (!weights_ready) {                       // gate-packed, padded copies: once per weight change and max_rows
+    if (!weights_ready) {                       // gate-packed, padded copies: once per weight change
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
     }

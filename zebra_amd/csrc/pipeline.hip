@@ -48,6 +48,7 @@ struct zt_pipeline {
         int n, n_done;
         int64_t Btot;
         uint64_t token;        // zt_tppr_plan token, 0 = none
+        int64_t q_lo, q_hi;    // pruning strategy: the rows of the (single) member the query was launched for
         bool launched, used;
     } slot[3];
     int next_slot;
@@ -56,6 +57,8 @@ struct zt_pipeline {
     int32_t *sh_on, *sh_oe;
     float *sh_od, *sh_ow;
     bool embed_ready, gru_ready;
+    hipEvent_t entry;          // main stream at the moment a group is staged: the batches' tensors are written by then
+    float *avg_topk;           // zt_pipeline_set_stats: mean row sum of model 0's weights over [src | dst] (or NULL)
 };
 
 namespace {
@@ -89,6 +92,22 @@ __global__ void k_stage_group(GroupPtrs g, int32_t *__restrict__ nodes, int32_t 
     else ts[t] = tt;
 }
 
+// embedding_module.average_topk (reference modules/embedding_module.py:232-233): mean over the 2B positive rows of
+// the sum of model 0's T-PPR weights; one workgroup, float64 accumulation
+__global__ __launch_bounds__(256) void k_avg_topk(const float *__restrict__ w, long long rows, int k, float *out)
+{
+    __shared__ double part[256];
+    double acc = 0.0;
+    for (long long q = threadIdx.x; q < rows * k; q += 256) acc += (double)w[q];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = rows > 0 ? (float)(part[0] / (double)rows) : 0.f;
+}
+
 bool same_batch(const zt_batch *a, const int64_t *key, int64_t B) { return a->eidx == key && a->B == B; }
 
 zt_pipeline::Slot *find_slot(zt_pipeline *p, const zt_batch *b, int *member)
@@ -116,7 +135,21 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
         const int c = (p->next_slot + q) % 3;
         if (p->slot[c].n == 0) { pick = c; break; }
     }
-    if (pick < 0) pick = p->next_slot;
+    const bool streaming = p->d.tppr != nullptr;
+    if (pick < 0) {
+        // every slot holds batches that have not been consumed: the caller left the order it announced.  A group that
+        // was only planned (or a pruning query, which carries no state) can be dropped; a streaming group whose update
+        // has been LAUNCHED cannot -- its edges are in the T-PPR state already and would be applied a second time.
+        for (int q = 0; q < 3; ++q) {
+            const int c = (p->next_slot + q) % 3;
+            if (!p->slot[c].launched || !streaming) { pick = c; break; }
+        }
+        if (pick < 0) {
+            set_error("zt_pipeline_step: batches must be presented in the order they were announced (three groups whose "
+                      "T-PPR update has been applied are still waiting to be consumed)");
+            return ZT_ERR_ARG;
+        }
+    }
     p->next_slot = (pick + 1) % 3;
     zt_pipeline::Slot &s = p->slot[pick];
     GroupPtrs g;
@@ -126,7 +159,6 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
         g.B[g.n] = b->B; g.off[g.n] = g.Btot; g.Btot += b->B; ++g.n;
     };
     add(first);
-    const bool streaming = p->d.tppr != nullptr;
     if (want > MAX_GROUP) want = MAX_GROUP;
     // Leave a follower in sight: the aggregation of a group's FIRST batch waits for the whole launch, so where the
     // view ahead ends (the end of a stream, or of a timed region) the last batches are queried one by one and the
@@ -141,6 +173,12 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
         add(b);
     }
     if (s.used) ZT_HIP(hipStreamWaitEvent(st, s.consumed, 0));
+    // the batches' tensors may have been produced on the caller's stream just before this call (the main stream is
+    // ordered behind it): the staging copy must not read them earlier
+    if (st != p->main_s) {
+        ZT_HIP(hipEventRecord(p->entry, p->main_s));
+        ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
+    }
     k_stage_group<<<(unsigned)((g.Btot + 255) / 256), 256, 0, st>>>(g, s.nodes, s.nodes_m, s.ts,
                                                                      reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1);
     ZT_LAUNCH_CHECK();
@@ -151,6 +189,7 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     s.od = reinterpret_cast<float *>(s.buf + 2 * per); s.ow = reinterpret_cast<float *>(s.buf + 3 * per);
     for (int j = 0; j < g.n; ++j) { s.key[j] = g.eidx[j]; s.B[j] = g.B[j]; }
     s.n = g.n; s.n_done = 0; s.Btot = g.Btot; s.token = 0; s.launched = false; s.used = true;
+    s.q_lo = 0; s.q_hi = 0;
     *out = &s;
     return ZT_OK;
 }
@@ -190,6 +229,7 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
     }
     ZT_HIP(hipEventRecord(s.ready, p->side));
     s.launched = true;
+    s.q_lo = row_lo; s.q_hi = row_hi;
     return ZT_OK;
 }
 
@@ -222,6 +262,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
     }
     ZT_HIP(hipStreamCreateWithFlags(&p->plan_s, hipStreamNonBlocking));
+    ZT_HIP(hipEventCreateWithFlags(&p->entry, hipEventDisableTiming | zt::sync_event_flags()));
     // a slot holds one batch of max_B edges, or a group of smaller ones up to what one T-PPR launch covers
     p->cap = desc->max_B > TPPR_MAX_LAUNCH ? desc->max_B : TPPR_MAX_LAUNCH;
     const size_t rows = (size_t)3 * p->cap, per = (size_t)desc->M * rows * desc->k;
@@ -252,11 +293,29 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
     (void)hipStreamDestroy(p->side); (void)hipStreamDestroy(p->main_s); (void)hipStreamDestroy(p->plan_s);
+    (void)hipEventDestroy(p->entry);
     delete p;
     return ZT_OK;
 }
 
 extern "C" void *zt_pipeline_main_stream(zt_pipeline *p) { return p ? (void *)p->main_s : nullptr; }
+
+extern "C" int zt_pipeline_outstanding(const zt_pipeline *p)
+{
+    // batches whose T-PPR query has been launched ahead and that have not been consumed by a step yet
+    if (!p) return 0;
+    int n = 0;
+    for (const auto &s : p->slot)
+        if (s.n > 0 && s.launched) n += s.n - s.n_done;
+    return n;
+}
+
+extern "C" int zt_pipeline_set_stats(zt_pipeline *p, float *avg_topk_dev)
+{
+    if (!p) return ZT_ERR_ARG;
+    p->avg_topk = avg_topk_dev;
+    return ZT_OK;
+}
 
 extern "C" int zt_pipeline_set_group(zt_pipeline *p, int32_t group)
 {
@@ -304,6 +363,10 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // (a batch nobody has queried ahead is queried ALONE: the aggregation waits for this launch, and a group would
     //  make it wait for the followers' updates as well; they form the next group, which runs beside this batch)
     if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, 1, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
+    // (pruning: a query made ahead covers the rows shard_of() derived for it; if this call asks for other rows --
+    //  the roundings differ when 3B is not divisible by the world size and the batch sizes change -- query again:
+    //  the strategy carries no state)
+    if (pruning && s->launched && (s->q_lo != row_lo || s->q_hi != row_hi)) s->launched = false;
     if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
     ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0));
     // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
@@ -356,6 +419,10 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         ZT_HIP(hipMemcpy2DAsync(p->sh_ow, w, ow + o2, pitch, w, d.M, hipMemcpyDeviceToDevice, p->main_s));
         on = p->sh_on; oe = p->sh_oe; od = p->sh_od; ow = p->sh_ow;
     }
+    if (p->avg_topk != nullptr && whole) {
+        k_avg_topk<<<1, 256, 0, p->main_s>>>(ow, 2 * B, d.k, p->avg_topk);
+        ZT_LAUNCH_CHECK();
+    }
     if (n_rows > 0) {
         rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                       od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
@@ -374,7 +441,8 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     p->gru_ready = true;
     if (d.proj_table != nullptr) {
         char *gw = reinterpret_cast<char *>(d.gru_ws);
-        rc = zt_project_memory(d.memory, d.num_nodes, d.D, d.F, d.T, &d.ew, 1, reinterpret_cast<const int32_t *>(gw + 256),
+        rc = zt_project_memory(d.memory, d.num_nodes, d.D, d.F, d.T, &d.ew, 1,
+                               reinterpret_cast<const int32_t *>(gw + zt_gru_rows_offset(d.D, msg_dim)),
                                reinterpret_cast<const int32_t *>(gw), 2 * B, d.proj_table, d.embed_ws, 3 * d.max_B, d.M, d.k,
                                p->main_s);
         if (rc != ZT_OK) return rc;

@@ -177,7 +177,8 @@ class GRUMemoryUpdater(nn.Module):
             return
         ws = self._workspace(max_rows, D)
         g = self.memory_updater
-        key = (ws.data_ptr(), max_rows) + tuple((t.data_ptr(), t._version) for t in (g.weight_ih, g.weight_hh))
+        # (the packed weights sit before the row list in the workspace: they survive a change of max_rows)
+        key = (ws.data_ptr(),) + tuple((t.data_ptr(), t._version) for t in (g.weight_ih, g.weight_hh))
         ready = key == getattr(self, "_ws_key", None)
         check(lib().zt_gru_update(ptr(memory.memory), ptr(memory.last_update), ptr(memory.messages),
                                   ptr(memory.timestamps), ptr(memory._flag_buf), C.c_int64(memory.n_nodes),
@@ -192,8 +193,10 @@ class GRUMemoryUpdater(nn.Module):
 
     def last_rows(self):
         """(rows int32[max_rows], count int32[1]) views of the ids the last update_device
-        call updated (layout of the zt_gru_update workspace: count at byte 0, rows at 256)."""
-        return self._ws[256:].view(torch.int32), self._ws[:4].view(torch.int32)
+        call updated (layout of the zt_gru_update workspace: count at byte 0, rows at zt_gru_rows_offset)."""
+        D = self.memory_updater.hidden_size
+        off = int(lib().zt_gru_rows_offset(C.c_int32(D), C.c_int32(self.message_dimension)))
+        return self._ws[off:].view(torch.int32), self._ws[:4].view(torch.int32)
 
     @torch.no_grad()
     def update_memory(self, memory, positives):                 # modules/memory_updater.py:29-43

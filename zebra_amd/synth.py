@@ -10,32 +10,38 @@ import numpy as np
 
 
 def _power_law_sampler(n, s, rng, perm_seed=None):
-    """Return draw(m) -> int64[m] ranks in [0, n) with p(r) ~ (r+1)^-s."""
+    """Return draw(m) -> int64[m] ids in [0, n) whose popularity RANK r has p(r) ~ (r+1)^-s.
+    perm_seed=None: id == rank (the hot ids are the low ones, contiguous in every per-node table);
+    otherwise ids are a seeded random permutation of the ranks, so hot rows are scattered."""
     p = np.arange(1, n + 1, dtype=np.float64) ** (-s)
     cdf = np.cumsum(p)
     cdf /= cdf[-1]
+    perm = None if perm_seed is None else np.random.RandomState(perm_seed).permutation(n)
 
     def draw(m):
-        return np.minimum(np.searchsorted(cdf, rng.random_sample(m)), n - 1)
+        r = np.minimum(np.searchsorted(cdf, rng.random_sample(m)), n - 1)
+        return r if perm is None else perm[r]
     return draw
 
 
 def power_law_stream(n_nodes, n_edges, bipartite=None, s=0.9, seed=2020, mean_dt=30.0,
-                     t0=0.0, first_eidx=1):
+                     t0=0.0, first_eidx=1, perm_seed=None):
     """Bounded power-law temporal stream.
 
     n_nodes  : number of real nodes (ids 1..n_nodes); ignored when bipartite.
     bipartite: (U, I) -> sources in 1..U, destinations in U+1..U+I.
     Returns src int32[E], dst int32[E], ts float64[E] (strictly increasing),
     eidx int64[E] = first_eidx..first_eidx+E-1.
+    perm_seed: shuffle which node id carries which popularity rank (bench.py does; None keeps id == rank,
+    which the committed fixtures and tests were generated with).
     """
     rng = np.random.RandomState(seed)
     if bipartite is not None:
         U, I = bipartite
-        src = 1 + _power_law_sampler(U, s, rng)(n_edges)
-        dst = 1 + U + _power_law_sampler(I, s, rng)(n_edges)
+        src = 1 + _power_law_sampler(U, s, rng, perm_seed)(n_edges)
+        dst = 1 + U + _power_law_sampler(I, s, rng, None if perm_seed is None else perm_seed + 1)(n_edges)
     else:
-        draw = _power_law_sampler(n_nodes, s, rng)
+        draw = _power_law_sampler(n_nodes, s, rng, perm_seed)
         src = 1 + draw(n_edges)
         dst = 1 + draw(n_edges)
     ts = t0 + np.cumsum(rng.exponential(mean_dt, n_edges))

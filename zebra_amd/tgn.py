@@ -6,6 +6,7 @@ of embedding, message store and memory update.  ``step_device`` is the same
 eval-mode protocol with device-resident inputs and no host synchronisation:
 it is what bench.py times.
 """
+import collections
 import ctypes as C
 import logging
 
@@ -114,7 +115,8 @@ class TGN(torch.nn.Module):
         self._pipe = None
         self._pipe_sig = None
         self._pipe_keep = None
-        self._batch_cache = {}
+        self._pipe_stats = None
+        self._batch_cache = collections.OrderedDict()
         self.main_stream = None
         if not on:
             return
@@ -192,14 +194,16 @@ class TGN(torch.nn.Module):
         cache = self._batch_cache
         key = id(batch[4])
         hit = cache.get(key)
-        if hit is not None and hit[0] is batch[4]:
+        if hit is not None and hit[0][4] is batch[4]:
             return hit[1]
         b = _capi.Batch()
         b.src, b.dst, b.neg, b.ts, b.eidx = [t.data_ptr() for t in batch]
         b.B = batch[0].numel()
-        if len(cache) > 16:
-            cache.clear()
-        cache[key] = (batch[4], b)
+        # ALL five tensors stay referenced while a slot may still read them on the plan / T-PPR streams (a batch is
+        # staged at most 3 * MAX_GROUP steps before its own step; the oldest entries go first)
+        while len(cache) >= 64:
+            cache.popitem(last=False)
+        cache[key] = (tuple(batch), b)
         return b
 
     def _pipe_step(self, batch, prefetch, plan, rows=None, positions=None, ahead=None):
@@ -220,15 +224,34 @@ class TGN(torch.nn.Module):
         """ctypes array of zt_batch for the batches that follow; remembered by the identity of its members."""
         key = tuple(id(b[4]) for b in ahead)
         hit = self._batch_cache.get(key)
-        if hit is not None and all(x is b[4] for x, b in zip(hit[0], ahead)):
+        if hit is not None and all(x[4] is b[4] for x, b in zip(hit[0], ahead)):
             return hit[1]
         arr = (_capi.Batch * max(1, len(ahead)))()
         for q, b in enumerate(ahead):
             arr[q] = self._batch_struct(b)
-        if len(self._batch_cache) > 64:
-            self._batch_cache.clear()
-        self._batch_cache[key] = ([b[4] for b in ahead], arr)
+        while len(self._batch_cache) >= 64:
+            self._batch_cache.popitem(last=False)
+        self._batch_cache[key] = ([tuple(b) for b in ahead], arr)
         return arr
+
+    def _pipe_want_stats(self, on):
+        """average_topk from the slot's weights (zt_pipeline_set_stats), only while somebody asks for it"""
+        if bool(on) == (self._pipe_stats is not None):
+            return
+        em = self.embedding_module
+        if on:
+            self._pipe_stats = torch.zeros(1, dtype=torch.float32, device=self.device)
+            check(lib().zt_pipeline_set_stats(self._pipe, ptr(self._pipe_stats)), "zt_pipeline_set_stats")
+            em._avg_topk_t = self._pipe_stats
+        else:
+            check(lib().zt_pipeline_set_stats(self._pipe, None), "zt_pipeline_set_stats")
+            self._pipe_stats = None
+
+    def pipeline_outstanding(self):
+        """Batches whose T-PPR update ran ahead of their step (0 without a pipeline)."""
+        if getattr(self, "_pipe", None) is None:
+            return 0
+        return int(lib().zt_pipeline_outstanding(self._pipe))
 
     def _pipe_step_main(self, batch, ahead, rows, positions):
         self._pipe_refresh()
@@ -258,7 +281,8 @@ class TGN(torch.nn.Module):
             self.test_mode = True
         em = self.embedding_module
         B = src_d.numel()
-        if getattr(self, "_pipe", None) is not None and not stats:
+        if getattr(self, "_pipe", None) is not None:
+            self._pipe_want_stats(stats and rows is None)
             emb = self._pipe_step((src_d, dst_d, neg_d, ts_d, eidx_d), prefetch, plan, rows, positions, ahead)
         else:
             nodes_d = torch.cat([src_d, dst_d, neg_d])
@@ -308,6 +332,10 @@ class TGN(torch.nn.Module):
             neg_d = torch.as_tensor(np.ascontiguousarray(negative_nodes, np.int32), device=d)
             node_embedding = self.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=True, stats=True)
         else:
+            if self.pipeline_outstanding():
+                raise RuntimeError("the step pipeline has queried %d batches ahead: their T-PPR updates are applied "
+                                   "already; step them (or rebuild the pipeline) before a training batch"
+                                   % self.pipeline_outstanding())
             self.test_mode = False
             nodes = np.concatenate([source_nodes, destination_nodes, negative_nodes])
             timestamps = np.concatenate([edge_times, edge_times, edge_times])
