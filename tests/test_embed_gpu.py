@@ -272,10 +272,10 @@ def test_pipeline_refuses_to_drop_an_applied_group():
     with torch.cuda.stream(tgn.main_stream):
         tgn.step_device(*batches[0], ahead=batches[1:3])          # 1 is queried ahead, 2 planned
         assert tgn.pipeline_outstanding() == 1
-        tgn.step_device(*batches[5], ahead=batches[6:8])          # out of order: 5 queried now, 6 ahead -> 1, 6 launched
+        # out of order: 5 is queried now (the free slot), 6 ahead (the slot of the merely PLANNED batch 2 may be
+        # dropped), and then nothing is left for 7: the slots hold 5, 1 and 6, all applied to the state already
         with pytest.raises(ValueError):
-            for b in (8, 9, 10):                                  # sooner or later no slot is left that may be dropped
-                tgn.step_device(*batches[b], ahead=batches[b + 1: b + 2])
+            tgn.step_device(*batches[5], ahead=batches[6:8])
     torch.cuda.synchronize()
     tgn.enable_pipeline(False)
 
