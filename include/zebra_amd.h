@@ -192,6 +192,18 @@ int zt_pruned_topk(const zt_csr *c, const int32_t *q_nodes_dev,
                    int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                    float *out_dt_dev, float *out_w_dev, int32_t *status_dev,
                    void *stream);
+/* GraphDiffusionEmbedding.pruning_topk (modules/embedding_module.py:280-297):
+ * the same query for every (alpha, beta) model of the ensemble in ONE walk of
+ * the adjacency -- which states a query reaches depends on (node, time) only,
+ * the models differ in the weights they carry along.  alpha_host / beta_host:
+ * n_models host doubles; outputs are [n_models][nq][k], model-major, and follow
+ * the same "empty rows stay untouched" rule. */
+int zt_pruned_topk_multi(const zt_csr *c, const int32_t *q_nodes_dev,
+                         const double *q_ts_dev, int64_t nq, int32_t width,
+                         int32_t depth, int32_t n_models, const double *alpha_host,
+                         const double *beta_host, int32_t k, int32_t *out_nodes_dev,
+                         int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
+                         int32_t *status_dev, void *stream);
 
 /* ------------------------------------------------------------------------ */
 /* Gather + TimeEncode + transform + weighted sum                            */

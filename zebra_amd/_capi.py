@@ -24,7 +24,7 @@ SYMBOLS = [
     "zt_last_error", "zt_version", "zt_profile_enable", "zt_profile_reset", "zt_profile_read", "zt_stream_create_masked", "zt_stream_destroy",
     "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
-    "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk",
+    "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
     "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
 ]

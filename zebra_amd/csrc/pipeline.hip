@@ -220,12 +220,9 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
             ZT_HIP(hipMemsetAsync(s.od, 0, per * 4, p->side));
             ZT_HIP(hipMemsetAsync(s.ow, 0, per * 4, p->side));
         }
-        for (int m = 0; m < d.M; ++m) {
-            const size_t o = (size_t)m * n * d.k;
-            int rc = zt_pruned_topk(d.csr, s.nodes_m + row_lo, s.ts + row_lo, n, d.width, d.depth, d.alpha[m], d.beta[m], d.k,
-                                    s.on + o, s.oe + o, s.od + o, s.ow + o, d.status, p->side);
-            if (rc != ZT_OK) return rc;
-        }
+        int rc = zt_pruned_topk_multi(d.csr, s.nodes_m + row_lo, s.ts + row_lo, n, d.width, d.depth, d.M, d.alpha, d.beta, d.k,
+                                      s.on, s.oe, s.od, s.ow, d.status, p->side);      // every model in one walk
+        if (rc != ZT_OK) return rc;
     }
     ZT_HIP(hipEventRecord(s.ready, p->side));
     s.launched = true;

@@ -395,10 +395,8 @@ class GraphDiffusionEmbedding(nn.Module):
         oe = torch.zeros_like(on)
         od = torch.zeros((self.n_tppr, n, self.k), dtype=torch.float32, device=self.device)
         ow = torch.zeros_like(od)
-        for i, alpha in enumerate(self.alpha_list):
-            self.neighbor_finder.pruned_topk_device(nodes_d, ts_d, self.width, self.depth, float(alpha),
-                                                    float(self.beta_list[i]), self.k, on[i], oe[i], od[i], ow[i],
-                                                    check_status=check_status)
+        self.neighbor_finder.pruned_topk_multi_device(nodes_d, ts_d, self.width, self.depth, self.alpha_list,
+                                                      self.beta_list, self.k, on, oe, od, ow, check_status=check_status)
         return on, oe, od, ow
 
     @property

@@ -361,6 +361,20 @@ class NeighborFinder:
                 self._status.zero_()
                 raise IndexError("get_pruned_topk: node id out of range (status %d)" % st)
 
+    def pruned_topk_multi_device(self, nodes_d, ts_d, width, depth, alphas, betas, k, on, oe, od, ow, check_status=True):
+        """All (alpha, beta) models of the ensemble in one walk (zt_pruned_topk_multi); on/oe/od/ow are [M, n, k]."""
+        M = len(alphas)
+        a = (C.c_double * M)(*[float(x) for x in alphas])
+        b = (C.c_double * M)(*[float(x) for x in betas])
+        check(lib().zt_pruned_topk_multi(self._h, ptr(nodes_d), ptr(ts_d), C.c_int64(nodes_d.numel()), C.c_int32(width),
+                                         C.c_int32(depth), C.c_int32(M), a, b, C.c_int32(k), ptr(on), ptr(oe), ptr(od),
+                                         ptr(ow), ptr(self._status), stream_ptr()), "zt_pruned_topk_multi")
+        if check_status:
+            st = int(self._status.item())
+            if st != 0:
+                self._status.zero_()
+                raise IndexError("get_pruned_topk: node id out of range (status %d)" % st)
+
     def get_pruned_topk(self, source_nodes, timestamps, width, depth, alpha, beta, k, node_list, edge_idxs_list,
                         delta_time_list, weight_list):                        # utils/util.py:185-276
         """Writes into the four caller-owned [N, k] arrays in place, returns None."""
