@@ -673,6 +673,296 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_fc1_agg_d100(
 }
 
 // ---------------------------------------------------------------------------
+// k_fc1_agg_reg<KK>: the same computation for the shapes the headline configurations run (D = T = 100, F <= 4
+// so that F + T <= 104, k in {20, 40}), built around the matrix pipe instead of around a workgroup's LDS tile:
+//   * PERSISTENT waves, each one on its own: a wave owns 80 gathered rows (4 or 2 whole query rows) x all 7 N-tiles
+//     of the hidden layer; no workgroup barrier anywhere, nothing but 1.3 KB of per-row scalars in LDS;
+//   * fc1's [ef | time] weights stay in REGISTERS for the whole launch (7 N-tiles x 26 k-steps = 182 per lane, one
+//     wave per SIMD: 512 registers) -- the MFMA's B operand never touches memory again;
+//   * the A operand is never staged either: MFMA 16x16x4 wants A[row = lane & 15][k = 4 s + (lane >> 4)] from each
+//     lane, which is cos(dt[row] * w_time[k]) -- the lane evaluates exactly that (one cosine per 7 MFMAs) while the
+//     matrix pipe works on the previous step (an MFMA holds the SIMD's vector issue for 8 of its 32 cycles);
+//   * the projected rows P[nbr] (fc1 is linear: W_m memory[nbr], see k_fc1_agg) are added in the epilogue of each
+//     16-row M-tile, their loads issued when the M-tile starts;
+//   * bias + ReLU + w / sum(w) and the reduction over the k neighbours of a query row happen in registers: k is a
+//     multiple of 4, so the 4 rows a lane holds of an M-tile belong to one query row; partial sums per (query
+//     row, N-tile) are combined across the four 16-lane groups with two cross-lane adds at the end of the tile.
+// Time encoding: every argument goes through the float64 reduction (time_cosf_rev): arguments beyond 4e6 (old
+// neighbours: dt is seconds) are everyday data at stream scale, and the seven float64 instructions hide behind the
+// matrix pipe like everything else.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float time_cosf_rev(float x)
+{
+    // cos(x) for |x| up to 3e8 (dt is seconds: 10 years) in SIX float32 instructions -- on this chip an f32 MFMA and
+    // vector instructions of the same SIMD do not overlap, so every vector instruction beside the MFMAs costs its
+    // full issue time (float64 ones twice that).  Revolutions x / 2pi with 1 / 2pi = c1 + c2 (two floats): the
+    // product x c1 and its rounding error (one FMA) are carried separately, so the FRACTION of the large term is
+    // exact; x c2 < 2 needs no such care.  rev = fract(x c1) + (err1 + x c2), then v_cos_f32 (argument in
+    // revolutions).  max |error| 9e-7 over |x| <= 3e8 (mean 7e-8): tools/exp/cos_rev_check.py.
+    const float c1 = 0x1.45f306p-3f, c2 = 0x1.b9391p-28f;
+    const float p1 = x * c1, e1 = fmaf(x, c1, -p1);
+    return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(p1) + fmaf(x, c2, e1));
+}
+
+__device__ unsigned long long g_regclk[4 * 1024];   // diagnostic (DBG builds): per wave: shader cycles, wall start, wall end (100 MHz), tiles
+constexpr int REG_NS = 26;       // MFMA k-steps: F + T <= 104
+constexpr int REG_NB = 7;        // N-tiles of the hidden layer (D = 100 -> 112 columns)
+
+template <int KK, int DBG = 0>     // DBG: diagnostic builds (ZT_AGG_DBG, wrong results): 1 no cosine, 2 bare epilogue, 4 no projected rows
+__global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
+    const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
+    long long num_edges, int F, long long N, int M, const int *__restrict__ nbr, const int *__restrict__ eix,
+    const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ W1t, int K2p,
+    const float *__restrict__ b1, float *__restrict__ H, float *__restrict__ S, int *status)
+{
+    constexpr int D = 100, T = 100, DP = 112, ROWS = 80, RQ = ROWS / KK;
+    static_assert(KK % 4 == 0 && ROWS % KK == 0, "groups of 4 rows must not straddle query rows");
+    __shared__ int s_nb[AGG_WAVES][ROWS];
+    __shared__ __attribute__((aligned(16))) float s_dt[AGG_WAVES][ROWS];
+    __shared__ __attribute__((aligned(16))) float s_w[AGG_WAVES][ROWS];
+    __shared__ float s_sum[AGG_WAVES][4];
+    __shared__ __attribute__((aligned(16))) float s_ef[AGG_WAVES][ROWS * 4];      // edge-feature columns k < F <= 4 of every row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    int *nb_s = s_nb[wave];
+    float *dt_s = s_dt[wave], *w_s = s_w[wave], *sum_s = s_sum[wave], *ef_s = s_ef[wave];
+
+    // ---- once per launch: this lane's slice of the weights, the time frequencies and the biases ----
+    // (the [112][K2p] matrix comes in through LDS, coalesced; 182 strided loads per lane straight from memory took 35 us)
+    extern __shared__ __attribute__((aligned(16))) float s_wt[];       // [DP][K2p], dead after this block
+    for (int i = threadIdx.x; i < DP * K2p / 4; i += AGG_THREADS)
+        reinterpret_cast<f32x4 *>(s_wt)[i] = reinterpret_cast<const f32x4 *>(W1t)[i];
+    __syncthreads();
+    float Breg[REG_NB][REG_NS];
+#pragma unroll
+    for (int b = 0; b < REG_NB; ++b)
+#pragma unroll
+        for (int st = 0; st < REG_NS; ++st) {
+            // defined by an accumulator-register write: the value then LIVES in the accumulator half of the register
+            // file (an MFMA takes its B operand from either half); left to itself the allocator keeps all 182 in
+            // vector registers, runs out of them and spills
+            const float wv = s_wt[(16 * b + r16) * K2p + 4 * st + g4];
+            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Breg[b][st]) : "v"(wv));
+        }
+    float freq[REG_NS];
+#pragma unroll
+    for (int st = 0; st < REG_NS; ++st) {
+        const int kc = 4 * st + g4 - F;
+        freq[st] = (kc >= 0 && kc < T) ? time_w[kc] : 0.f;
+    }
+    float bias[REG_NB];
+#pragma unroll
+    for (int b = 0; b < REG_NB; ++b) bias[b] = (16 * b + r16) < D ? b1[16 * b + r16] : 0.f;
+
+    const unsigned long long clk0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull, wall0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const long long tpm = (N + RQ - 1) / RQ;                           // tiles per model
+    const long long n_tiles = tpm * M;
+    const long long stride = (long long)gridDim.x * AGG_WAVES;
+    long long tile = (long long)blockIdx.x * AGG_WAVES + wave;
+
+    // per-row scalars of a tile: lane l holds rows l and (l < 16) 64 + l; fetched one tile ahead
+    int pf_nb[2] = {0, 0}, pf_ei[2] = {0, 0};
+    float pf_dt[2] = {0.f, 0.f}, pf_w[2] = {0.f, 0.f};
+    auto fetch = [&](long long t) {
+        const long long m = t / tpm, q0 = (t - m * tpm) * RQ;
+        const int rows = (int)((N - q0) < RQ ? (N - q0) : RQ) * KK;
+        const size_t mb = ((size_t)m * N + q0) * KK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 64 + lane;
+            const bool in = row < rows && (h == 0 || lane < ROWS - 64);
+            pf_nb[h] = in ? nbr[mb + row] : 0;
+            pf_ei[h] = in ? eix[mb + row] : 0;
+            pf_dt[h] = in ? dt[mb + row] : 0.f;
+            pf_w[h] = in ? w[mb + row] : 0.f;
+        }
+    };
+    // ... and, once those edge ids are there, the rows' edge features (second stage, half a tile later)
+    float pf_ef[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    auto fetch_ef = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ei = pf_ei[h];
+            const bool ok = ei >= 0 && ei < num_edges && (h == 0 || lane < ROWS - 64);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pf_ef[h][c] = (ok && c < F) ? efeat[(size_t)ei * F + c] : 0.f;
+        }
+    };
+    if (tile < n_tiles) { fetch(tile); fetch_ef(); }
+
+#pragma nounroll
+    for (; tile < n_tiles; tile += stride) {
+        const long long m = tile / tpm, q0 = (tile - m * tpm) * RQ;
+        const int nq = (int)((N - q0) < RQ ? (N - q0) : RQ);
+        // ---- this tile's scalars: registers -> LDS (the previous tile is done with the buffer) ----
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 64 + lane;
+            if (h == 0 || lane < ROWS - 64) {
+                int nb = pf_nb[h], ei = pf_ei[h];
+                if (nb < 0 || nb >= num_nodes || ei < 0 || ei >= num_edges) { atomicExch(status, ZT_ERR_RANGE); nb = 0; ei = 0; }
+                nb_s[row] = nb; dt_s[row] = pf_dt[h]; w_s[row] = pf_w[h];
+                *reinterpret_cast<f32x4 *>(ef_s + 4 * row) = f32x4{pf_ef[h][0], pf_ef[h][1], pf_ef[h][2], pf_ef[h][3]};
+            }
+        }
+        wave_sync();
+        if (lane < RQ) {                                               // sum(w) in entry order, like torch.sum(dim=1)
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < KK; ++j) sm += w_s[lane * KK + j];
+            sum_s[lane] = sm;
+            if (lane < nq) S[(size_t)m * N + q0 + lane] = (sm == 0.f) ? 0.f : 1.f;
+        }
+        wave_sync();
+        // w / sum(w), 0 where the sum is 0 (:267-270): once per row here, not once per use in the M-tiles
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = h * 64 + lane;
+            if (h == 0 || lane < ROWS - 64) {
+                const float qs = sum_s[row / KK];
+                w_s[row] = (qs == 0.f) ? 0.f : pf_w[h] / qs;
+            }
+        }
+        wave_sync();
+        const bool has_next = tile + stride < n_tiles;
+        if (has_next) fetch(tile + stride);                             // in flight while this tile computes
+
+        float Hloc[RQ][REG_NB];
+#pragma unroll
+        for (int q = 0; q < RQ; ++q)
+#pragma unroll
+            for (int b = 0; b < REG_NB; ++b) Hloc[q][b] = 0.f;
+
+        // Software pipeline over the five M-tiles (16 rows each): while the matrix pipe runs M-tile a, the vector
+        // unit evaluates the NEXT k-step's cosine and, during the first seven steps, the epilogue of M-tile a - 1 (one
+        // N-tile per step) from a copy of its accumulators taken at the boundary; the projected rows of M-tile a are
+        // requested at step 7, once that epilogue is through with the previous ones (one register set), and used
+        // twenty steps later.  A sixth round drains the last epilogue.  sched_barrier between steps keeps the compiler
+        // from hoisting five M-tiles' worth of loads and cosines to the top.  Register budget: accumulator half 182
+        // weights + 28 accumulators; vector half ~180.
+        f32x4 acc[REG_NB];
+        float accv[REG_NB][4], Pv[2][REG_NB][4], wn_cur[4], wn_prv[4];
+        // the projected rows of M-tile x into register set x & 1: requested TWO M-tiles ahead of their epilogue (a wave
+        // has its SIMD to itself: nothing else hides a 2-4 us gather from a multi-gigabyte table)
+        auto load_P = [&](int x) {
+            const int4 nb4 = *reinterpret_cast<const int4 *>(nb_s + x * 16 + 4 * g4);         // epilogue rows 4 g4 + j
+            const float *p0 = P + (size_t)nb4.x * DP + r16, *p1 = P + (size_t)nb4.y * DP + r16,
+                        *p2 = P + (size_t)nb4.z * DP + r16, *p3 = P + (size_t)nb4.w * DP + r16;
+#pragma unroll
+            for (int b = 0; b < REG_NB; ++b) {
+                Pv[x & 1][b][0] = p0[16 * b]; Pv[x & 1][b][1] = p1[16 * b]; Pv[x & 1][b][2] = p2[16 * b]; Pv[x & 1][b][3] = p3[16 * b];
+            }
+        };
+        if (!(DBG & 4)) { load_P(0); load_P(1); }
+#pragma unroll
+        for (int a = 0; a <= 5; ++a) {
+            float dta = 0.f, A_next[2] = {0.f, 0.f};
+            if (a > 0) {
+#pragma unroll
+                for (int b = 0; b < REG_NB; ++b)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accv[b][j] = acc[b][j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wn_prv[j] = wn_cur[j];
+            }
+            if (a < 5) {
+                // ---- M-tile a: rows 16 a .. 16 a + 15 ----
+                dta = dt_s[a * 16 + r16];                              // A operand: row r16 of the M-tile
+                const float ef = ef_s[4 * (a * 16 + r16) + (g4 & 3)];  // k = g4 < F: an edge-feature column
+                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(w_s + a * 16 + 4 * g4);   // already w / sum(w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wn_cur[j] = w4[j];
+#pragma unroll
+                for (int b = 0; b < REG_NB; ++b) acc[b] = f32x4{bias[b], bias[b], bias[b], bias[b]};     // C operand of the first MFMA
+                A_next[0] = (DBG & 1) ? dta * freq[0] : time_cosf_rev(dta * freq[0]);
+                A_next[1] = (DBG & 1) ? dta * freq[1] : time_cosf_rev(dta * freq[1]);
+                if (g4 < F) A_next[0] = ef;
+                if (a == 2 && has_next) fetch_ef();                    // the next tile's edge ids have arrived by now
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // query rows M-tile a - 1 touches (constants once unrolled)
+            const int ap = a > 0 ? a - 1 : 0;
+            const int q_lo = (16 * ap) / KK, q_hi = (16 * ap + 15) / KK;
+            // Two k-steps at a time: 14 MFMAs, the cosines of the NEXT two steps (two independent chains: the f32 MFMA
+            // keeps vector instructions off the SIMD while it runs, so what counts is that they issue back to back
+            // once they do run) and, in the first rounds, two slices of the previous M-tile's epilogue.
+#pragma unroll
+            for (int st0 = 0; st0 < REG_NS; st0 += 2) {
+                if (a == 5 && st0 >= REG_NB) break;
+                const float A_cur[2] = {A_next[0], A_next[1]};
+                if (a < 5) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (st0 + 2 + u < REG_NS)
+                            A_next[u] = (DBG & 1) ? dta * freq[st0 + 2 + u] : time_cosf_rev(dta * freq[st0 + 2 + u]);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int b = 0; b < REG_NB; ++b)
+                            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_cur[u], Breg[b][st0 + u], acc[b], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int st = st0 + u;
+                    if (!(a > 0 && st < REG_NB)) continue;
+                    // epilogue of M-tile a - 1, N-tile st: + projected row (the bias went in as the MFMAs' C operand),
+                    // ReLU, x w / sum(w); the lane's 4 rows belong to ONE query row
+                    const int b = st;
+                    float part = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = accv[b][j] + ((DBG & 2) ? 0.f : Pv[ap & 1][b][j]);
+                        v = v > 0.f ? v : 0.f;
+                        part += (DBG & 2) ? v : v * wn_prv[j];
+                    }
+                    if (DBG & 2) {
+                        Hloc[q_lo][b] += part;
+                    } else {
+                        // The four 16-lane groups hold rows 4 g .. 4 g + 3 of the M-tile.  Every lane gets all four partial
+                        // sums (two half-wave swaps + two row swaps, no LDS) and adds them to their query rows in ROW order:
+                        // a query row's k / 4 groups are then always summed first to last, wherever in a tile the row falls
+                        // -- a row's value must not depend on which shard or tile it is computed in.
+                        const int pi = __float_as_int(part);
+                        const auto h = __builtin_amdgcn_permlane32_swap(pi, pi, false, false);       // [0]: groups 0,1,0,1   [1]: 2,3,2,3
+                        const auto lo = __builtin_amdgcn_permlane16_swap(h[0], h[0], false, false);  // [0]: group 0 everywhere, [1]: group 1
+                        const auto hi = __builtin_amdgcn_permlane16_swap(h[1], h[1], false, false);  // [0]: group 2, [1]: group 3
+                        const float pg[4] = {__int_as_float(lo[0]), __int_as_float(lo[1]), __int_as_float(hi[0]), __int_as_float(hi[1])};
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int q = (16 * ap + 4 * g) / KK;                   // constant once unrolled
+                            if (q < RQ) Hloc[q][b] += pg[g];
+                        }
+                    }
+                    // (an empty side-effecting statement: it pins this arithmetic to THIS round.  Nothing else orders pure
+                    //  vector work against the scheduling barriers, and instruction selection otherwise sinks all five
+                    //  epilogues to the end of the tile, where their inputs -- 5 x 60 registers -- are still alive)
+                    asm volatile("" : "+v"(Hloc[q_lo][b]));
+                    if (q_hi != q_lo && q_hi < RQ) asm volatile("" : "+v"(Hloc[q_hi][b]));
+                }
+                if (a >= 1 && a <= 3 && st0 == REG_NB + 1 && !(DBG & 4)) load_P(a + 1);   // its register set has just been released
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- every lane holds every sum: group g writes query row g ----
+#pragma unroll
+        for (int q = 0; q < RQ; ++q) {
+            if (g4 == (q & 3) && q < nq) {
+                float *hrow = H + ((size_t)m * N + q0 + q) * D;
+#pragma unroll
+                for (int b = 0; b < REG_NB; ++b)
+                    if (16 * b + r16 < D) hrow[16 * b + r16] = Hloc[q][b];
+            }
+        }
+        wave_sync();                                                   // all reads of the scalar buffer are done
+    }
+    if (DBG && lane == 0 && blockIdx.x * AGG_WAVES + wave < 1024) {
+        unsigned long long *o = g_regclk + 4 * (blockIdx.x * AGG_WAVES + wave);
+        o[0] = __builtin_amdgcn_s_memtime() - clk0; o[1] = wall0; o[2] = __builtin_amdgcn_s_memrealtime();
+        o[3] = __builtin_amdgcn_s_getreg(((5 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+    }
+}
+
+// ---------------------------------------------------------------------------
 // out[n] = [ fc2s(relu(fc1s(memory[nodes[n]]))) | fc2(H_0[n]) + b2*S_0[n] | ... ]
 // Three small D x D layers on f32 MFMA.  One workgroup per 32 rows; the input
 // rows sit in LDS, weights ([Dp][Dp], zero padded) stream from L2 as b128
@@ -936,6 +1226,13 @@ extern "C" int zt_debug_agg(unsigned long long *host, int reset)
 }
 #endif
 
+extern "C" int zt_debug_regclk(unsigned long long *host)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_regclk), sizeof(unsigned long long) * 4 * 1024));
+    return ZT_OK;
+}
+
 extern "C" int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
 {
     EmbedPlan p;
@@ -989,6 +1286,31 @@ extern "C" int zt_project_memory(const float *memory_dev, int64_t num_nodes, int
         memory_dev, num_nodes, D, reinterpret_cast<const float *>(ws + p.off_wm), rows_dev, count_dev, n, table_dev);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
+}
+
+// CUs the stream may use (CU-masked streams: the size of the mask), remembered per stream
+static int stream_cu_count(hipStream_t s)
+{
+    static hipStream_t last_s = nullptr;
+    static int last_n = 0, total = 0;
+    if (total == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        total = prop.multiProcessorCount;
+    }
+    if (s == last_s && last_n > 0) return last_n;
+    uint32_t mask[32] = {0};
+    int c = total;
+    if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
+        int n = 0;
+        for (int q = 0; q < 32; ++q) n += __builtin_popcount(mask[q]);
+        if (n > 0 && n < total) c = n;
+    } else {
+        (void)hipGetLastError();
+    }
+    last_s = s; last_n = c;
+    return c;
 }
 
 extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
@@ -1048,8 +1370,40 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
             attr_fast[ki] = lds;
         }
     }
+    // register-resident kernel: D = T = 100, F + T <= 104, k in {20, 40} (ZT_AGG_REG=0: off)
+    static const bool reg_ok = !(getenv("ZT_AGG_REG") && atoi(getenv("ZT_AGG_REG")) == 0);
+    const bool regk = reg_ok && tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p >= 4 * REG_NS &&
+                      !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
     ZT_PROF_BEGIN(s, P_FC1_AGG);
-    if (d100) {
+    if (regk) {
+        const long long rq = 80 / k, tiles = ((N + rq - 1) / rq) * M;
+        long long wgs = (tiles + AGG_WAVES - 1) / AGG_WAVES;
+        const int cus = stream_cu_count(s);
+        if (wgs > cus) wgs = cus;                                      // persistent: one workgroup (4 waves) per CU
+        const size_t reg_lds = (size_t)112 * p.K2p * 4;                 // the weight matrix, staged once per workgroup
+        static bool reg_attr = false;
+        if (!reg_attr) {
+            const void *fns[] = {reinterpret_cast<const void *>(k_fc1_agg_reg<20>), reinterpret_cast<const void *>(k_fc1_agg_reg<40>),
+                                 reinterpret_cast<const void *>(k_fc1_agg_reg<20, 1>), reinterpret_cast<const void *>(k_fc1_agg_reg<20, 2>),
+                                 reinterpret_cast<const void *>(k_fc1_agg_reg<20, 6>), reinterpret_cast<const void *>(k_fc1_agg_reg<20, 7>)};
+            for (const void *fn : fns) ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            reg_attr = true;
+        }
+        static const int dbg = getenv("ZT_AGG_DBG") ? atoi(getenv("ZT_AGG_DBG")) : 0;       // diagnostic (wrong results)
+#define ZT_REG_DBG(DB) k_fc1_agg_reg<20, DB><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, \
+            num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
+        if (k == 20 && dbg == 1) ZT_REG_DBG(1);
+        else if (k == 20 && dbg == 2) ZT_REG_DBG(2);
+        else if (k == 20 && dbg == 6) ZT_REG_DBG(6);
+        else if (k == 20 && dbg == 7) ZT_REG_DBG(7);
+#undef ZT_REG_DBG
+        else if (k == 20)
+            k_fc1_agg_reg<20><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev);
+        else
+            k_fc1_agg_reg<40><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev);
+    } else if (d100) {
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
 #define ZT_D100(KK) k_fc1_agg_d100<KK><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes,     \
             num_edges, F, N, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
