@@ -179,6 +179,9 @@ struct zt_tppr {
     int *pflag;      // edge whose "reads done" flag must be seen first, or -1
     int *nxt;        // number of later edges of the launch touching the access' node (chain still ahead)
     unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
+    unsigned *cdone; // [M][MAX_CHUNK] the same for the CHAIN's reads of a chain-owned edge (hub + partner row)
+    u64 *hubver;     // [M][MAX_CHAINS][CH_MAX + 1][rg]: version t of a chain's hub row = the row before chain position t
+                     // (dictionary order, tagged with the launch epoch), or nullptr (k > 31: no chains)
     // hub chains of the launch
     int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
     int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts
@@ -187,6 +190,7 @@ struct zt_tppr {
     int *chain_len;    // [MAX_CHAINS]
     int *chain_edges;  // [MAX_CHAINS][CH_MAX] edges owned by the chain, ascending
     int *owner_of;     // [MAX_CHUNK] chain owning the edge, or -1
+    int *pos_of;       // [MAX_CHUNK] its position in that chain's edge list
     // control words (device): [0] cursor, [1] queue head, [2] status, [3] hot candidates, [4] chains,
     // [13] timeout reports, [16..] the reports (see note_timeout)
     int *ctl;
@@ -203,7 +207,7 @@ struct zt_tppr {
     // the next call can run on another stream while k_stream still reads the previous call's set.
     struct PlanSet {
         int *cnt, *off, *slot, *list, *wo, *pflag, *nxt, *chain_of, *hot_node, *hot_cnt, *chain_node, *chain_len,
-            *chain_edges, *owner_of, *ctl;
+            *chain_edges, *owner_of, *pos_of, *ctl;
         hipEvent_t planned, consumed;      // prepass finished / k_stream finished with the set
         bool used;                         // `consumed` has been recorded at least once
         // what the set was planned for (valid == a zt_tppr_plan result not consumed yet)
@@ -398,7 +402,7 @@ __global__ void k_own(const int *__restrict__ nodes, long long role_stride, int 
 }
 
 // K2d: one wavefront per chain sorts its edges ascending (rank by counting).
-__global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *chain_len, int *chain_edges)
+__global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *chain_len, int *chain_edges, int *pos_of)
 {
     __shared__ int e[CH_MAX];
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *ch
         int r = 0;
         for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
         chain_edges[c * CH_MAX + r] = me;           // edge indices are distinct
+        pos_of[me] = r;
     }
 }
 
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
     long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
     int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
-    int max_chains)
+    int *pos_of, int max_chains)
 {
     __shared__ int e[CH_MAX];
     const int tid = threadIdx.x, A = B * n_roles;
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
             int r = 0;
             for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
             chain_edges[c * CH_MAX + r] = me;
+            pos_of[me] = r;
         }
         __syncthreads();
     }
@@ -549,10 +555,13 @@ struct Row {
 
 // Loads one row.  expect != 0: every granule must carry that tag; returns the
 // first mismatching tag seen (or `expect` when the row is complete).
+__device__ __forceinline__ unsigned load_row_at(const u64 *base, int k, int lane, unsigned expect, Row &r);
 __device__ __forceinline__ unsigned load_row(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r)
 {
-    const u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
-    const int k = h.k;
+    return load_row_at(h.rows + ((long long)m * h.N + x) * h.rg, h.k, lane, expect, r);
+}
+__device__ __forceinline__ unsigned load_row_at(const u64 *base, int k, int lane, unsigned expect, Row &r)
+{
     u64 g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, gh = 0;
     if (lane < 3) gh = ld_agent(base + lane);
     if (lane < k) {
@@ -990,11 +999,16 @@ __device__ inline int merge_pair_reg(WaveLds &L, int lane, int k, double alpha, 
 }
 
 // Write a whole row (all k entries, zeros beyond n) with one tag.
+__device__ __forceinline__ void store_row_at(u64 *base, int k, int lane, int n, u64 key, double ts, double w,
+                                             double new_norm, unsigned tag);
 __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, int lane, int n, u64 key, double ts,
                                           double w, double new_norm, unsigned tag)
 {
-    u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
-    const int k = h.k;
+    store_row_at(h.rows + ((long long)m * h.N + x) * h.rg, h.k, lane, n, key, ts, w, new_norm, tag);
+}
+__device__ __forceinline__ void store_row_at(u64 *base, int k, int lane, int n, u64 key, double ts, double w,
+                                             double new_norm, unsigned tag)
+{
     if (lane < k) {
         const bool a = lane < n;
         const u64 kk = a ? key : 0ull;
@@ -1017,11 +1031,16 @@ __device__ __forceinline__ void store_row(const zt_tppr &h, int m, long long x, 
 
 // The same from a Cand (merge_pair_reg): every candidate lane writes its own entry into its slot; slots
 // [n, k) are zeroed by lanes n..k-1.
+__device__ __forceinline__ void store_row_scatter_at(u64 *base, int k, int lane, int n, const Cand &c, double new_norm,
+                                                     unsigned tag);
 __device__ __forceinline__ void store_row_scatter(const zt_tppr &h, int m, long long x, int lane, int n, const Cand &c,
                                                   double new_norm, unsigned tag)
 {
-    u64 *base = h.rows + ((long long)m * h.N + x) * h.rg;
-    const int k = h.k;
+    store_row_scatter_at(h.rows + ((long long)m * h.N + x) * h.rg, h.k, lane, n, c, new_norm, tag);
+}
+__device__ __forceinline__ void store_row_scatter_at(u64 *base, int k, int lane, int n, const Cand &c, double new_norm,
+                                                     unsigned tag)
+{
     if (c.slot >= 0) {
         const u64 tt = (u64)__double_as_longlong(c.ts), ww = (u64)__double_as_longlong(c.w);
         u64 *e = base + HDR + c.slot;
@@ -1164,6 +1183,7 @@ struct StreamArgs {
     int *out_nodes, *out_eidx;
     float *out_dt, *out_w;
     unsigned epoch;
+    int chain_waves;   // waves of a chain workgroup that take chain hops (the others exit: the chain wave keeps its SIMD)
     int sub_B;         // > 0: the launch covers several consecutive batches of sub_B edges (the last may be shorter); the
                        // output rows of batch g form their own [n_models][n_roles][B_g][k] block, blocks back to back
 };
@@ -1199,14 +1219,42 @@ struct ChainHint {
     int tpos;
 };
 
+// the three output rows of edge i for emitted model mo (utils/util.py:504-506)
+__device__ __forceinline__ void emit_edge(const StreamArgs &A, int k, int lane, int i, int mo, const Row &ru, const Row &rv,
+                                          const Row &rg, double tnow)
+{
+    const int B = A.B, n_roles = A.n_roles;
+    long long ou, ov, og;                      // first element of the three output rows of this edge
+    if (A.sub_B > 0) {
+        const int g = i / A.sub_B, ii = i - g * A.sub_B;
+        const int Bg = (B - g * A.sub_B) < A.sub_B ? (B - g * A.sub_B) : A.sub_B;
+        const long long base = ((long long)g * A.n_models * n_roles * A.sub_B + (long long)mo * n_roles * Bg) * k;
+        ou = base + (long long)ii * k; ov = base + (long long)(Bg + ii) * k; og = base + (long long)(2 * Bg + ii) * k;
+    } else {
+        const long long ob = (long long)mo * A.out_rows * k;
+        ou = ob + (long long)i * k; ov = ob + (A.role_stride + i) * k; og = ob + (2 * A.role_stride + i) * k;
+    }
+    emit_row(ru, k, lane, tnow, A.out_nodes + ou, A.out_eidx + ou, A.out_dt + ou, A.out_w + ou);
+    emit_row(rv, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
+    if (n_roles == 3) emit_row(rg, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
+}
+
+// version t of chain c's hub row for model m (see zt_tppr::hubver)
+__device__ __forceinline__ u64 *hub_version(const zt_tppr &h, int m, int c, int t)
+{
+    return h.hubver + (((size_t)m * MAX_CHAINS + c) * (CH_MAX + 1) + t) * h.rg;
+}
+
 __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
-                                    long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint = nullptr)
+                                    long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint = nullptr,
+                                    int chain_idx = -1)
 {
     const int k = h.k, B = A.B, n_roles = A.n_roles;
     const int m = A.m_lo + mo;
     const double alpha = h.alpha[m], beta = h.beta[m];
     unsigned *done = h.done + (long long)m * MAX_CHUNK;
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS;
+    const unsigned vtag = tag_base | 1u;             // tag of the hub-row versions of this launch
     const long long role_stride = A.role_stride;
 #ifdef ZT_CRIT
     long long crit_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1248,10 +1296,15 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // into memory before ours and ours would then overwrite it.  Whenever the row IS stored, its next
     // accessor waits for it in memory (directly, or through a reader's reads-done flag).
     bool hub_to_memory = true;
+    // next_by_mail: the chain's next edge takes this hop's new row (nobody else writes the hub in between): that row is
+    // then also the next position's VERSION (hub_version), which its partner task reads; otherwise the next hop stores
+    // its version itself, from the row it finds in memory
+    bool next_by_mail = false;
     if (mail != nullptr && next_edge >= 0) {
         const int nrole = A.nodes[next_edge] == hub ? 0 : 1;
         const int my_out = ((u == hub) ? wo_u : wo_v) + 1;
-        hub_to_memory = !(h.wo[nrole * B + next_edge] == my_out && h.pflag[nrole * B + next_edge] < 0);
+        next_by_mail = h.wo[nrole * B + next_edge] == my_out;
+        hub_to_memory = !(next_by_mail && h.pflag[nrole * B + next_edge] < 0);
     }
 
     // ---- rows: one memory round trip; poll where a writer of this launch precedes us ----
@@ -1260,7 +1313,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     unsigned su = 0, sv = 0, sg = 0;
     if (!u_mail) su = load_row(h, m, u, lane, wo_u ? (tag_base | (unsigned)wo_u) : 0u, ru);
     if (v != u && !v_mail) sv = load_row(h, m, v, lane, wo_v ? (tag_base | (unsigned)wo_v) : 0u, rv);
-    const bool g_own = n_roles == 3 && g != u && g != v;
+    // (a chain wave applies the HUB's update only: the partner's update and the emission of this edge's rows are a
+    //  general task of their own, process_chain_partner -- the negative sample's row is not needed here)
+    const bool g_own = mail == nullptr && n_roles == 3 && g != u && g != v;
     if (g_own) sg = load_row(h, m, g, lane, wo_g ? (tag_base | (unsigned)wo_g) : 0u, rg);
     WL(0, 3);
     if (!u_mail && wo_u && su != (tag_base | (unsigned)wo_u))
@@ -1391,7 +1446,8 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // release store at agent scope would do it too, but it also writes the XCD's L2 back (buffer_wbl2) on
     // every hop; the rows themselves travel as write-through sc1 granules and need no such flush.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
+    if (mail == nullptr) st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
+    else st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);   // the chain's reads: the partner task may store the partner's new row
 
     // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
     // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
@@ -1442,8 +1498,20 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 __builtin_amdgcn_s_setprio(0);
             }
             if (hub_to_memory || xa != hub) store_row_scatter(h, m, xa, lane, n, c, new_norm, tag_base | (unsigned)(oa + 1));
+            if (mail != nullptr && xa == hub && next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n, c, new_norm, vtag);
         };
-        if (!split) {
+        if (!split && mail != nullptr) {
+            // a chain wave whose hub row did not come through the mailbox in set order (first hop, self-loop, the partner is
+            // the busier node): the hub's update in one piece; the old row is this position's version if nobody stored it
+            if (x1 == hub) update(r1, r2, x1, x2, o1, pre_hash, mo == 0 ? i : -1);
+            else update(r2, r1, x2, x1, o2, 0, -1);
+            if (!hub_by_mail) {
+                const Row &ro = hub_is_u ? ru : rv;
+                store_row_at(hub_version(h, m, chain_idx, tpos), k, lane, ro.len, ro.key, ro.ts, ro.w, ro.norm, vtag);
+            }
+            STAMP(2);
+            WL(0, 8);
+        } else if (!split) {
             update(r1, r2, x1, x2, o1, pre_hash, mo == 0 ? i : -1);
             STAMP(2);
             WL(0, 8);
@@ -1588,31 +1656,16 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             }
             c.slot = trueslot;
             if (hub_to_memory) store_row_scatter(h, m, x1, lane, n_new, c, new_norm, tag_base | (unsigned)(o1 + 1));
-            // ---- the partner's update reads the hub's old row in dictionary order ----
-            hub_to_dict();
+            // the new row in dictionary order is the NEXT position's version: its partner task reads it there
+            if (next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
             release_in();
-            update(r2, r1, x2, x1, o2, 0, -1);
         }
     }
     if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
 
     // ---- emission is off the critical path (utils/util.py:504-506) ----
     // (Leaving the emission of hub edges out -- as if other compute units did it -- does not make the chain faster.)
-    if (A.emit) {
-        long long ou, ov, og;                      // first element of the three output rows of this edge
-        if (A.sub_B > 0) {
-            const int g = i / A.sub_B, ii = i - g * A.sub_B;
-            const int Bg = (B - g * A.sub_B) < A.sub_B ? (B - g * A.sub_B) : A.sub_B;
-            const long long base = ((long long)g * A.n_models * n_roles * A.sub_B + (long long)mo * n_roles * Bg) * k;
-            ou = base + (long long)ii * k; ov = base + (long long)(Bg + ii) * k; og = base + (long long)(2 * Bg + ii) * k;
-        } else {
-            const long long ob = (long long)mo * A.out_rows * k;
-            ou = ob + (long long)i * k; ov = ob + (role_stride + i) * k; og = ob + (2 * role_stride + i) * k;
-        }
-        emit_row(ru, k, lane, tnow, A.out_nodes + ou, A.out_eidx + ou, A.out_dt + ou, A.out_w + ou);
-        emit_row(rv, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
-        if (n_roles == 3) emit_row(rg, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
-    }
+    if (A.emit && mail == nullptr) emit_edge(A, k, lane, i, mo, ru, rv, rg, tnow);
 #ifdef ZT_CRIT
     if (lane == 0 && mo == 0 && mail != nullptr && i < 8192)
         for (int q = 0; q < 8; ++q) g_crit[i * 8 + q] = crit_t[q];
@@ -1620,6 +1673,80 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     STAMP(3);
     WL(4, wall_clock64() >> 7); WL(0, 9);
     (void)wl_fail;
+}
+
+// The other half of a chain-owned edge (i, model mo), run by a wave of the GENERAL queue on another compute unit: the
+// partner's update from the hub's OLD row (utils/util.py:509-564 for the pair (partner, hub)) and the emission of the
+// edge's three rows.  The hub's old row is version t of its chain (hub_version: written by the chain in dictionary
+// order, hop after hop), the partner's and the negative sample's rows come from memory like everybody's.  The chain
+// reads the partner's OLD row as well: its "reads done" flag (cdone) gates the store of the partner's new row.
+// Taking this work out of the chain workgroup leaves the wave that holds the chain alone on its SIMD.
+__device__ inline void process_chain_partner(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo)
+{
+    const int k = h.k, B = A.B, n_roles = A.n_roles;
+    const int m = A.m_lo + mo;
+    const double alpha = h.alpha[m], beta = h.beta[m];
+    unsigned *done = h.done + (long long)m * MAX_CHUNK;
+    const unsigned *cdone = h.cdone + (long long)m * MAX_CHUNK;
+    const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS, vtag = tag_base | 1u;
+    const long long role_stride = A.role_stride;
+    const int c = h.owner_of[i], t = h.pos_of[i];
+    const long long hub = h.chain_node[c];
+    int my_wo = 0, my_pf = -1;
+    if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; }
+    if (my_pf >= 0) (void)wait_flag(done + my_pf, epoch, h.ctl + 2, my_pf);      // a reader before me has not read yet
+    const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
+    const long long u = A.nodes[i], v = A.nodes[role_stride + i];
+    const long long g = n_roles == 3 ? A.nodes[2 * role_stride + i] : u;
+    const double tnow = A.tsv[i];
+    const long long e = A.eidx[i];
+    const bool hub_is_u = u == hub;
+    const long long pnode = hub_is_u ? v : u;          // == hub for a self-loop
+    const int wo_p = hub_is_u ? wo_v : wo_u;
+    Row rh, rp, rg;
+    // ---- rows: the partner's and the negative sample's from memory, the hub's old one from its version slot ----
+    const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u, gtag = wo_g ? (tag_base | (unsigned)wo_g) : 0u;
+    const bool g_own = n_roles == 3 && g != u && g != v;
+    unsigned sp = 0, sg = 0;
+    const u64 *ver = hub_version(h, m, c, t);
+    unsigned sh = load_row_at(ver, k, lane, vtag, rh);
+    if (pnode != hub) sp = load_row(h, m, pnode, lane, ptag, rp);
+    if (g_own) sg = load_row(h, m, g, lane, gtag, rg);
+    if (pnode != hub && ptag && sp != ptag) (void)load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2);
+    if (g_own && gtag && sg != gtag) (void)load_row_wait(h, m, g, lane, gtag, rg, h.ctl + 2);
+    {
+        unsigned polls = 0;
+        long long t0 = 0;
+        while (sh != vtag) {                           // the chain has not reached this position yet
+            __builtin_amdgcn_s_sleep(32);
+            sh = load_row_at(ver, k, lane, vtag, rh);
+            if ((++polls & 255u) == 0) {
+                const long long now = (long long)wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > WAIT_TICKS) { note_timeout(h.ctl + 2, 4, i, (int)vtag, (int)sh, t); break; }
+                if (launch_failed(h.ctl + 2)) break;
+            }
+        }
+    }
+    // ---- all reads done: later writers of these rows may go ahead ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent(done + i, epoch);
+    if (pnode != hub) {
+        // (edge_idx, hub, ts) is the key entering the partner's dictionary
+        const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)hub;
+        Cand cc;
+        const int n = merge_pair_reg(L, lane, k, alpha, beta, rp, rh, nkey, tnow, cc);
+        const double new_norm = rp.norm * beta + beta;
+        (void)wait_flag(cdone + i, epoch, h.ctl + 2, -i - 2);      // the chain has read the partner's old row
+        store_row_scatter(h, m, pnode, lane, n, cc, new_norm, tag_base | (unsigned)(wo_p + 1));
+    } else {
+        rp = rh;
+    }
+    if (A.emit) {
+        const Row &ru = hub_is_u ? rh : rp, &rv = hub_is_u ? rp : rh;
+        if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
+        emit_edge(A, k, lane, i, mo, ru, rv, rg, tnow);
+    }
 }
 
 __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, StreamArgs A)
@@ -1657,6 +1784,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         len = len < CH_MAX ? len : CH_MAX;
         const int *edges = h.chain_edges + c * CH_MAX;
         // (Four waves per chain instead of eight: 835 us -- a wave's whole hop, off-chain half included, is ~16 us.)
+        // Only chain_waves waves (one per SIMD) take hops, the others leave: what a hop needs besides the hub's update --
+        // the partner's update, the emission -- runs elsewhere (process_chain_partner), so four waves keep up with the
+        // chain and the wave that holds it never shares its SIMD with a busy mate.
+        if ((int)(threadIdx.x / WAVE) >= A.chain_waves) return;
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
         // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
@@ -1667,8 +1798,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
             process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t,
-                         &hint);
+                         &hint, c);
         }
+        return;                                           // chain workgroups take no general tasks
     }
 
     // ---- general queue: every (edge, model) task not owned by a chain, in order ----
@@ -1683,7 +1815,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= total) return;
         const int i = idx / n_models;
-        if (A.use_chains && h.owner_of[i] >= 0) continue;   // a chain workgroup applies this edge
+        if (A.use_chains && h.owner_of[i] >= 0) {           // its chain applies the hub's update, this wave the rest
+            process_chain_partner(h, A, L, lane, i, idx % n_models);
+            continue;
+        }
         process_edge(h, A, L, lane, i, idx % n_models, nullptr, -1, -1, -1, 0);
     }
 }
@@ -1701,7 +1836,7 @@ void use_set(zt_tppr *h, int q)
     const zt_tppr::PlanSet &P = h->set[q];
     h->cnt = P.cnt; h->off = P.off; h->slot = P.slot; h->list = P.list; h->wo = P.wo; h->pflag = P.pflag; h->nxt = P.nxt;
     h->chain_of = P.chain_of; h->hot_node = P.hot_node; h->hot_cnt = P.hot_cnt; h->chain_node = P.chain_node;
-    h->chain_len = P.chain_len; h->chain_edges = P.chain_edges; h->owner_of = P.owner_of; h->ctl = P.ctl;
+    h->chain_len = P.chain_len; h->chain_edges = P.chain_edges; h->owner_of = P.owner_of; h->pos_of = P.pos_of; h->ctl = P.ctl;
 }
 
 }  // namespace
@@ -1726,6 +1861,14 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     ZT_HIP(hipMalloc(&h->rows, rows * h->rg * sizeof(u64)));
     ZT_HIP(hipMalloc(&h->done, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     ZT_HIP(hipMemset(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
+    ZT_HIP(hipMalloc(&h->cdone, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
+    ZT_HIP(hipMemset(h->cdone, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
+    h->hubver = nullptr;
+    if (k <= 31) {                                    // hub chains (register-resident merge) exist for k <= 31 only
+        const size_t vb = (size_t)n_tppr * MAX_CHAINS * (CH_MAX + 1) * h->rg * sizeof(u64);
+        ZT_HIP(hipMalloc(&h->hubver, vb));
+        ZT_HIP(hipMemset(h->hubver, 0, vb));
+    }
     for (int q = 0; q < 2; ++q) {
         zt_tppr::PlanSet &P = h->set[q];
         ZT_HIP(hipMalloc(&P.cnt, (size_t)num_nodes * sizeof(int)));
@@ -1743,6 +1886,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         ZT_HIP(hipMalloc(&P.chain_len, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMalloc(&P.chain_edges, sizeof(int) * MAX_CHAINS * CH_MAX));
         ZT_HIP(hipMalloc(&P.owner_of, sizeof(int) * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.pos_of, sizeof(int) * MAX_CHUNK));
         ZT_HIP(hipMemset(P.chain_of, 0xff, (size_t)num_nodes * sizeof(int)));
         ZT_HIP(hipMemset(P.chain_len, 0, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMemset(P.cnt, 0, (size_t)num_nodes * sizeof(int)));
@@ -1782,14 +1926,15 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
 {
     if (!h) return ZT_OK;
     (void)hipDeviceSynchronize();
-    (void)hipFree(h->rows); (void)hipFree(h->done);
+    (void)hipFree(h->rows); (void)hipFree(h->done); (void)hipFree(h->cdone);
+    if (h->hubver) (void)hipFree(h->hubver);
     if (h->latch_host) (void)hipHostFree(h->latch_host);
     for (int q = 0; q < 2; ++q) {
         zt_tppr::PlanSet &P = h->set[q];
         (void)hipFree(P.cnt); (void)hipFree(P.off); (void)hipFree(P.ctl); (void)hipFree(P.slot); (void)hipFree(P.list);
         (void)hipFree(P.wo); (void)hipFree(P.pflag); (void)hipFree(P.nxt); (void)hipFree(P.chain_of);
         (void)hipFree(P.hot_node); (void)hipFree(P.hot_cnt); (void)hipFree(P.chain_node); (void)hipFree(P.chain_len);
-        (void)hipFree(P.chain_edges); (void)hipFree(P.owner_of);
+        (void)hipFree(P.chain_edges); (void)hipFree(P.owner_of); (void)hipFree(P.pos_of);
         (void)hipEventDestroy(P.planned); (void)hipEventDestroy(P.consumed);
     }
     delete h;
@@ -1883,7 +2028,7 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
         k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
                                                   h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
                                                   h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
-                                                  max_chains);
+                                                  h->pos_of, max_chains);
         ZT_PROF_END(s, P_PREPASS);
     } else {
         ZT_PROF_BEGIN(s, P_PREPASS);
@@ -1896,7 +2041,7 @@ static int plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *
                                            max_chains);
         k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
                                                h->chain_edges, h->owner_of);
-        if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges);
+        if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges, h->pos_of);
         ZT_PROF_END(s, P_PREPASS);
         // per-node counters and the control words back to their rest state: the set is ready for k_stream
         ZT_PROF_BEGIN(s, P_CLEANUP);
@@ -1920,6 +2065,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
         k_retag<<<2048, 256, 0, s>>>(h->rows, (long long)h->M * h->N * h->rg);
         ZT_HIP(hipMemsetAsync(h->done, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * h->M, s));   // flags of old epochs
+        ZT_HIP(hipMemsetAsync(h->cdone, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * h->M, s));
+        if (h->hubver) ZT_HIP(hipMemsetAsync(h->hubver, 0, (size_t)h->M * MAX_CHAINS * (CH_MAX + 1) * h->rg * sizeof(u64), s));
         h->epoch = 0;
     }
     h->epoch += 1;
@@ -1942,6 +2089,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
     sa.sub_B = sub_B;
+    static const int chain_waves_env = getenv("ZT_CHAIN_WAVES") ? atoi(getenv("ZT_CHAIN_WAVES")) : 8;
+    sa.chain_waves = chain_waves_env < 1 ? 1 : (chain_waves_env > WAVES_PER_WG ? WAVES_PER_WG : chain_waves_env);
 #ifdef ZT_WAITLOG
     {
         void *wl = nullptr;
