@@ -20,7 +20,7 @@ for b in range(NB):
 f.check_status()
 n, ms = C.c_int64(), C.c_double(); lib.zt_profile_read(b"tppr_stream", C.byref(n), C.byref(ms))
 print("avg k_stream us: %.1f" % (1e3 * ms.value / n.value))
-c = np.zeros((B, 8), np.int64)
+c = np.zeros((B, 16), np.int64)
 lib.zt_debug_crit(c.ctypes.data_as(C.c_void_p), C.c_int(B))
 s0 = (NB - 1) * B
 u, v = src[s0:s0 + B], dst[s0:s0 + B]
@@ -35,6 +35,7 @@ print("core clocks 10/50/90 %%: row arrived -> front half done %s ; -> ready to 
     p(cc[:, 1] - cc[:, 0]), p(cc[:, 2] - cc[:, 1]), p(cc[:, 3] - cc[:, 2]), p(cc[:, 3] - cc[:, 0])))
 print("inside the front half: arrival -> merge_front entered %s ; scales + matching + new key %s ; layout %s ; rank pass %s ; return %s" % (
     p(cc[:, 4] - cc[:, 0]), p(cc[:, 5] - cc[:, 4]), p(cc[:, 6] - cc[:, 5]), p(cc[:, 7] - cc[:, 6]), p(cc[:, 1] - cc[:, 7])))
+print("arrival -> row read from LDS %s ; -> split path entered %s ; -> front half called %s ; -> inside %s" % (p(cc[:, 8] - cc[:, 0]), p(cc[:, 9] - cc[:, 8]), p(cc[:, 10] - cc[:, 9]), p(cc[:, 4] - cc[:, 10])))
 arr = c[idx][:, 0]; pub = c[idx][:, 3]
 g = (arr[1:] > 0) & (pub[:-1] > 0)
 print("publication(t-1) -> row arrived(t) [clocks of two different waves, same CU]: %s" % p((arr[1:] - pub[:-1])[g]))

@@ -232,7 +232,7 @@ constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock:
 // -DZT_CRIT (diagnostic build, tools/crit_profile.py): core-clock readings at four points of a hub hop, kept in
 // registers and written out at the end of the hop -- the chain itself is not disturbed by stores
 #ifdef ZT_CRIT
-__device__ long long g_crit[8192 * 8];     // per hub edge (model 0): see tools/crit_profile.py
+__device__ long long g_crit[8192 * 16];    // per hub edge (model 0): see tools/crit_profile.py
 #define CRIT(j) do { crit_t[j] = (long long)__builtin_readcyclecounter(); } while (0)
 #define CRITP(j) do { if (crit_p) crit_p[j] = (long long)__builtin_readcyclecounter(); } while (0)
 #define CRIT_ARG , long long *crit_p = nullptr
@@ -787,6 +787,10 @@ struct Front {
     bool keep;         // FR_RANKS, FR_TIES: this lane's candidate is kept
     unsigned claimed;  // uniform: bit r = some candidate has exactly drop + r smaller ones (rank_pass)
     u64 touched;       // uniform: s1 lanes whose weight a key match or the new key changed
+    // merge_front_fast only (fast): the candidates ascending by weight occupy sorted positions 0 .. n-1
+    bool fast;
+    int sp;            // sorted position of this lane's candidate
+    u64 S;             // uniform: positions where a run of equal weights starts
 };
 
 // The same pair update with the candidate list held in REGISTERS, for k <= 31: s1's entries stay in lanes
@@ -941,6 +945,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     F.key = ck; F.ts = ct; F.w = cw;
     F.live = live; F.n = n; F.n1 = n1; F.pos_tail = pos;
     F.lt = 0; F.keep = false; F.touched = touched; F.claimed = 0u;
+    F.fast = false; F.sp = -1; F.S = 0ull;
     STAMP2(2);
     STAMP2(3);
     const bool mine = (live >> lane) & 1ull;
@@ -953,6 +958,179 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     if (lane == 0) atomicAdd(&g_paths[F.mode == FR_RANKS ? 0 : (F.mode == FR_TIES ? 4 : 5)], 1);
 #endif
     STAMP2(4);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The front half on sorted inputs (hub chains): ranks from a bitonic MERGE instead of 48 lane broadcasts.
+// Along a chain the hub's row arrives in ascending order of weight (the arrangement the previous hop published)
+// and scaling by scale_s1 keeps that order.  The partner's side -- its scaled entries and the new key -- is
+// known while the wave still WAITS for the hub's row: it is sorted there (prepare_b, off the chain), descending,
+// into lanes 32..63 behind +inf padding, so that lanes 0..63 form a bitonic sequence once the hub's entries sit in
+// lanes 0..n1-1.  Six compare-exchange stages (lane distance 32, 16, 8, 4, 2, 1: permlane swaps and DPP moves,
+// no LDS) then leave the 2k+1 candidates ascending in lanes 0..n-1, each with the lane its candidate lives in; a
+// run of equal weights starts where a lane differs from its left neighbour, the number of strictly smaller
+// candidates of every member is the lane of that start, one ds_permute carries it home, and "do ties reach the
+// kept ranks / does a run straddle the cut" are bit tests on the mask of run starts.  The results (lt, keep,
+// claimed, mode) are those of rank_pass, bit for bit.
+// Preconditions, checked here (false: the caller takes merge_front): the scale factors were predicted for the norm
+// that arrived, no key of the partner's row is in the hub's row already (hash probe, verified), the new key is not in
+// the hub's row, no NaN.
+// ---------------------------------------------------------------------------------------------------------
+struct PreB {
+    bool ok;           // uniform: the fast path may be tried
+    int len2, nb;      // uniform: partner entries, candidates of the partner's side (entries + the new key unless present)
+    u64 cb_key;        // lanes >= 32: payload of the partner-side candidate living in this lane (entry j in lane 32 + j,
+    double cb_ts, cb_w;   //           the new key in lane 32 + len2), as merge_front lays them out
+    double sw;         // lanes >= 32: the same weights sorted DESCENDING behind +inf padding
+    int sid;           // lanes >= 32: the lane the candidate of that sorted position lives in (padding: an unused lane)
+    int h2;            // lanes < len2: hash slot of the partner's entry (to clear the table)
+};
+
+__device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u64 newkey, double newts,
+                                 const PreScale &ps, PreB &B)
+{
+    B.ok = false;
+    if (!ps.valid || k > 31) return;
+    const int len2 = __builtin_amdgcn_readfirstlane((r2.norm != 0.0) ? r2.len : 0);
+    const bool in2 = lane < len2;
+    const double v = (alpha != 0.0) ? ps.scale_s2 * alpha : ps.scale_s2;           // :531 / :540-541
+    const bool h2 = in2 && r2.key == newkey && r2.ts == newts;
+    const bool present2 = __ballot(h2) != 0ull;
+    const double w2 = h2 ? v : r2.w * ps.scale_s2;                                  // value * scale_s2 (:530-538)
+    const int nb = len2 + (present2 ? 0 : 1);
+    const bool isnew = !present2 && lane == len2;
+    const bool el = lane < nb;                                                      // this lane holds element `lane` of the side
+    const double bw = isnew ? v : w2;
+    if (__ballot(el && bw != bw) != 0ull) return;                                   // NaN: the general path
+    // descending order, equal weights by element number: rb = elements that come before mine
+    int rb = 0;
+    for (int q = 0; q < nb; ++q) {
+        const double x = readlane_f64(bw, q);
+        rb += (x > bw || (x == bw && q < lane)) ? 1 : 0;
+    }
+    // sorted lane of my element; lanes without one push to lane 0 (nobody reads the low half of these registers)
+    const int dst = el ? 64 - nb + rb : 0;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double sw = push_f64(bw, dst);
+    int sid = push_i32(32 + lane, dst);
+    const bool pad = lane >= 32 && lane < 64 - nb;                                  // sorted lanes nobody pushed to
+    sw = pad ? inf : sw;
+    sid = pad ? lane + nb : sid;                      // unused home lanes 32 + nb .. 63, one each
+    // payload where merge_front puts it: partner entry j -> lane 32 + j, the new key -> lane 32 + len2
+    {
+        const unsigned b0 = (unsigned)r2.key, b1 = (unsigned)(r2.key >> 32);
+        const u64 tb = (u64)__double_as_longlong(r2.ts), wb = (u64)__double_as_longlong(w2);
+#define ZT_SWAP(x, y) ((unsigned)__builtin_amdgcn_permlane32_swap((x), (y), false, false)[0])
+        B.cb_key = ((u64)ZT_SWAP(0u, b1) << 32) | ZT_SWAP(0u, b0);
+        B.cb_ts = __longlong_as_double((long long)(((u64)ZT_SWAP(0u, (unsigned)(tb >> 32)) << 32) | ZT_SWAP(0u, (unsigned)tb)));
+        B.cb_w = __longlong_as_double((long long)(((u64)ZT_SWAP(0u, (unsigned)(wb >> 32)) << 32) | ZT_SWAP(0u, (unsigned)wb)));
+#undef ZT_SWAP
+        if (!present2 && lane == 32 + len2) { B.cb_key = newkey; B.cb_ts = newts; B.cb_w = v; }
+    }
+    B.sw = sw; B.sid = sid; B.len2 = len2; B.nb = nb;
+    B.h2 = key_hash(r2.key);
+    B.ok = true;
+}
+
+// partner of this lane at distance D (lane ^ D) for one 32-bit register
+template <int D>
+__device__ __forceinline__ int xor_lane(int v, int lane)
+{
+    if (D == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // [0] = low half twice, [1] = high half twice
+        return lane < 32 ? r[1] : r[0];
+    } else if (D == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // [0] = rows 0,0,2,2   [1] = rows 1,1,3,3
+        return (lane & 16) ? r[0] : r[1];
+    } else if (D == 8) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);        // row_ror:8
+    } else if (D == 4) {
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);       // row_shl:4 into banks 0, 2 (lane i <- i + 4)
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);        // row_shr:4 into banks 1, 3 (lane i <- i - 4)
+    } else if (D == 2) {
+        return __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false);         // quad_perm [2,3,0,1]
+    } else {
+        return __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
+    }
+}
+
+// one stage of the bitonic merge: the lower lane of a pair keeps the smaller weight, the upper one the larger
+template <int D>
+__device__ __forceinline__ void merge_stage(int lane, double &w, int &id)
+{
+    const long long wb = __double_as_longlong(w);
+    const int plo = xor_lane<D>((int)(unsigned)(wb & 0xffffffffll), lane), phi = xor_lane<D>((int)(wb >> 32), lane);
+    const int pid = xor_lane<D>(id, lane);
+    const double pw = __longlong_as_double(((long long)phi << 32) | (unsigned)plo);
+    const bool take = (lane & D) ? (w < pw) : (pw < w);
+    w = take ? pw : w;
+    id = take ? pid : id;
+}
+
+__device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &r1, const Row &r2, const PreB &B,
+                                        const PreScale &ps, u64 newkey, double newts, bool table_ready, Front &F CRIT_ARG)
+{
+    CRITP(4);
+    if (!B.ok || r1.norm == 0.0 || ps.norm != r1.norm) return false;
+    const int n1 = __builtin_amdgcn_readfirstlane(r1.len);
+    const bool in1 = lane < n1;
+    const double w1 = r1.w * ps.scale_s1;                       // t_s1_PPR[key] = value * scale_s1
+    const int len2 = B.len2;
+    if (len2 > 0 && n1 > 0) {
+        if (!table_ready) return false;                         // (slot collision among the partner's keys: general path)
+        const int cand = in1 ? L.htab[key_hash(r1.key)] : -1;
+        if (__ballot(cand >= 0) != 0ull) {                      // an occupied slot: compare the keys in full
+            const int src = cand >= 0 ? cand : 0;
+            const u64 kj = __shfl(r2.key, src);
+            const double tj = __shfl(r2.ts, src);
+            if (__ballot(in1 && cand >= 0 && kj == r1.key && tj == r1.ts) != 0ull) return false;   // a real match
+        }
+    }
+    if (__ballot(in1 && ((r1.key == newkey && r1.ts == newts) || w1 != w1)) != 0ull) return false;
+    if (len2 > 0 && n1 > 0 && lane < len2) L.htab[B.h2] = -1;    // the table is clean again (merge_front does the same)
+    CRITP(5);
+    const int nb = B.nb, n = n1 + nb;
+    F.key = lane < 32 ? r1.key : B.cb_key;
+    F.ts = lane < 32 ? r1.ts : B.cb_ts;
+    F.w = lane < 32 ? w1 : B.cb_w;
+    F.live = (n1 > 0 ? ((1ull << n1) - 1ull) : 0ull) | (((1ull << nb) - 1ull) << 32);
+    F.n = n; F.n1 = n1;
+    F.pos_tail = lane < 32 ? lane : n1 + (lane - 32);           // place in the reference's dictionary order
+    F.lt = 0; F.keep = false; F.touched = 0ull; F.claimed = 0u;
+    F.fast = false; F.sp = -1; F.S = 0ull;
+    if (n <= k) { F.mode = FR_NOPRUNE; return true; }
+    CRITP(6);
+    // ---- bitonic merge of (weight, home lane): hub entries ascending in lanes [0, n1), +inf up to lane 31 ----
+    double sw = lane < 32 ? (in1 ? w1 : __longlong_as_double(0x7ff0000000000000ll)) : B.sw;
+    int sid = lane < 32 ? lane : B.sid;
+    merge_stage<32>(lane, sw, sid);
+    merge_stage<16>(lane, sw, sid);
+    merge_stage<8>(lane, sw, sid);
+    merge_stage<4>(lane, sw, sid);
+    merge_stage<2>(lane, sw, sid);
+    merge_stage<1>(lane, sw, sid);
+    // ---- runs of equal weights: a run starts where a lane differs from its left neighbour ----
+    const long long swb = __double_as_longlong(sw);
+    const int llo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const int lhi = __builtin_amdgcn_update_dpp(0, (int)(swb >> 32), 0x138, 0xf, 0xf, false);
+    const double left = __longlong_as_double(((long long)lhi << 32) | (unsigned)llo);
+    const u64 S = __ballot(lane == 0 || left != sw);
+    // number of strictly smaller candidates of the candidate at sorted lane p = lane of its run's start
+    const u64 below = S & (((u64)2 << lane) - 1ull);            // run starts at or below this lane (never empty: bit 0)
+    const int rs = 63 - __builtin_clzll(below);
+    const int both = push_i32(rs | (lane << 8), sid);           // ... carried, with the sorted position, to the lane the candidate lives in
+    const int lt = both & 0xff;
+    F.fast = true; F.sp = both >> 8; F.S = S;
+    const int drop = n - k;
+    const bool mine = (F.live >> lane) & 1ull;
+    F.lt = lt;
+    F.keep = mine && lt >= drop;
+    const bool full = (S >> drop) & 1ull;                       // the cut falls on a run start: exactly k candidates are kept
+    const unsigned claimed = (unsigned)(S >> drop) & ((1u << k) - 1u);
+    F.claimed = claimed;
+    F.mode = full ? (claimed == (1u << k) - 1u ? FR_RANKS : FR_TIES) : FR_STRADDLE;
+    CRITP(7);
+    return true;
 }
 
 // The ORDER half: posA = dictionary position of this lane's s1 entry (lanes < n1).  Returns the slot of this
@@ -1163,6 +1341,7 @@ struct MailSlot {
     unsigned unc;      // stage 1: bit s = the entry at provisional slot s may sit elsewhere in its run of equal weights
     int munc;          // stage 1: slots [0, munc) hold a PICK of munc members out of a run of munc + n_alt equal
     int n_alt;         //          weights that straddles the cut; which members stay is settled by the replay
+    int sorted;        // stage 1: the arrangement is ascending by weight (every pruned row; not a row that was never full)
     int seq_set;       // written last of stage 1
     int seq_ord;       // written last of stage 2
     int seq_free;      // = position of the READER once it is done with both stages: the slot may be rewritten
@@ -1257,7 +1436,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     const unsigned vtag = tag_base | 1u;             // tag of the hub-row versions of this launch
     const long long role_stride = A.role_stride;
 #ifdef ZT_CRIT
-    long long crit_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long crit_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
     WL(0, 1); WL(1, blockIdx.x * WAVES_PER_WG + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
@@ -1340,6 +1519,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     const bool hub_is_u = u == hub;
     PreScale pre_scale;
     pre_scale.valid = false;
+    PreB pre_b;
+    pre_b.ok = false;
+    int hub_sorted = 0;                         // the hub's row arrived ascending by weight
     int free_seen = -1;                         // seq_free of my ring slot as read with the row (-1: not read)
     if (hub_by_mail) {
         // everything else is in registers by now; the hub's row arrives through LDS
@@ -1372,6 +1554,16 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 pre_scale.valid = true;
             }
         }
+        // ... and the partner's side of the candidate list, sorted (merge_front_fast)
+        {
+            const long long x1_0 = sw ? v : u, x2_0 = sw ? u : v;
+            if (x1_0 == hub && u != v && pre_hash != 2)
+                prepare_b(lane, k, alpha, sw ? ru : rv, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2_0, tnow, pre_scale, pre_b);
+        }
+        // All rows that come from memory have arrived (the hub's comes through LDS): "reads done" can be said now
+        // instead of on the chain (see below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
         // From here to the publication of the new kept set this wave IS the chain: it shares its SIMD with a wave that
         // is busy with the off-chain half of an earlier hop (replay, partner's update, emission), and at equal
         // priority the two alternate issue slots.
@@ -1402,11 +1594,16 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         hub_unc = in_slot->unc;
         hub_munc = in_slot->munc;
         hub_nalt = in_slot->n_alt;
+        hub_sorted = in_slot->sorted;
         hub_alt = in_slot->alt_key[lane & 31];
         free_seen = lds_load_seq(&out_slot->seq_free);
         if (hub_is_u) ru = rm; else rv = rm;
         hub_ordered = hub_unc == 0u && hub_munc == 0;   // nothing provisional: the arrangement is the dictionary order
         hub_final = hub_ordered;
+#ifdef ZT_CRIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        CRIT(8);
     }
     // stage 2 of the hub's row: dictionary position of my set-order entry (identity when the row came from memory)
     int hub_pos = lane;
@@ -1445,9 +1642,11 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     // sample is not consumed until emission, so nothing else orders its loads): drain vmcnt explicitly.  A
     // release store at agent scope would do it too, but it also writes the XCD's L2 back (buffer_wbl2) on
     // every hop; the rows themselves travel as write-through sc1 granules and need no such flush.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (mail == nullptr) st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
-    else st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);   // the chain's reads: the partner task may store the partner's new row
+    if (!hub_by_mail) {                                               // (a hop whose hub row comes by mail has said so already)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (mail == nullptr) st_agent(done + i, epoch);              // every lane, same word (no lane-0 branch, see the dequeue)
+        else st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);   // the chain's reads: the partner task may store the partner's new row
+    }
 
     // ---- both directions from the OLD rows (utils/util.py:509-564); each new row is
     // ---- written back (utils/util.py:567-574) as soon as it exists: the tagged row IS the hand-off
@@ -1466,9 +1665,12 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 else if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
             }
         };
-        auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u, int munc = 0, int n_alt = 0) {
+        auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u, int munc = 0, int n_alt = 0, int sorted = 0) {
             if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
-            if (lane == 0) { out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt; }
+            if (lane == 0) {
+                out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt;
+                out_slot->sorted = sorted;
+            }
         };
         auto publish_seq = [&](bool set, bool ord) {
             // The mailbox lives in LDS and a wave's LDS instructions execute in program order: the sequence word, issued
@@ -1518,6 +1720,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
             if (u != v) update(r2, r1, x2, x1, o2, 0, -1);
         } else {
             // ---- the hub's update on a row that may still be in its provisional arrangement ----
+            CRIT(9);
             const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)x2;
             const double new_norm = r1.norm * beta + beta;
             if (hint != nullptr) { hint->norm_out = new_norm; hint->tpos = tpos; }
@@ -1530,7 +1733,9 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
                 if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
             }
-            merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale CRIT_PASS);
+            CRIT(10);
+            if (!(hub_sorted && merge_front_fast(L, lane, k, r1, r2, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_b.len2 == 0, F CRIT_PASS)))
+                merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale CRIT_PASS);
             CRIT(1);
             if (!settled) {
                 // a key match (or the new key) on an entry whose slot is provisional: the weights by position would
@@ -1615,7 +1820,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 set_out = true;
             }
             if (set_out) {
-                publish_set(provslot, n_new, new_norm, unc_out, munc_out, nalt_out);
+                publish_set(provslot, n_new, new_norm, unc_out, munc_out, nalt_out, F.mode != FR_NOPRUNE ? 1 : 0);
                 final_out = unc_out == 0u && munc_out == 0 && F.mode != FR_TIES && F.mode != FR_STRADDLE;
                 if (final_out) {
                     if (provslot >= 0) out_slot->pos[provslot] = provslot;
@@ -1668,11 +1873,299 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
     if (A.emit && mail == nullptr) emit_edge(A, k, lane, i, mo, ru, rv, rg, tnow);
 #ifdef ZT_CRIT
     if (lane == 0 && mo == 0 && mail != nullptr && i < 8192)
-        for (int q = 0; q < 8; ++q) g_crit[i * 8 + q] = crit_t[q];
+        for (int q = 0; q < 16; ++q) g_crit[i * 16 + q] = crit_t[q];
 #endif
     STAMP(3);
     WL(4, wall_clock64() >> 7); WL(0, 9);
     (void)wl_fail;
+}
+
+// One hop of a hub chain, the common case, as a function of its own: the hub's row comes through the mailbox from the
+// chain's previous edge, the partner is another node.  The chain applies the HUB's update only (the rest of the edge is
+// process_chain_partner's), so this is process_edge's mailbox path with everything else taken out -- no row selection by
+// role, no third row, no emission: what is left between the arrival of the row and the publication of the new kept set
+// is the chain's critical path, and every scalar branch and register move on it is paid 200 times per batch.
+// Returns false when the hop is not of this kind (first hop, another writer in between, self-loop): process_edge takes it.
+__device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
+                                 long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint, int chain_idx)
+{
+    if (prev_edge < 0 || h.k > 31) return false;
+    const int k = h.k, B = A.B;
+    const int m = A.m_lo + mo;
+    const long long role_stride = A.role_stride;
+    const long long u = A.nodes[i], v = A.nodes[role_stride + i];
+    if (u == v) return false;
+    const int role_h = u == hub ? 0 : 1, role_p = 1 - role_h;
+    const long long pnode = role_h == 0 ? v : u;
+    const int wo_h = h.wo[role_h * B + i], wo_p = h.wo[role_p * B + i];
+    {
+        const int prole = A.nodes[prev_edge] == hub ? 0 : 1;
+        if (h.wo[prole * B + prev_edge] + 1 != wo_h) return false;          // somebody else wrote the hub in between
+    }
+    const double alpha = h.alpha[m], beta = h.beta[m];
+    unsigned *done = h.done + (long long)m * MAX_CHUNK;
+    const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS, vtag = tag_base | 1u;
+#ifdef ZT_CRIT
+    long long crit_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    int wl_fail = 0;
+    // a reader of the hub's row in memory that precedes this edge must have read it before this hop may store there
+    const int pf_h = h.pflag[role_h * B + i];
+    if (pf_h >= 0 && !wait_flag(done + pf_h, epoch, h.ctl + 2, pf_h)) wl_fail |= 1;
+    const double tnow = A.tsv[i];
+    const long long e = A.eidx[i];
+    bool hub_to_memory = true, next_by_mail = false;                        // see process_edge
+    if (next_edge >= 0) {
+        const int nrole = A.nodes[next_edge] == hub ? 0 : 1;
+        next_by_mail = h.wo[nrole * B + next_edge] == wo_h + 1;
+        hub_to_memory = !(next_by_mail && h.pflag[nrole * B + next_edge] < 0);
+    }
+    // ---- the partner's row from memory (poll where a writer of this launch precedes us) ----
+    Row rp;
+    const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u;
+    if (load_row(h, m, pnode, lane, ptag, rp) != ptag)
+        if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
+    MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
+    // ---- while the hub's row is on its way: everything that depends on the partner only ----
+    int pre_hash = 0;                           // 1: partner entered into this wave's hash table, 2: with a clash
+    {
+        const int lenp = (rp.norm != 0.0) ? rp.len : 0;
+        if (lenp > 0) {
+            const int h2 = key_hash(rp.key);
+            if (lane < lenp) L.htab[h2] = lane;
+            wave_sync();
+            const int back = lane < lenp ? L.htab[h2] : lane;
+            const bool clash = __ballot(lane < lenp && back != lane) != 0ull;
+            if (clash && lane < lenp && back == lane) L.htab[h2] = -1;
+            pre_hash = clash ? 2 : 1;
+            wave_sync();
+        }
+    }
+    PreScale pre_scale;
+    pre_scale.valid = false;
+    if (hint->tpos >= 0 && tpos - hint->tpos <= 16) {
+        double pn = hint->norm_out;
+        for (int q = hint->tpos + 1; q < tpos; ++q) pn = pn * beta + beta;
+        if (pn != 0.0) {
+            const double nn = pn * beta + beta;
+            pre_scale.norm = pn;
+            pre_scale.scale_s1 = pn / nn * beta;
+            pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
+            pre_scale.valid = true;
+        }
+    }
+    const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)pnode;      // (edge_idx, partner, ts) enters the hub's dictionary
+    PreB pre_b;
+    pre_b.ok = false;
+    if (pre_hash != 2) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b);
+    // the rows that come from memory have arrived: the partner task may store the partner's new row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
+    // waves whose turn is two or more hops away doze (see process_edge)
+    if (tpos >= 2) {
+        const int *far = &mail->slot[(tpos - 2) % MAIL_R].seq_set;
+        unsigned spins = 0;
+        while (lds_load_seq(far) != tpos - 1 && lds_load_seq(&in_slot->seq_set) != tpos) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0 && launch_failed(h.ctl + 2)) break;
+        }
+    }
+    if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
+    __builtin_amdgcn_s_setprio(3);
+    CRIT(0);
+    // ---- the hub's row: one batch of LDS reads ----
+    Row rh;
+    rh.len = in_slot->len; rh.norm = in_slot->norm;
+    rh.key = in_slot->key[lane & 31]; rh.ts = in_slot->ts[lane & 31]; rh.w = in_slot->w[lane & 31];
+    unsigned hub_unc = in_slot->unc;
+    int hub_munc = in_slot->munc, hub_nalt = in_slot->n_alt;
+    const u64 hub_alt = in_slot->alt_key[lane & 31];
+    const int hub_sorted = in_slot->sorted;
+    const int free_seen = lds_load_seq(&out_slot->seq_free);
+    bool hub_ordered = hub_unc == 0u && hub_munc == 0, hub_final = hub_ordered;
+    int hub_pos = lane;
+    CRIT(8);
+    auto hub_order = [&]() {
+        if (hub_ordered) return;
+        if (!wait_seq(&in_slot->seq_ord, tpos, h.ctl + 2, i, -prev_edge - 2)) wl_fail |= 32;
+        hub_pos = in_slot->pos[lane & 31];
+        hub_ordered = true;
+    };
+    auto hub_to_dict = [&]() {
+        hub_order();
+        if (hub_final) return;
+        rh.key = in_slot->key2[lane & 31]; rh.ts = in_slot->ts2[lane & 31];
+        hub_pos = lane;
+        hub_final = true;
+        hub_unc = 0u; hub_munc = 0; hub_nalt = 0;
+    };
+    Cand c;
+    auto ring_free = [&]() {
+        if (tpos >= MAIL_R) {
+            if (free_seen == tpos - MAIL_R + 1) asm volatile("" ::: "memory");
+            else if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
+        }
+    };
+    auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc, int munc, int n_alt, int sorted) {
+        if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
+        if (lane == 0) {
+            out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt;
+            out_slot->sorted = sorted;
+        }
+    };
+    auto publish_seq = [&](bool set, bool ord) {           // LDS only, in program order (see process_edge)
+        asm volatile("" ::: "memory");
+        if (lane == 0 && set) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0 && ord) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    CRIT(9);
+    const double new_norm = rh.norm * beta + beta;
+    hint->norm_out = new_norm; hint->tpos = tpos;
+    Front F;
+    bool settled = hub_final;                                    // the row is known to be the dictionary
+    if (!settled && hub_munc > 0) {
+        // members of a straddling run that were not picked may turn out to be in the row (process_edge)
+        bool t = lane < hub_nalt && hub_alt == nkey;
+        if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
+        if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
+    }
+    CRIT(10);
+    if (!(hub_sorted && merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_b.len2 == 0, F CRIT_PASS)))
+        merge_front(L, lane, k, alpha, beta, rh, rp, nkey, tnow, F, pre_hash, -1, &pre_scale CRIT_PASS);
+    CRIT(1);
+    if (!settled) {
+        bool redo = (F.touched & (u64)hub_unc) != 0ull;
+        if (!redo && hub_munc > 0) {
+            const bool picked = lane < hub_munc;
+            if (F.mode == FR_RANKS || F.mode == FR_TIES) redo = __ballot(picked && F.keep) != 0ull;
+            else if (F.mode == FR_STRADDLE) {
+                const int top_below = wave_max0(((F.live >> lane) & 1ull) && F.lt < F.n - k ? F.lt + 1 : 0) - 1;   // rank of the straddling run
+                redo = __ballot(picked && F.lt >= top_below) != 0ull;
+            } else redo = true;
+        }
+        if (redo) {
+            hub_to_dict();
+            settled = true;
+            merge_front(L, lane, k, alpha, beta, rh, rp, nkey, tnow, F, 0, -1);
+        }
+    }
+    const unsigned unc_in = settled ? 0u : hub_unc;              // provisional slots of the row as I used it
+    c.key = F.key; c.ts = F.ts; c.w = F.w;
+    const bool mine = (F.live >> lane) & 1ull;
+    const int pos_prov = lane < 32 ? lane : F.pos_tail;          // my candidate's place in the list as it arrived
+    const int drop = F.n - k;
+    int n_new = F.n <= k ? F.n : k, provslot = -1, trueslot = -1;
+    unsigned unc_out = 0u;
+    int munc_out = 0, nalt_out = 0;
+    bool set_out = false, final_out = false;
+    ring_free();
+    if (F.mode == FR_NOPRUNE) {
+        provslot = mine ? pos_prov : -1;                         // s1's entries keep their slots, and their doubts
+        unc_out = unc_in;
+        set_out = true;
+    } else if (F.mode == FR_RANKS) {
+        provslot = F.keep ? F.lt - drop : -1;                    // all kept weights distinct: nothing provisional
+        set_out = true;
+    } else if (F.fast) {
+        // Ties, from the sorted positions the merge network left: the candidate at position p >= drop takes provisional
+        // slot p - drop (ascending by weight, members of a run of equal weights in whatever order the network put them:
+        // "arbitrary" is all stage 1 promises); a slot is in doubt iff its run has another member.  A run that straddles
+        // the cut has its members at positions >= drop in slots [0, j) -- the pick -- and the others are the alternates.
+        const u64 S = F.S;
+        const u64 nmask = ((u64)2 << (F.n - 1)) - 1ull;                         // positions 0 .. n-1 (n <= 63)
+        const u64 multi = (~S | ~(S >> 1)) & nmask;                             // position p shares its run with p-1 or with p+1
+                                                                                // (position n, the padding, always starts a run)
+        provslot = (mine && F.sp >= drop) ? F.sp - drop : -1;
+        unc_out = (unsigned)(multi >> drop) & ((1u << k) - 1u);
+        if (F.mode == FR_STRADDLE) {
+            const int rsG = 63 - __builtin_clzll(S & (((u64)2 << drop) - 1ull)); // start of the run that holds position `drop`
+            const u64 above = S & ~(((u64)2 << drop) - 1ull);                     // the next run starts here (the padding's at n, at the latest)
+            const int endG = __ffsll((long long)above) - 1;
+            munc_out = endG - drop;
+            nalt_out = drop - rsG;
+            if (mine && F.sp >= rsG && F.sp < drop) out_slot->alt_key[F.sp - rsG] = c.key;
+        }
+        set_out = true;
+    } else if (F.mode == FR_TIES || F.mode == FR_STRADDLE) {
+        // (process_edge: ascending by weight; equal weights take the slots of their run in lane order; a run that
+        //  straddles the cut sends its first j members to slots [0, j) and the others along as alternates)
+        int ltG = -1, j = 0;
+        u64 Gm = 0ull;
+        if (F.mode == FR_STRADDLE) {
+            ltG = wave_max0(mine && F.lt < drop ? F.lt + 1 : 0) - 1;
+            Gm = __ballot(mine && F.lt == ltG);
+            j = ltG + __popcll(Gm) - drop;
+        }
+        const bool certain = mine && F.lt >= drop;
+        const int r0 = F.lt - drop;
+        provslot = certain ? r0 : -1;
+        unsigned ub = 0u;
+        u64 todo = __ballot(certain && r0 + 1 < k && ((F.claimed >> ((r0 + 1) & 31)) & 1u) == 0u);
+        while (todo != 0ull) {
+            const int l = __ffsll((long long)todo) - 1;
+            const int rv = __builtin_amdgcn_readlane(r0, l);
+            const u64 grp = __ballot(certain && r0 == rv);
+            if ((grp >> lane) & 1ull) { provslot = rv + __popcll(grp & lanemask_lt()); ub = 1u << provslot; }
+            todo &= ~grp;
+        }
+        if (F.mode == FR_STRADDLE) {
+            const int gi = __popcll(Gm & lanemask_lt());
+            const bool member = (Gm >> lane) & 1ull;
+            if (member && gi < j) { provslot = gi; ub = 1u << gi; }
+            if (member && gi >= j) out_slot->alt_key[gi - j] = c.key;
+            munc_out = j;
+            nalt_out = __popcll(Gm) - j;
+        }
+        unc_out = wave_or(ub);
+        set_out = true;
+    }
+    if (set_out) {
+        publish_set(provslot, n_new, new_norm, unc_out, munc_out, nalt_out, F.mode != FR_NOPRUNE ? 1 : 0);
+        final_out = unc_out == 0u && munc_out == 0 && F.mode != FR_TIES && F.mode != FR_STRADDLE;
+        if (final_out) {
+            if (provslot >= 0) out_slot->pos[provslot] = provslot;
+            trueslot = provslot;
+        }
+        CRIT(2);
+        publish_seq(true, final_out);                            // the successor can start
+        CRIT(3);
+        __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
+    }
+    if (!final_out) {
+        // ---- my own replay: final slot of every list POSITION (identity-free, see Mail) ----
+        const int slot_c = merge_order(L, lane, k, F, lane, &n_new, -1);
+        int *sig = L.sel;                                        // final slot by list position
+        if (mine) sig[pos_prov] = slot_c;
+        wave_sync();
+        // ---- identities: where my candidate REALLY stood in the list ----
+        if (unc_in != 0u) hub_order();
+        const int truepos = lane < 32 ? hub_pos : F.pos_tail;    // hub_pos = lane when nothing was provisional
+        trueslot = (mine && truepos >= 0) ? sig[truepos] : -1;
+        wave_sync();
+        if (trueslot >= 0) { out_slot->key2[trueslot] = c.key; out_slot->ts2[trueslot] = c.ts; }
+        if (!set_out) {                                          // (NaN weights) the kept set itself needed the replay
+            provslot = trueslot;
+            publish_set(provslot, n_new, new_norm, 0u, 0, 0, 0);
+            if (provslot >= 0) out_slot->pos[provslot] = provslot;
+            publish_seq(true, true);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            if (provslot >= 0) out_slot->pos[provslot] = trueslot;
+            publish_seq(false, true);
+        }
+    }
+    c.slot = trueslot;
+    if (hub_to_memory) store_row_scatter(h, m, hub, lane, n_new, c, new_norm, tag_base | (unsigned)(wo_h + 1));
+    // the new row in dictionary order is the NEXT position's version: its partner task reads it there
+    if (next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
+    if (lane == 0)                                               // both stages of the incoming slot have been read
+        __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef ZT_CRIT
+    if (lane == 0 && mo == 0 && i < 8192)
+        for (int q = 0; q < 16; ++q) g_crit[i * 16 + q] = crit_t[q];
+#endif
+    (void)wl_fail;
+    return true;
 }
 
 // The other half of a chain-owned edge (i, model mo), run by a wave of the GENERAL queue on another compute unit: the
@@ -1797,8 +2290,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
-            process_edge(h, A, L, lane, edges[t], mo, &mail, hub, t > 0 ? edges[t - 1] : -1, t + 1 < len ? edges[t + 1] : -1, t,
-                         &hint, c);
+            const int pe = t > 0 ? edges[t - 1] : -1, ne = t + 1 < len ? edges[t + 1] : -1;
+            if (!chain_hop(h, A, L, lane, edges[t], mo, &mail, hub, pe, ne, t, &hint, c))
+                process_edge(h, A, L, lane, edges[t], mo, &mail, hub, pe, ne, t, &hint, c);
         }
         return;                                           // chain workgroups take no general tasks
     }
@@ -2217,7 +2711,7 @@ extern "C" int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double
 extern "C" int zt_debug_crit(long long *host, int n)
 {
     ZT_HIP(hipDeviceSynchronize());
-    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_crit), sizeof(long long) * n * 8));
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_crit), sizeof(long long) * n * 16));
     return ZT_OK;
 }
 #endif
