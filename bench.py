@@ -248,7 +248,7 @@ def main():
                          "0 for the pruning strategy, whose query kernel wants the whole chip)")
     ap.add_argument("--group", type=int, default=-1,
                     help="consecutive batches whose streaming T-PPR update runs as ONE launch (zt_pipeline_set_group); "
-                         "default: as many as fit a launch (<= 8192 edges), at most 4; 1 for the pruning strategy")
+                         "default: as many as fit a launch (<= 16384 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     ap.add_argument("--perm-seed", type=int, default=7,
@@ -337,7 +337,7 @@ def main():
         step = tgn.step_device
 
     if a.group < 1:
-        a.group = max(1, min(4, 8192 // bs)) if wl["strategy"] == "streaming" else 1
+        a.group = max(1, min(4, 16384 // bs)) if wl["strategy"] == "streaming" else 1
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
         if a.tppr_cus < 0:

@@ -117,7 +117,7 @@ int zt_tppr_stream(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev,
  * streams is handled inside).  A call with token 0, or with a token whose plan
  * has been dropped (zt_tppr_reset / copy / import, or two newer plans), runs
  * its own prepass.  Two plans can be outstanding.  *token_out = 0 and a no-op
- * for B == 0 or B > 8192 (multi-launch calls plan inline).
+ * for B == 0 or B > 16384 (multi-launch calls plan inline).
  * The k_stream grid is sized for the compute units of the stream that RUNS it
  * (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs of that stream's mask);
  * if that stream turns out to offer fewer CUs than the plan assumed, the grid
@@ -411,7 +411,7 @@ int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, 
  * (edges applied in order across them, exactly as in separate calls; every batch's output rows form their own
  * block), which pays a launch's fixed costs once per group; the pipeline then queries the group after the current
  * one and plans the one after that, so 3 g batches in sight keep it full (a group is only filled while a follower of it is in sight; fewer: smaller groups).  Batches of
- * a group are equally long (the last may be shorter) and together at most 8192 edges.  zt_pipeline_step is this
+ * a group are equally long (the last may be shorter) and together at most 16384 edges.  zt_pipeline_step is this
  * call with ahead = {next, plan}.  The pruning strategy carries no state between batches: its group is 1. */
 int zt_pipeline_set_group(zt_pipeline *p, int32_t group);
 /* embedding_module.average_topk (modules/embedding_module.py:232-233): with a non-NULL device float, every step

@@ -249,7 +249,7 @@ def test_exact_topk_selection_paths(zt, oracle, n, k):
 
 
 def test_large_single_call_and_epoch_wrap(zt, oracle):
-    """One call with more edges than a launch chunk (8192), and launches across
+    """One call with more edges than a launch chunk (16384), and launches across
     the tag-epoch wrap-around, still match the oracle bit for bit."""
     import ctypes as C
     from zebra_amd import _capi
@@ -258,14 +258,14 @@ def test_large_single_call_and_epoch_wrap(zt, oracle):
     src, dst, neg, ts, eidx = I.make_stream("bipartite", N, E, 401)
     f = zt.tppr_finder(N, k, 2, al, be)
     o = oracle.TpprOracle(N, k, 2, al, be)
-    # 20000 edges in ONE call -> three device launches
+    # 20000 edges in ONE call -> two device launches
     nodes = np.concatenate([src[:20000], dst[:20000], neg[:20000]])
     a = f.streaming_topk(nodes, ts[:20000], eidx[:20000])
     b = o.streaming_topk(nodes, ts[:20000], eidx[:20000])
     for x, y in zip(a, b):
         assert np.array_equal(np.stack(x), np.stack(y))
     # jump next to the epoch wrap and keep streaming across it
-    _capi.check(_capi.lib().zt_test_set_epoch(f._live.h, C.c_uint32((1 << 18) - 4)))
+    _capi.check(_capi.lib().zt_test_set_epoch(f._live.h, C.c_uint32((1 << 17) - 4)))
     for s in range(20000, 30000, 1000):
         e = s + 1000
         nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])

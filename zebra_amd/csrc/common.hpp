@@ -26,7 +26,7 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
                    int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                    float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
                    hipEvent_t *done_out, int32_t sub_B);
-constexpr int TPPR_MAX_LAUNCH = 8192;     // edges one T-PPR launch can cover (tppr_stream.hip: MAX_CHUNK)
+constexpr int TPPR_MAX_LAUNCH = 16384;     // edges one T-PPR launch can cover (tppr_stream.hip: MAX_CHUNK)
 
 // extra flags for events that only order streams of this device (experiment knob: ZT_EVENT_FLAGS, hex)
 inline unsigned sync_event_flags()

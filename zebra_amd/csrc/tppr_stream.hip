@@ -150,8 +150,8 @@ extern "C" const char *zt_version(void) { return "zebra_amd 0.1 gfx950"; }
 // ---- handle --------------------------------------------------------------------
 namespace {
 constexpr int HDR = 4;                 // header granules: len, norm lo, norm hi, pad
-constexpr int ORD_BITS = 14;           // writer ordinal inside one launch
-constexpr int MAX_CHUNK = 8192;        // edges per launch (ordinals must fit ORD_BITS)
+constexpr int ORD_BITS = 15;           // writer ordinal inside one launch (a node has at most MAX_CHUNK writers)
+constexpr int MAX_CHUNK = 16384;       // edges per launch (ordinals must fit ORD_BITS)
 constexpr unsigned EPOCH_MAX = (1u << (32 - ORD_BITS)) - 1;
 static_assert(MAX_CHUNK == zt::TPPR_MAX_LAUNCH, "common.hpp: TPPR_MAX_LAUNCH");
 // hub chains: the nodes touched most often in a launch get a workgroup of their own
@@ -277,6 +277,12 @@ struct WaveLds {
 __device__ __forceinline__ int key_hash(u64 key)
 {
     return (int)((((unsigned)key * 0x9E3779B1u) ^ ((unsigned)(key >> 32) * 0x85EBCA77u)) >> 22);
+}
+
+// a second, independent slot function: a partner row whose keys collide under key_hash rarely collides under this one
+__device__ __forceinline__ int key_hash2(u64 key)
+{
+    return (int)((((unsigned)key * 0x85EBCA77u) ^ ((unsigned)(key >> 32) * 0xC2B2AE3Du)) >> 22);
 }
 
 __host__ __device__ inline u64 granule(unsigned tag, unsigned payload) { return ((u64)tag << 32) | payload; }
@@ -987,7 +993,7 @@ struct PreB {
 };
 
 __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u64 newkey, double newts,
-                                 const PreScale &ps, PreB &B)
+                                 const PreScale &ps, PreB &B, int h2slot)
 {
     B.ok = false;
     if (!ps.valid || k > 31) return;
@@ -1028,7 +1034,7 @@ __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u
         if (!present2 && lane == 32 + len2) { B.cb_key = newkey; B.cb_ts = newts; B.cb_w = v; }
     }
     B.sw = sw; B.sid = sid; B.len2 = len2; B.nb = nb;
-    B.h2 = key_hash(r2.key);
+    B.h2 = h2slot;
     B.ok = true;
 }
 
@@ -1068,25 +1074,31 @@ __device__ __forceinline__ void merge_stage(int lane, double &w, int &id)
 }
 
 __device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &r1, const Row &r2, const PreB &B,
-                                        const PreScale &ps, u64 newkey, double newts, bool table_ready, Front &F CRIT_ARG)
+                                        const PreScale &ps, u64 newkey, double newts, bool table_ready, bool hash2, Front &F CRIT_ARG)
 {
     CRITP(4);
-    if (!B.ok || r1.norm == 0.0 || ps.norm != r1.norm) return false;
+#ifdef ZT_CRIT
+#define FAILC(code) do { if (crit_p) crit_p[11] = (code); } while (0)
+#else
+#define FAILC(code) do { } while (0)
+#endif
+    if (!B.ok) { FAILC(1); return false; }
+    if (r1.norm == 0.0 || ps.norm != r1.norm) { FAILC(2); return false; }
     const int n1 = __builtin_amdgcn_readfirstlane(r1.len);
     const bool in1 = lane < n1;
     const double w1 = r1.w * ps.scale_s1;                       // t_s1_PPR[key] = value * scale_s1
     const int len2 = B.len2;
     if (len2 > 0 && n1 > 0) {
-        if (!table_ready) return false;                         // (slot collision among the partner's keys: general path)
-        const int cand = in1 ? L.htab[key_hash(r1.key)] : -1;
+        if (!table_ready) { FAILC(6); return false; }            // (slot collision among the partner's keys: general path)
+        const int cand = in1 ? L.htab[hash2 ? key_hash2(r1.key) : key_hash(r1.key)] : -1;
         if (__ballot(cand >= 0) != 0ull) {                      // an occupied slot: compare the keys in full
             const int src = cand >= 0 ? cand : 0;
             const u64 kj = __shfl(r2.key, src);
             const double tj = __shfl(r2.ts, src);
-            if (__ballot(in1 && cand >= 0 && kj == r1.key && tj == r1.ts) != 0ull) return false;   // a real match
+            if (__ballot(in1 && cand >= 0 && kj == r1.key && tj == r1.ts) != 0ull) { FAILC(3); return false; }   // a real match
         }
     }
-    if (__ballot(in1 && ((r1.key == newkey && r1.ts == newts) || w1 != w1)) != 0ull) return false;
+    if (__ballot(in1 && ((r1.key == newkey && r1.ts == newts) || w1 != w1)) != 0ull) { FAILC(4); return false; }
     if (len2 > 0 && n1 > 0 && lane < len2) L.htab[B.h2] = -1;    // the table is clean again (merge_front does the same)
     CRITP(5);
     const int nb = B.nb, n = n1 + nb;
@@ -1558,7 +1570,8 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         {
             const long long x1_0 = sw ? v : u, x2_0 = sw ? u : v;
             if (x1_0 == hub && u != v && pre_hash != 2)
-                prepare_b(lane, k, alpha, sw ? ru : rv, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2_0, tnow, pre_scale, pre_b);
+                prepare_b(lane, k, alpha, sw ? ru : rv, ((u64)(unsigned)e << 32) | (u64)(unsigned)x2_0, tnow, pre_scale, pre_b,
+                          key_hash((sw ? ru : rv).key));
         }
         // All rows that come from memory have arrived (the hub's comes through LDS): "reads done" can be said now
         // instead of on the chain (see below)
@@ -1734,7 +1747,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
                 if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
             }
             CRIT(10);
-            if (!(hub_sorted && merge_front_fast(L, lane, k, r1, r2, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_b.len2 == 0, F CRIT_PASS)))
+            if (!(hub_sorted && merge_front_fast(L, lane, k, r1, r2, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_b.len2 == 0, false, F CRIT_PASS)))
                 merge_front(L, lane, k, alpha, beta, r1, r2, nkey, tnow, F, pre_hash, mo == 0 ? i : -1, &pre_scale CRIT_PASS);
             CRIT(1);
             if (!settled) {
@@ -1927,18 +1940,21 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
     MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
-    int pre_hash = 0;                           // 1: partner entered into this wave's hash table, 2: with a clash
-    {
-        const int lenp = (rp.norm != 0.0) ? rp.len : 0;
-        if (lenp > 0) {
-            const int h2 = key_hash(rp.key);
-            if (lane < lenp) L.htab[h2] = lane;
+    int pre_hash = 0;                           // 1 / 3: partner entered into this wave's hash table (slot function 1 / 2),
+    int h2slot = 0;                             // 2: its keys collide under both
+    const int lenp = (rp.norm != 0.0) ? rp.len : 0;
+    if (lenp > 0) {
+        pre_hash = 2;
+#pragma unroll
+        for (int var = 0; var < 2; ++var) {
+            const int hs = var == 0 ? key_hash(rp.key) : key_hash2(rp.key);
+            if (lane < lenp) L.htab[hs] = lane;
             wave_sync();
-            const int back = lane < lenp ? L.htab[h2] : lane;
+            const int back = lane < lenp ? L.htab[hs] : lane;
             const bool clash = __ballot(lane < lenp && back != lane) != 0ull;
-            if (clash && lane < lenp && back == lane) L.htab[h2] = -1;
-            pre_hash = clash ? 2 : 1;
+            if (clash && lane < lenp) L.htab[hs] = -1;           // (several lanes may clear one slot)
             wave_sync();
+            if (!clash) { pre_hash = var == 0 ? 1 : 3; h2slot = hs; break; }
         }
     }
     PreScale pre_scale;
@@ -1957,7 +1973,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)pnode;      // (edge_idx, partner, ts) enters the hub's dictionary
     PreB pre_b;
     pre_b.ok = false;
-    if (pre_hash != 2) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b);
+    if (pre_hash != 2) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b, h2slot);
     // the rows that come from memory have arrived: the partner task may store the partner's new row
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
@@ -2026,12 +2042,22 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (!settled && hub_munc > 0) {
         // members of a straddling run that were not picked may turn out to be in the row (process_edge)
         bool t = lane < hub_nalt && hub_alt == nkey;
-        if (pre_hash == 1) t = t || (lane < hub_nalt && L.htab[key_hash(hub_alt)] >= 0);
-        if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; pre_hash = pre_hash == 2 ? 2 : 1; }
+        if (pre_hash == 1 || pre_hash == 3) t = t || (lane < hub_nalt && L.htab[pre_hash == 3 ? key_hash2(hub_alt) : key_hash(hub_alt)] >= 0);
+        if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; }
     }
     CRIT(10);
-    if (!(hub_sorted && merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_b.len2 == 0, F CRIT_PASS)))
+#ifdef ZT_CRIT
+    crit_t[11] = hub_sorted ? 0 : 5; crit_t[12] = pre_hash; crit_t[13] = pre_scale.valid ? 1 : 0;
+#endif
+    if (!(hub_sorted && merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_hash == 3 || lenp == 0,
+                                         pre_hash == 3, F CRIT_PASS))) {
+        if (pre_hash == 3) {                                     // merge_front probes with the first slot function: start it clean
+            if (lane < lenp) L.htab[h2slot] = -1;
+            wave_sync();
+            pre_hash = 0;
+        }
         merge_front(L, lane, k, alpha, beta, rh, rp, nkey, tnow, F, pre_hash, -1, &pre_scale CRIT_PASS);
+    }
     CRIT(1);
     if (!settled) {
         bool redo = (F.touched & (u64)hub_unc) != 0ull;

@@ -102,7 +102,7 @@ class TGN(torch.nn.Module):
         return B
 
     # -- the step as ONE native call (csrc/pipeline.hip): P1 of batch b+1 on a side stream beside P2 + P3 of batch b
-    def enable_pipeline(self, on=True, tppr_cus=0, max_batch=8192, group=1):
+    def enable_pipeline(self, on=True, tppr_cus=0, max_batch=16384, group=1):
         """Create (or drop) the native step pipeline.  ``tppr_cus`` > 0 pins the T-PPR stream to the first
         tppr_cus compute units (CU mask) and everything else to the rest; callers run their own work on
         ``self.main_stream``.  With it, ``step_device`` takes ``prefetch`` (the NEXT batch: its T-PPR query is
