@@ -354,6 +354,40 @@ int zt_gru_update(float *memory_dev, float *last_update_dev,
                   void *workspace_dev, int32_t weights_ready, void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Training-side dense operators on exact-f32 MFMA (csrc/train_ops.hip).       */
+/*   What the reference's autograd does with nn.GRUCell (get_updated_memory,   */
+/*   modules/memory_updater.py:61-90,95-98) and nn.Linear (fc2,                */
+/*   transform_source: modules/embedding_module.py:86-98,320-328) on the       */
+/*   compact rows of a training step.                                          */
+/* ------------------------------------------------------------------------ */
+/* C[M][N] = op(A)[M][K] op(B)[K][N] (+ C if accumulate), row-major float32;
+ * op(A)(m, k) = trans_a ? A[k * lda + m] : A[m * lda + k], likewise B. */
+int zt_gemm_f32(const float *A_dev, const float *B_dev, float *C_dev, int64_t M, int64_t N,
+                int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int32_t trans_a,
+                int32_t trans_b, int32_t accumulate, void *stream);
+/* out[c] (+)= sum over rows of X[r][c] (bias gradients). */
+int zt_colsum_f32(const float *X_dev, int64_t rows, int64_t cols, int64_t ldx, float *out_dev,
+                  int32_t accumulate, void *stream);
+/* h_out[u] = GRUCell(messages[ids[u]], memory[ids[u]]) for the U rows ids (the
+ * lazily updated rows of get_updated_memory); saved [U][4 D] keeps r, z, n and
+ * W_hn h + b_hn for the backward.  workspace: zt_gru_train_workspace_bytes. */
+int64_t zt_gru_train_workspace_bytes(int64_t U, int32_t D, int32_t msg_dim);
+int zt_gru_train_forward(const float *messages_dev, const float *memory_dev,
+                         const int32_t *ids_dev, int64_t U, int32_t D, int32_t msg_dim,
+                         const zt_gru_weights *weights, float *h_out_dev, float *saved_dev,
+                         void *workspace_dev, void *stream);
+/* Gradients of the four GRU parameters from d_h [U][D] (written, not
+ * accumulated).  Messages and memory are buffers in the reference: they get
+ * no gradient.  workspace_dev must be the FORWARD call's workspace, untouched:
+ * it holds the gathered rows (the tables themselves change between forward
+ * and backward, model/tgn_model.py:155-168). */
+int zt_gru_train_backward(const float *d_h_dev, const float *messages_dev,
+                          const float *memory_dev, const int32_t *ids_dev, int64_t U,
+                          int32_t D, int32_t msg_dim, const float *saved_dev,
+                          float *d_w_ih_dev, float *d_w_hh_dev, float *d_b_ih_dev,
+                          float *d_b_hh_dev, void *workspace_dev, void *stream);
+
+/* ------------------------------------------------------------------------ */
 /* One batch as one call -- TGN.compute_temporal_embeddings, train=False      */
 /*   (model/tgn_model.py:124-174) for device-resident batches.  The reference */
 /*   issues these steps from Python on one stream (train.py:145-146); here     */

@@ -22,6 +22,7 @@ SOURCES = {
     "aggregate.hip": [],
     "aggregate_bwd.hip": [],
     "memory_update.hip": [],
+    "train_ops.hip": [],
     "attention.hip": [],
     "pipeline.hip": [],
     "test_hooks.hip": ["-ffp-contract=off"],

@@ -1,0 +1,271 @@
+// Training-side dense operators on exact-f32 MFMA: what the reference's autograd does with
+// nn.GRUCell and nn.Linear on the COMPACT rows of a training step --
+//   * the lazily updated memory of the selected neighbours, get_updated_memory (reference
+//     modules/memory_updater.py:61-90, nn.GRUCell :95-98): forward over the U flagged rows with the gate activations
+//     kept for the backward, backward to dW_ih, dW_hh, db_ih, db_hh (the memory and the stored messages are buffers of the
+//     reference, not parameters: no gradient flows into them);
+//   * fc2 and transform_source of GraphDiffusionEmbedding (modules/embedding_module.py:86-98,320-328) on [N, D]
+//     matrices: Y = X W^T (+ b) forward, dX = dY W, dW = dY^T X, db = column sums backward.
+// One small tiled GEMM kernel serves all of them (v_mfma_f32_16x16x4_f32: products and sums are float32 FMAs in k
+// order, so results agree with a float32 BLAS to rounding); the GRU's gate arithmetic is element-wise around it.
+// The neighbour aggregation itself (fc1 + ReLU + dropout + weighted k-reduction, forward and backward) is
+// aggregate.hip / aggregate_bwd.hip.
+#include "common.hpp"
+
+using namespace zt;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// C[M][N] = op(A)[M][K] op(B)[K][N] (+ C), row-major; op(A)(m, k) = TA ? A[k * lda + m] : A[m * lda + k], likewise B.
+// 64 x 64 tile per workgroup (4 waves, 32 x 32 each as 2 x 2 MFMA tiles), K in steps of 16 through LDS.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                  long long M, long long N, long long K, long long lda, long long ldb,
+                                                  long long ldc, int accumulate)
+{
+    __shared__ float As[64][17];      // [m][k]
+    __shared__ float Bs[16][65];      // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long m0 = (long long)blockIdx.y * 64, n0 = (long long)blockIdx.x * 64;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int idx = tid + t * 256;
+            // consecutive threads walk the contiguous dimension of the operand as it lies in memory
+            const int am = TA ? (idx & 63) : (idx >> 4), ak = TA ? (idx >> 6) : (idx & 15);
+            const long long gm = m0 + am, gk = k0 + ak;
+            As[am][ak] = (gm < M && gk < K) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : 0.f;
+            const int bn = TB ? (idx >> 4) : (idx & 63), bk = TB ? (idx & 15) : (idx >> 6);
+            const long long gn = n0 + bn, gk2 = k0 + bk;
+            Bs[bk][bn] = (gn < N && gk2 < K) ? (TB ? B[gn * ldb + gk2] : B[gk2 * ldb + gn]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[wm + i * 16 + r16][kk + g4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[kk + g4][wn + j * 16 + r16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long row = m0 + wm + i * 16 + g4 * 4 + r, col = n0 + wn + j * 16 + r16;
+                if (row < M && col < N) {
+                    float *c = C + row * ldc + col;
+                    *c = accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+}
+
+int gemm(const float *A, const float *B, float *C, long long M, long long N, long long K, long long lda, long long ldb,
+         long long ldc, bool ta, bool tb, bool accumulate, hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return ZT_OK;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    const int acc = accumulate ? 1 : 0;
+    if (ta && tb) k_gemm_f32<true, true><<<grid, 256, 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, acc);
+    else if (ta) k_gemm_f32<true, false><<<grid, 256, 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, acc);
+    else if (tb) k_gemm_f32<false, true><<<grid, 256, 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, acc);
+    else k_gemm_f32<false, false><<<grid, 256, 0, s>>>(A, B, C, M, N, K, lda, ldb, ldc, acc);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+// out[c] (+)= sum_r X[r][c]; one workgroup per 64 columns, rows strided over 4 waves
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ X, long long R, long long Cn, long long ldx,
+                                                float *__restrict__ out, int accumulate)
+{
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long c = (long long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < Cn)
+        for (long long r = wave; r < R; r += 4) s += X[r * ldx + c];
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < Cn) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+
+// rows ids[u] of a [*, W] table -> dense [U, W]
+__global__ void k_gather_rows_f32(const float *__restrict__ T, const int *__restrict__ ids, long long U, int W,
+                                  float *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= U * W) return;
+    const long long u = i / W;
+    out[i] = T[(long long)ids[u] * W + (i - u * W)];
+}
+
+// torch.nn.GRUCell's gate arithmetic: gi = W_ih x + b_ih, gh = W_hh h + b_hh (gate order r, z, n);
+// r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h.
+// saved[u] = [r | z | n | gh_n] for the backward.
+__global__ void k_gru_gates_fwd(const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ b_ih,
+                                const float *__restrict__ b_hh, const float *__restrict__ H, long long U, int D,
+                                float *__restrict__ h_out, float *__restrict__ saved)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= U * D) return;
+    const long long u = i / D;
+    const int c = (int)(i - u * D);
+    const float *gir = gi + u * 3 * D, *ghr = gh + u * 3 * D;
+    const float r = 1.f / (1.f + expf(-((gir[c] + b_ih[c]) + (ghr[c] + b_hh[c]))));
+    const float z = 1.f / (1.f + expf(-((gir[D + c] + b_ih[D + c]) + (ghr[D + c] + b_hh[D + c]))));
+    const float hn = ghr[2 * D + c] + b_hh[2 * D + c];
+    const float n = tanhf((gir[2 * D + c] + b_ih[2 * D + c]) + r * hn);
+    const float h = H[i];
+    h_out[i] = (1.f - z) * n + z * h;
+    float *sv = saved + u * 4 * D;
+    sv[c] = r; sv[D + c] = z; sv[2 * D + c] = n; sv[3 * D + c] = hn;
+}
+
+// d_gi = [dr_pre | dz_pre | dn_pre], d_gh = [dr_pre | dz_pre | dn_pre r] from d_h' (see k_gru_gates_fwd)
+__global__ void k_gru_gates_bwd(const float *__restrict__ dh, const float *__restrict__ saved, const float *__restrict__ H,
+                                long long U, int D, float *__restrict__ dgi, float *__restrict__ dgh)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= U * D) return;
+    const long long u = i / D;
+    const int c = (int)(i - u * D);
+    const float *sv = saved + u * 4 * D;
+    const float r = sv[c], z = sv[D + c], n = sv[2 * D + c], hn = sv[3 * D + c];
+    const float g = dh[i], h = H[i];
+    const float dn_pre = g * (1.f - z) * (1.f - n * n);
+    const float dz_pre = g * (h - n) * z * (1.f - z);
+    const float dr_pre = dn_pre * hn * r * (1.f - r);
+    float *a = dgi + u * 3 * D, *b = dgh + u * 3 * D;
+    a[c] = dr_pre; a[D + c] = dz_pre; a[2 * D + c] = dn_pre;
+    b[c] = dr_pre; b[D + c] = dz_pre; b[2 * D + c] = dn_pre * r;
+}
+
+struct GruTrainPlan {
+    size_t off_x, off_h, off_gi, off_gh, total;
+};
+
+void gru_train_plan(long long U, int D, int msg, GruTrainPlan &p)
+{
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t u = (size_t)(U > 0 ? U : 1);
+    p.off_x = take(u * msg * 4);
+    p.off_h = take(u * D * 4);
+    p.off_gi = take(u * 3 * D * 4);
+    p.off_gh = take(u * 3 * D * 4);
+    p.total = o;
+}
+
+}  // namespace
+
+extern "C" int zt_gemm_f32(const float *A_dev, const float *B_dev, float *C_dev, int64_t M, int64_t N, int64_t K, int64_t lda,
+                           int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t accumulate, void *stream)
+{
+    if (M < 0 || N < 0 || K < 0 || (M > 0 && N > 0 && (!C_dev || (K > 0 && (!A_dev || !B_dev))))) {
+        set_error("zt_gemm_f32: bad argument");
+        return ZT_ERR_ARG;
+    }
+    return gemm(A_dev, B_dev, C_dev, M, N, K, lda, ldb, ldc, trans_a != 0, trans_b != 0, accumulate != 0, (hipStream_t)stream);
+}
+
+extern "C" int zt_colsum_f32(const float *X_dev, int64_t rows, int64_t cols, int64_t ldx, float *out_dev, int32_t accumulate,
+                             void *stream)
+{
+    if (rows < 0 || cols < 0 || (cols > 0 && (!out_dev || (rows > 0 && !X_dev)))) { set_error("zt_colsum_f32: bad argument"); return ZT_ERR_ARG; }
+    if (cols == 0) return ZT_OK;
+    k_colsum<<<(unsigned)((cols + 63) / 64), 256, 0, (hipStream_t)stream>>>(X_dev, rows, cols, ldx, out_dev, accumulate != 0);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int64_t zt_gru_train_workspace_bytes(int64_t U, int32_t D, int32_t msg_dim)
+{
+    if (U < 0 || D <= 0 || msg_dim <= 0) return -1;
+    GruTrainPlan p;
+    gru_train_plan(U, D, msg_dim, p);
+    return (int64_t)p.total;
+}
+
+extern "C" int zt_gru_train_forward(const float *messages_dev, const float *memory_dev, const int32_t *ids_dev, int64_t U,
+                                    int32_t D, int32_t msg_dim, const zt_gru_weights *wt, float *h_out_dev, float *saved_dev,
+                                    void *workspace_dev, void *stream)
+{
+    if (!messages_dev || !memory_dev || !wt || U < 0 || D <= 0 || msg_dim <= 0 || (U > 0 && (!ids_dev || !h_out_dev || !saved_dev || !workspace_dev))) {
+        set_error("zt_gru_train_forward: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (U == 0) return ZT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    GruTrainPlan p;
+    gru_train_plan(U, D, msg_dim, p);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    float *X = reinterpret_cast<float *>(ws + p.off_x), *H = reinterpret_cast<float *>(ws + p.off_h);
+    float *gi = reinterpret_cast<float *>(ws + p.off_gi), *gh = reinterpret_cast<float *>(ws + p.off_gh);
+    k_gather_rows_f32<<<(unsigned)((U * msg_dim + 255) / 256), 256, 0, s>>>(messages_dev, ids_dev, U, msg_dim, X);
+    k_gather_rows_f32<<<(unsigned)((U * D + 255) / 256), 256, 0, s>>>(memory_dev, ids_dev, U, D, H);
+    int rc = gemm(X, wt->w_ih, gi, U, 3 * D, msg_dim, msg_dim, msg_dim, 3 * D, false, true, false, s);      // gi = X W_ih^T
+    if (rc != ZT_OK) return rc;
+    rc = gemm(H, wt->w_hh, gh, U, 3 * D, D, D, D, 3 * D, false, true, false, s);                            // gh = H W_hh^T
+    if (rc != ZT_OK) return rc;
+    k_gru_gates_fwd<<<(unsigned)((U * D + 255) / 256), 256, 0, s>>>(gi, gh, wt->b_ih, wt->b_hh, H, U, D, h_out_dev, saved_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int zt_gru_train_backward(const float *d_h_dev, const float *messages_dev, const float *memory_dev,
+                                     const int32_t *ids_dev, int64_t U, int32_t D, int32_t msg_dim, const float *saved_dev,
+                                     float *d_w_ih_dev, float *d_w_hh_dev, float *d_b_ih_dev, float *d_b_hh_dev,
+                                     void *workspace_dev, void *stream)
+{
+    if (!messages_dev || !memory_dev || U < 0 || D <= 0 || msg_dim <= 0 || !d_w_ih_dev || !d_w_hh_dev || !d_b_ih_dev || !d_b_hh_dev ||
+        (U > 0 && (!d_h_dev || !ids_dev || !saved_dev || !workspace_dev))) {
+        set_error("zt_gru_train_backward: bad argument");
+        return ZT_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (U == 0) {
+        ZT_HIP(hipMemsetAsync(d_w_ih_dev, 0, (size_t)3 * D * msg_dim * 4, s));
+        ZT_HIP(hipMemsetAsync(d_w_hh_dev, 0, (size_t)3 * D * D * 4, s));
+        ZT_HIP(hipMemsetAsync(d_b_ih_dev, 0, (size_t)3 * D * 4, s));
+        ZT_HIP(hipMemsetAsync(d_b_hh_dev, 0, (size_t)3 * D * 4, s));
+        return ZT_OK;
+    }
+    GruTrainPlan p;
+    gru_train_plan(U, D, msg_dim, p);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    float *X = reinterpret_cast<float *>(ws + p.off_x), *H = reinterpret_cast<float *>(ws + p.off_h);
+    float *dgi = reinterpret_cast<float *>(ws + p.off_gi), *dgh = reinterpret_cast<float *>(ws + p.off_gh);
+    // X and H are the rows the FORWARD gathered: the tables change between forward and backward (a training step
+    // updates the memory and stores new messages before loss.backward(), model/tgn_model.py:155-168), so the workspace
+    // of the forward call must be handed back untouched
+    (void)messages_dev; (void)memory_dev; (void)ids_dev;
+    k_gru_gates_bwd<<<(unsigned)((U * D + 255) / 256), 256, 0, s>>>(d_h_dev, saved_dev, H, U, D, dgi, dgh);
+    int rc = gemm(dgi, X, d_w_ih_dev, 3 * D, msg_dim, U, 3 * D, msg_dim, msg_dim, true, false, false, s);   // dW_ih = dgi^T X
+    if (rc != ZT_OK) return rc;
+    rc = gemm(dgh, H, d_w_hh_dev, 3 * D, D, U, 3 * D, D, D, true, false, false, s);                         // dW_hh = dgh^T H
+    if (rc != ZT_OK) return rc;
+    k_colsum<<<(unsigned)((3 * D + 63) / 64), 256, 0, s>>>(dgi, U, 3 * D, 3 * D, d_b_ih_dev, 0);
+    k_colsum<<<(unsigned)((3 * D + 63) / 64), 256, 0, s>>>(dgh, U, 3 * D, 3 * D, d_b_hh_dev, 0);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}

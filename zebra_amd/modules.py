@@ -231,6 +231,86 @@ def get_memory_updater(module_type, message_dimension, memory_dimension, device)
     return GRUMemoryUpdater(message_dimension, memory_dimension, device)
 
 
+def _gemm(a, b, m, n, k, lda, ldb, ta, tb, out=None, accumulate=False):
+    """out[m, n] = op(a)[m, k] op(b)[k, n] on f32 MFMA (zt_gemm_f32); a, b contiguous float32 CUDA tensors."""
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    check(lib().zt_gemm_f32(ptr(a), ptr(b), ptr(out), C.c_int64(m), C.c_int64(n), C.c_int64(k), C.c_int64(lda),
+                            C.c_int64(ldb), C.c_int64(n), C.c_int32(1 if ta else 0), C.c_int32(1 if tb else 0),
+                            C.c_int32(1 if accumulate else 0), stream_ptr()), "zt_gemm_f32")
+    return out
+
+
+class _HipLinear(torch.autograd.Function):
+    """y = x W^T (+ b) with forward and backward on the HIP GEMM (csrc/train_ops.hip): the nn.Linear layers that act
+    on [N, D] matrices in a training step (fc2, fc1_source, fc2_source; modules/embedding_module.py:86-98)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        w = w.contiguous()
+        n, k = x.shape
+        o = w.shape[0]
+        y = _gemm(x, w, n, o, k, k, k, False, True)                 # x [n, k] . w[o, k]^T
+        if b is not None:
+            y += b
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, k = x.shape
+        o = w.shape[0]
+        dx = _gemm(dy, w, n, k, o, o, k, False, False) if ctx.needs_input_grad[0] else None      # dy [n, o] . w [o, k]
+        dw = _gemm(dy, x, o, k, n, o, k, True, False) if ctx.needs_input_grad[1] else None       # dy^T [o, n] . x [n, k]
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(o, dtype=torch.float32, device=dy.device)
+            check(lib().zt_colsum_f32(ptr(dy), C.c_int64(n), C.c_int64(o), C.c_int64(o), ptr(db), C.c_int32(0), stream_ptr()),
+                  "zt_colsum_f32")
+        return dx, dw, db
+
+
+class _HipGruRows(torch.autograd.Function):
+    """overlay[u] = GRUCell(messages[ids[u]], memory[ids[u]]) -- the lazily updated rows of get_updated_memory
+    (modules/memory_updater.py:61-90) -- with the backward to the four GRU parameters on the HIP kernels
+    (zt_gru_train_forward / zt_gru_train_backward).  Messages and memory are buffers: no gradient flows into them."""
+
+    @staticmethod
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, messages, memory_t, ids32):
+        U, D, msg = int(ids32.numel()), memory_t.shape[1], messages.shape[1]
+        dev = memory_t.device
+        h = torch.empty((U, D), dtype=torch.float32, device=dev)
+        saved = torch.empty((U, 4 * D), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib().zt_gru_train_workspace_bytes(C.c_int64(U), C.c_int32(D), C.c_int32(msg))), dtype=torch.uint8,
+                         device=dev)
+        wt = _capi.GruWeights(ptr(w_ih.detach().contiguous()), ptr(w_hh.detach().contiguous()), ptr(b_ih.detach().contiguous()),
+                              ptr(b_hh.detach().contiguous()))
+        check(lib().zt_gru_train_forward(ptr(messages), ptr(memory_t), ptr(ids32), C.c_int64(U), C.c_int32(D), C.c_int32(msg),
+                                         C.byref(wt), ptr(h), ptr(saved), ptr(ws), stream_ptr()), "zt_gru_train_forward")
+        ctx.save_for_backward(saved, ids32)
+        ctx.misc = (messages, memory_t, ws, w_ih.shape, w_hh.shape)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        saved, ids32 = ctx.saved_tensors
+        messages, memory_t, ws, s_ih, s_hh = ctx.misc
+        U, D, msg = int(ids32.numel()), memory_t.shape[1], messages.shape[1]
+        dev = memory_t.device
+        d_w_ih = torch.empty(s_ih, dtype=torch.float32, device=dev)
+        d_w_hh = torch.empty(s_hh, dtype=torch.float32, device=dev)
+        d_b_ih = torch.empty(3 * D, dtype=torch.float32, device=dev)
+        d_b_hh = torch.empty(3 * D, dtype=torch.float32, device=dev)
+        check(lib().zt_gru_train_backward(ptr(dh.contiguous()), ptr(messages), ptr(memory_t), ptr(ids32), C.c_int64(U),
+                                          C.c_int32(D), C.c_int32(msg), ptr(saved), ptr(d_w_ih), ptr(d_w_hh), ptr(d_b_ih),
+                                          ptr(d_b_hh), ptr(ws), stream_ptr()), "zt_gru_train_backward")
+        return d_w_ih, d_w_hh, d_b_ih, d_b_hh, None, None, None
+
+
 class _NeighbourAggregate(torch.autograd.Function):
     """H[m][n] = sum_k w_k/sum(w) relu(fc1([memory'[nbr] | ef | cos(dt w)])), S[m][n] = (sum_k w != 0) with
     memory' = overlay rows where row_map says so (zt_agg_train_forward / zt_agg_train_backward)."""
@@ -554,7 +634,12 @@ class GraphDiffusionEmbedding(nn.Module):
             index = torch.unique(on.reshape(-1).long())
         ids = index[memory.flags[index] != 0]                                   # neighbours with a pending message
         U = int(ids.numel())
-        if U:
+        hip_dense = getattr(self, "fused_training", True)
+        if U and hip_dense:
+            g = memory_updater.memory_updater                                   # nn.GRUCell's parameters, HIP forward + backward
+            overlay = _HipGruRows.apply(g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh, memory.messages, memory.memory,
+                                        ids.to(torch.int32).contiguous())      # [U, D]
+        elif U:
             overlay = memory_updater.memory_updater(memory.messages[ids], memory.memory[ids])      # [U, D]
         else:
             overlay = torch.zeros((1, self.embedding_dimension), device=self.device)
@@ -565,7 +650,11 @@ class GraphDiffusionEmbedding(nn.Module):
             row_map[ids] = torch.arange(U, dtype=torch.int32, device=self.device)
             m = row_map[nodes_d.long()].long()
             src_rows = torch.where((m >= 0).unsqueeze(1), overlay[m.clamp(min=0)], src_rows)
-        embeddings = self.transform_source(src_rows)
+        if hip_dense:                                                           # transform_source on the HIP GEMM (:320-322)
+            embeddings = _HipLinear.apply(self.drop(self.act(_HipLinear.apply(src_rows, self.fc1_source.weight, self.fc1_source.bias))),
+                                          self.fc2_source.weight, self.fc2_source.bias)
+        else:
+            embeddings = self.transform_source(src_rows)
         fused = getattr(self, "fused_training", True) and self.embedding_dimension <= 128
         if fused:
             # the dropout of the hidden layer (self.drop, active in train mode) runs inside the kernels: a seed from
@@ -579,7 +668,7 @@ class GraphDiffusionEmbedding(nn.Module):
                 row_map[ids] = -1
             for m_ in range(self.n_tppr):
                 # fc2 is linear: sum_k w_k fc2(h_k) = fc2(sum_k w_k h_k) + b2 * [sum_k w_k != 0]
-                out = torch.nn.functional.linear(H[m_], self.fc2.weight) + self.fc2.bias * S[m_].unsqueeze(1)
+                out = _HipLinear.apply(H[m_], self.fc2.weight, None) + self.fc2.bias * S[m_].unsqueeze(1)
                 embeddings = torch.cat((embeddings, out), dim=1)
             return embeddings
         # dropout inside the neighbour transform: composed from torch ops on the same overlay
