@@ -6,6 +6,10 @@ accesses are uncalibrated, so the corrected read figure is an upper bound for th
 WRITE_SIZE is exact.
 
     python profiles/make_pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <last_n> <workload>
+                                        [<bench line of the profiled command (json)> [<commit>]]
+
+The summary records what it was measured on -- commit, prefill, batches per T-PPR launch, T-PPR CUs, edges per k_stream
+launch -- so that bench.py merges its `traffic` only into a line of the same launch shape.
 """
 import collections
 import csv
@@ -27,7 +31,16 @@ def main():
     fetch, write, last, workload = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, w = per_kernel(fetch, "FETCH_SIZE", last), per_kernel(write, "WRITE_SIZE", last)
     out = {"workload": workload, "launches_averaged": last, "unit": "bytes per launch", "kernels": {}}
-    names = {"k_stream": "tppr_stream", "k_fc1_agg_d100<20>": "fc1_agg", "k_fc1_agg_d100<40>": "fc1_agg", "k_fc1_agg_d100<10>": "fc1_agg",
+    if len(sys.argv) > 5:
+        line = [l for l in open(sys.argv[5]).read().splitlines() if l.startswith('{"metric"')]
+        if line:
+            d = json.loads(line[-1])
+            cfg = d.get("config", {})
+            out["measured_on"] = {"commit": sys.argv[6] if len(sys.argv) > 6 else None, "workload_line": cfg.get("workload"),
+                                  "tppr_launch_group": cfg.get("tppr_launch_group"), "tppr_cus": cfg.get("tppr_cus"),
+                                  "steps": d.get("steps"),
+                                  "edges_per_k_stream_launch": (d.get("roofline") or {}).get("edges_per_launch")}
+    names = {"k_stream": "tppr_stream", "k_fc1_agg_reg<20, 0>": "fc1_agg", "k_fc1_agg_reg<40, 0>": "fc1_agg", "k_fc1_agg_d100<20>": "fc1_agg", "k_fc1_agg_d100<40>": "fc1_agg", "k_fc1_agg_d100<10>": "fc1_agg",
              "k_fc1_agg<true>": "fc1_agg_generic", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
              "k_gru": "gru_update", "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass",
              "k_project_rows": "project_rows"}

@@ -18,7 +18,7 @@ def main():
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"workload": workload, "launches_averaged": last, "kernels": {}}
-    for k in ("k_stream", "k_fc1_agg_d100<20>", "k_fc1_agg_d100<40>", "k_fc1_agg_d100<10>", "k_fc1_agg<true>", "k_embed_out", "k_gru",
+    for k in ("k_stream", "k_fc1_agg_reg<20, 0>", "k_fc1_agg_reg<40, 0>", "k_fc1_agg_d100<20>", "k_fc1_agg_d100<40>", "k_fc1_agg_d100<10>", "k_fc1_agg<true>", "k_embed_out", "k_gru",
               "k_build_messages", "k_pruned_topk", "k_project_rows"):
         if k not in agg:
             continue
