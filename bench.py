@@ -451,7 +451,13 @@ def main():
         for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % a.workload)
             if os.path.isfile(pj):
-                pmc = json.load(open(pj)).get("kernels", {})
+                summ = json.load(open(pj))
+                pmc = summ.get("kernels", {})
+                # per-launch bytes of the T-PPR kernel belong to a launch SHAPE: a summary measured with another
+                # number of batches per launch says nothing about this run's launches
+                on = summ.get("measured_on") or {}
+                if on.get("tppr_launch_group") not in (None, a.group):
+                    pmc = {kk: vv for kk, vv in pmc.items() if kk != "tppr_stream"}
                 break
     ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
     af = algorithmic_flops(k, F, M)

@@ -39,7 +39,7 @@ def main():
             out["measured_on"] = {"commit": sys.argv[6] if len(sys.argv) > 6 else None, "workload_line": cfg.get("workload"),
                                   "tppr_launch_group": cfg.get("tppr_launch_group"), "tppr_cus": cfg.get("tppr_cus"),
                                   "steps": d.get("steps"),
-                                  "edges_per_k_stream_launch": (d.get("roofline") or {}).get("edges_per_launch")}
+                                  "edges_per_k_stream_launch": (cfg.get("tppr_launch_group") or 1) * (cfg.get("global_batch") or 0)}
     names = {"k_stream": "tppr_stream", "k_fc1_agg_reg<20, 0>": "fc1_agg", "k_fc1_agg_reg<40, 0>": "fc1_agg", "k_fc1_agg_d100<20>": "fc1_agg", "k_fc1_agg_d100<40>": "fc1_agg", "k_fc1_agg_d100<10>": "fc1_agg",
              "k_fc1_agg<true>": "fc1_agg_generic", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
              "k_gru": "gru_update", "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass",

@@ -729,7 +729,8 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
 
     // ---- once per launch: this lane's slice of the weights, the time frequencies and the biases ----
     // (the [112][K2p] matrix comes in through LDS, coalesced; 182 strided loads per lane straight from memory took 35 us)
-    extern __shared__ __attribute__((aligned(16))) float s_wt[];       // [DP][K2p], dead after this block
+    __shared__ __attribute__((aligned(16))) float s_wt[DP * 112];      // [DP][K2p = 112], dead after this block (static: 57 KB in
+                                                                       // all, below the 64 KB a launch gets without an attribute)
     for (int i = threadIdx.x; i < DP * K2p / 4; i += AGG_THREADS)
         reinterpret_cast<f32x4 *>(s_wt)[i] = reinterpret_cast<const f32x4 *>(W1t)[i];
     __syncthreads();
@@ -1372,7 +1373,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     }
     // register-resident kernel: D = T = 100, F + T <= 104, k in {20, 40} (ZT_AGG_REG=0: off)
     static const bool reg_ok = !(getenv("ZT_AGG_REG") && atoi(getenv("ZT_AGG_REG")) == 0);
-    const bool regk = reg_ok && tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p >= 4 * REG_NS &&
+    const bool regk = reg_ok && tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p == 112 &&
                       !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
     ZT_PROF_BEGIN(s, P_FC1_AGG);
     if (regk) {
@@ -1380,15 +1381,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         long long wgs = (tiles + AGG_WAVES - 1) / AGG_WAVES;
         const int cus = stream_cu_count(s);
         if (wgs > cus) wgs = cus;                                      // persistent: one workgroup (4 waves) per CU
-        const size_t reg_lds = (size_t)112 * p.K2p * 4;                 // the weight matrix, staged once per workgroup
-        static bool reg_attr = false;
-        if (!reg_attr) {
-            const void *fns[] = {reinterpret_cast<const void *>(k_fc1_agg_reg<20>), reinterpret_cast<const void *>(k_fc1_agg_reg<40>),
-                                 reinterpret_cast<const void *>(k_fc1_agg_reg<20, 1>), reinterpret_cast<const void *>(k_fc1_agg_reg<20, 2>),
-                                 reinterpret_cast<const void *>(k_fc1_agg_reg<20, 6>), reinterpret_cast<const void *>(k_fc1_agg_reg<20, 7>)};
-            for (const void *fn : fns) ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            reg_attr = true;
-        }
+        const size_t reg_lds = 0;
         static const int dbg = getenv("ZT_AGG_DBG") ? atoi(getenv("ZT_AGG_DBG")) : 0;       // diagnostic (wrong results)
 #define ZT_REG_DBG(DB) k_fc1_agg_reg<20, DB><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, \
             num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
