@@ -36,7 +36,8 @@ print("core clocks 10/50/90 %%: row arrived -> front half done %s ; -> ready to 
 print("inside the front half: arrival -> merge_front entered %s ; scales + matching + new key %s ; layout %s ; rank pass %s ; return %s" % (
     p(cc[:, 4] - cc[:, 0]), p(cc[:, 5] - cc[:, 4]), p(cc[:, 6] - cc[:, 5]), p(cc[:, 7] - cc[:, 6]), p(cc[:, 1] - cc[:, 7])))
 print("arrival -> row read from LDS %s ; -> split path entered %s ; -> front half called %s ; -> inside %s" % (p(cc[:, 8] - cc[:, 0]), p(cc[:, 9] - cc[:, 8]), p(cc[:, 10] - cc[:, 9]), p(cc[:, 4] - cc[:, 10])))
-print("front half taken: fast %d | partner side not prepared %d (hash clash %d, scale factors not predicted %d) | norm differs %d | key match %d | new key / NaN in the hub row %d | row not sorted %d | clash late %d" % tuple([int((cc[:, 11] == q).sum()) for q in (0, 1)] + [int(((cc[:, 11] == 1) & (cc[:, 12] == 2)).sum()), int(((cc[:, 11] == 1) & (cc[:, 13] == 0)).sum())] + [int((cc[:, 11] == q).sum()) for q in (2, 3, 4, 5, 6)]))
+print("front half taken: fast %d | partner side not prepared %d | norm differs %d | key match %d | new key / NaN in the hub row %d | row not sorted %d | clash late %d" % tuple([int((cc[:, 11] == q).sum()) for q in (0, 1, 2, 3, 4, 5, 6)]))
+print("front half done -> settled / redo checks %s ; -> ring slot free %s ; -> slots assigned %s ; -> set written %s" % (p(cc[:, 12] - cc[:, 1]), p(cc[:, 13] - cc[:, 12]), p(cc[:, 14] - cc[:, 13]), p(cc[:, 2] - cc[:, 14])))
 arr = c[idx][:, 0]; pub = c[idx][:, 3]
 g = (arr[1:] > 0) & (pub[:-1] > 0)
 print("publication(t-1) -> row arrived(t) [clocks of two different waves, same CU]: %s" % p((arr[1:] - pub[:-1])[g]))

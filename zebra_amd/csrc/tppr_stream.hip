@@ -2047,7 +2047,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     }
     CRIT(10);
 #ifdef ZT_CRIT
-    crit_t[11] = hub_sorted ? 0 : 5; crit_t[12] = pre_hash; crit_t[13] = pre_scale.valid ? 1 : 0;
+    crit_t[11] = hub_sorted ? 0 : 5;
 #endif
     if (!(hub_sorted && merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_hash == 3 || lenp == 0,
                                          pre_hash == 3, F CRIT_PASS))) {
@@ -2075,6 +2075,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             merge_front(L, lane, k, alpha, beta, rh, rp, nkey, tnow, F, 0, -1);
         }
     }
+    CRIT(12);
     const unsigned unc_in = settled ? 0u : hub_unc;              // provisional slots of the row as I used it
     c.key = F.key; c.ts = F.ts; c.w = F.w;
     const bool mine = (F.live >> lane) & 1ull;
@@ -2085,6 +2086,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     int munc_out = 0, nalt_out = 0;
     bool set_out = false, final_out = false;
     ring_free();
+    CRIT(13);
     if (F.mode == FR_NOPRUNE) {
         provslot = mine ? pos_prov : -1;                         // s1's entries keep their slots, and their doubts
         unc_out = unc_in;
@@ -2097,8 +2099,11 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         // slot p - drop (ascending by weight, members of a run of equal weights in whatever order the network put them:
         // "arbitrary" is all stage 1 promises); a slot is in doubt iff its run has another member.  A run that straddles
         // the cut has its members at positions >= drop in slots [0, j) -- the pick -- and the others are the alternates.
-        const u64 S = F.S;
-        const u64 nmask = ((u64)2 << (F.n - 1)) - 1ull;                         // positions 0 .. n-1 (n <= 63)
+        // (wave-uniform by construction: say so, or the 64-bit mask arithmetic below runs on the vector unit)
+        const u64 S = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(F.S >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)F.S);
+        const int n_u = __builtin_amdgcn_readfirstlane(F.n);
+        const u64 nmask = ((u64)2 << (n_u - 1)) - 1ull;                         // positions 0 .. n-1 (n <= 63)
         const u64 multi = (~S | ~(S >> 1)) & nmask;                             // position p shares its run with p-1 or with p+1
                                                                                 // (position n, the padding, always starts a run)
         provslot = (mine && F.sp >= drop) ? F.sp - drop : -1;
@@ -2145,6 +2150,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         unc_out = wave_or(ub);
         set_out = true;
     }
+    CRIT(14);
     if (set_out) {
         publish_set(provslot, n_new, new_norm, unc_out, munc_out, nalt_out, F.mode != FR_NOPRUNE ? 1 : 0);
         final_out = unc_out == 0u && munc_out == 0 && F.mode != FR_TIES && F.mode != FR_STRADDLE;
