@@ -1257,6 +1257,13 @@ static void embed_prepare(const zt_embed_weights *wt, int D, int F, int T, const
     pad(wt->fc1_w, K1, 0, D, p.off_wm, p.Dp);             // W_m: the memory columns of fc1 (k_project_rows)
 }
 
+const float *zt::embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
+{
+    EmbedPlan p;
+    if (!embed_ws || D > 128 || !make_plan(N > 0 ? N : 1, D, F, T, M, k, p)) return nullptr;
+    return reinterpret_cast<const float *>(reinterpret_cast<char *>(embed_ws) + p.off_wm);
+}
+
 extern "C" int64_t zt_project_table_bytes(int64_t num_nodes, int32_t D)
 {
     if (num_nodes <= 0 || D <= 0) return -1;

@@ -24,9 +24,10 @@ __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m *
 // ------------------------------------------------------------ last message ----
 __global__ void k_last_pos(const int *__restrict__ src, const int *__restrict__ dst,
                            const long long *__restrict__ eidx, long long B, long long num_nodes, long long num_edges,
-                           int *scratch, int *status)
+                           int *scratch, int *status, int *zero_word)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 && zero_word != nullptr) *zero_word = 0;      // (the row counter of the GRU update that follows on this stream)
     if (p >= 2 * B) return;
     const int v = p < B ? src[p] : dst[p - B];
     const long long e = eidx[p < B ? p : p - B];
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                                              const float *__restrict__ msg_ts, const int *__restrict__ rows,
                                              const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
                                              int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
-                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh)
+                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+                                             const float *__restrict__ Wm_p, float *__restrict__ P)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
@@ -219,6 +221,9 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     };
     part(Wih_p, Xp, 0, false);      // message part: gi = W_ih x
     part(Whh_p, Hp, Xp, true);      // memory part:  gh = W_hh h
+    // (the new rows go back into the tile for the projection below: every wave must be done READING the old ones -- the
+    //  memory columns are the K operand of everybody's W_hh product)
+    if (P != nullptr) __syncthreads();
     // gates (torch.nn.GRUCell): r,z = sigmoid(gi+gh); n = tanh(gi_n + r*gh_n); h' = (1-z)*n + z*h
 #pragma unroll
     for (int b = 0; b < GRU_NTW; ++b) {
@@ -237,12 +242,40 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                 const float z = 1.f / (1.f + expf(-(az[a][b][j] + biz + bhz)));
                 const float n = tanhf(ani[a][b][j] + bin + r * (anh[a][b][j] + bhn));
                 const float hold = A[(size_t)g * lda + Xp + col];
-                memory[(size_t)rid[g] * D + col] = (1.f - z) * n + z * hold;
+                const float hnew = (1.f - z) * n + z * hold;
+                memory[(size_t)rid[g] * D + col] = hnew;
+                if (P != nullptr) A[(size_t)g * lda + Xp + col] = hnew;    // (this thread alone reads and writes the element)
             }
     }
     for (int g = tid; g < nr; g += nthr) {
         const int v = rows[r0 + g];
         last_update[v] = msg_ts[v];                   // memory_updater.py:40
+    }
+    // ---- the projected table follows the rows just rewritten: P[v] = W_m memory'[v] (aggregate.hip, k_project_rows),
+    // ---- here from the new rows while they are still in LDS: one kernel and one pass over the rows less per step
+    if (P != nullptr) {
+        __syncthreads();                              // every column of the new rows is in the tile
+        if (wave < Hp / 16) {                         // wave w: output columns 16 w .. 16 w + 15
+            const int KC = Hp / 16;                   // <= 8 (D <= 128)
+            f32x4 wv[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                wv[c] = c < KC ? *reinterpret_cast<const f32x4 *>(Wm_p + (size_t)(wave * 16 + r16) * Hp + 16 * c + 4 * g4)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c >= KC) break;
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)r16 * lda + Xp + 16 * c + 4 * g4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[c][j], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = g4 * 4 + j;
+                if (g < nr) P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
+            }
+        }
     }
 }
 
@@ -354,6 +387,19 @@ extern "C" int zt_store_messages_range(const float *memory_dev, const float *las
                                        int32_t *scratch_dev, int32_t *uniq_ids_dev, int32_t *n_uniq_dev,
                                        int32_t *status_dev, void *stream)
 {
+    return zt::store_messages_ex(memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev,
+                                 ts_dev, eidx_dev, B, pos_lo, pos_hi, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev,
+                                 n_uniq_dev, status_dev, nullptr, stream);
+}
+
+// ... with one extra: *zero_word_dev = 0 by the first kernel (pipeline.hip: the GRU update's row counter, instead of a
+// memset node of its own between the two)
+int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev, const float *efeat_dev, const float *time_w_dev,
+                          int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,
+                          const int32_t *dst_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
+                          int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
+                          int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream)
+{
     if (B < 0 || D <= 0 || F < 0 || T < 0 || !status_dev) { set_error("zt_store_messages: bad argument"); return ZT_ERR_ARG; }
     if (B == 0) return ZT_OK;
     if (!memory_dev || !last_update_dev || !efeat_dev || !time_w_dev || !src_dev || !dst_dev || !ts_dev || !eidx_dev ||
@@ -366,7 +412,7 @@ extern "C" int zt_store_messages_range(const float *memory_dev, const float *las
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
     ZT_PROF_BEGIN(s, P_STORE_MSG);
     k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
-                                                               scratch_dev, status_dev);
+                                                               scratch_dev, status_dev, zero_word_dev);
     k_build_messages<<<(unsigned)((2 * B + 3) / 4), 256, 0, s>>>(
         memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
         B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi);
@@ -396,6 +442,17 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
                              int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids, const int32_t *n_ids_dev,
                              const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready, void *stream)
 {
+    return zt::gru_update_ex(memory_dev, last_update_dev, messages_dev, msg_ts_dev, flags_dev, num_nodes, D, msg_dim, ids_dev,
+                             n_ids, n_ids_dev, wt, workspace_dev, weights_ready, nullptr, nullptr, stream, false);
+}
+
+// zt_gru_update with the refresh of the projected table folded in (pipeline.hip): wm_p = W_m padded to [Dp][Dp]
+// (zt::embed_wm_ptr), proj_table = [num_nodes][Dp]; both NULL: plain zt_gru_update
+int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
+                      uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
+                      const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
+                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed)
+{
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
         set_error("zt_gru_update: bad argument");
@@ -413,7 +470,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     int *rows = reinterpret_cast<int *>(ws + p.off_rows);
     float *wih = reinterpret_cast<float *>(ws + p.off_wih);
     float *whh = reinterpret_cast<float *>(ws + p.off_whh);
-    ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    if (!counter_zeroed) ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
     ZT_PROF_BEGIN(s, P_GRU);
     k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
                                                                       rows, cnt);
@@ -429,7 +486,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
     }
     const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
     k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
-                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh);
+                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table);
     ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

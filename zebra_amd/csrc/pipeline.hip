@@ -427,16 +427,19 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         p->embed_ready = true;
     }
     // ---- P3: last messages of the endpoints at positions [pos_lo, pos_hi), GRU update, projected rows ----
-    rc = zt_store_messages_range(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
-                                 cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
-                                 d.scratch, nullptr, nullptr, d.status, p->main_s);
+    rc = zt::store_messages_ex(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
+                               cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
+                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->main_s);
     if (rc != ZT_OK) return rc;
     const int msg_dim = 2 * d.D + d.F + d.T;
-    rc = zt_gru_update(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                       nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, p->main_s);
+    // the refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace
+    const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
+                                                                     : nullptr;
+    rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
+                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true);
     if (rc != ZT_OK) return rc;
     p->gru_ready = true;
-    if (d.proj_table != nullptr) {
+    if (d.proj_table != nullptr && wm_p == nullptr) {
         char *gw = reinterpret_cast<char *>(d.gru_ws);
         rc = zt_project_memory(d.memory, d.num_nodes, d.D, d.F, d.T, &d.ew, 1,
                                reinterpret_cast<const int32_t *>(gw + zt_gru_rows_offset(d.D, msg_dim)),
