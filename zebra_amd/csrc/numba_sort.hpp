@@ -593,6 +593,163 @@ __device__ inline int topk_reg(double v, u64 live, int pos, int n, int k, SortLd
     return 4;
 }
 
+// ---------------------------------------------------------------------------
+// The same exact top-k for 64 < n <= 128 candidates (no NaN), two list positions per lane (p and p + 64): the
+// pruning strategy's candidate lists (width + width^2 = 110 states at width 10, depth 2).  Ranks (`lt`: strictly smaller
+// candidates, equal values <=> equal ranks) come from ONE pass of broadcast reads; if no tie reaches the kept ranks
+// the ranks are the answer; otherwise numba's quicksort is replayed on the ranks as in topk_ties_reg -- segment
+// bookkeeping in scalar registers, Hoare's pair swaps as the reversal of the swapped stops -- with the elements
+// (rank << 8 | candidate) of the two positions in registers between partitions and one round through LDS (write,
+// read) for the permutation of a partition.  Segments wholly below the cut are neither partitioned nor ordered.
+// Writes sel[0..k).  Returns 0 (ranks decided) or 5 (replay).  a, sel and S are LDS of this wave.
+// ---------------------------------------------------------------------------
+__device__ inline int topk_select_wave128(const double *a, int n, int k, int *sel, SortLds &S)
+{
+#define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
+    const int lane = lane_id();
+    const int drop = ZT_U(n - k);
+    const int p0 = lane, p1 = lane + WAVE;
+    const bool has0 = p0 < n, has1 = p1 < n;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const double v0 = has0 ? a[p0] : inf, v1 = has1 ? a[p1] : inf;
+    // ---- ranks: one broadcast read per candidate, two counters per lane ----
+    int lt0 = 0, lt1 = 0;
+    for (int q0 = 0; q0 < n; q0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) x[t] = a[(q0 + t) < n ? (q0 + t) : 0];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool in = (q0 + t) < n;
+            lt0 += (in && x[t] < v0) ? 1 : 0;
+            lt1 += (in && x[t] < v1) ? 1 : 0;
+        }
+    }
+    const bool keep0 = has0 && lt0 >= drop, keep1 = has1 && lt1 >= drop;
+    // tie-free among the kept <=> exactly k are kept and no two of them have the same rank
+    if (lane < k) sel[lane] = -1;
+    wave_sync();
+    if (keep0) sel[lt0 - drop] = p0;
+    if (keep1) sel[lt1 - drop] = p1;
+    wave_sync();
+    const bool clash = (keep0 && sel[lt0 - drop] != p0) || (keep1 && sel[lt1 - drop] != p1);
+    const bool plain = __popcll(__ballot(keep0)) + __popcll(__ballot(keep1)) == k && __ballot(clash) == 0ull;
+    wave_sync();
+    if (plain) return 0;
+    // ---- replay on the ranks ----
+    int *E = S.r, *stage = S.r2;
+    int e0 = (lt0 << 8) | p0, e1 = (lt1 << 8) | p1;            // (rank, candidate) at positions p0, p1
+    if (has0) { S.seg_lo[p0] = (short)1; S.seg_hi[p0] = (short)0; }      // finished segment of the position: none yet
+    if (has1) { S.seg_lo[p1] = (short)1; S.seg_hi[p1] = (short)0; }
+    unsigned pend_lo = 0u, pend_hi = 0u;                        // stack of pending segments, 16 bits each: lo | hi << 8
+    int depth = 0;
+    int lo = 0, hi = ZT_U(n - 1);
+    bool work = true;
+    auto finish = [&](int slo, int shi) {                       // [slo, shi]: fewer than 16 entries, reaches the cut
+        if (p0 >= slo && p0 <= shi) { S.seg_lo[p0] = (short)slo; S.seg_hi[p0] = (short)shi; }
+        if (p1 >= slo && p1 <= shi) { S.seg_lo[p1] = (short)slo; S.seg_hi[p1] = (short)shi; }
+    };
+    if (hi - lo < 15) { finish(lo, hi); work = false; }
+    const u64 below = lanemask_lt();
+    while (work) {
+        lo = ZT_U(lo); hi = ZT_U(hi);
+        const int mid = (lo + hi) >> 1;
+        auto at = [&](int pos) { return pos < WAVE ? __builtin_amdgcn_readlane(e0, pos) : __builtin_amdgcn_readlane(e1, pos - WAVE); };
+        int el = at(lo), em = at(mid), eh = at(hi);
+        if ((em >> 8) < (el >> 8)) { const int t = el; el = em; em = t; }
+        if ((eh >> 8) < (em >> 8)) { const int t = eh; eh = em; em = t; }
+        if ((em >> 8) < (el >> 8)) { const int t = el; el = em; em = t; }
+        const int pk = em >> 8;
+        e0 = p0 == lo ? el : (p0 == mid ? eh : (p0 == hi ? em : e0));   // pivot stashed at `hi`
+        e1 = p1 == lo ? el : (p1 == mid ? eh : (p1 == hi ? em : e1));
+        // ---- stops of the two scans over lo .. hi-1 ----
+        const bool in0 = p0 >= lo && p0 < hi, in1 = p1 >= lo && p1 < hi;
+        const u64 GE0 = __ballot(in0 && (e0 >> 8) >= pk), GE1 = __ballot(in1 && (e1 >> 8) >= pk);
+        const u64 LE0 = __ballot(in0 && (e0 >> 8) <= pk), LE1 = __ballot(in1 && (e1 >> 8) <= pk);
+        const bool ge0 = (GE0 >> lane) & 1ull, ge1 = (GE1 >> lane) & 1ull, le0 = (LE0 >> lane) & 1ull, le1 = (LE1 >> lane) & 1ull;
+        const int nJ = __popcll(LE0) + __popcll(LE1);
+        const int mi0 = __popcll(GE0 & below), mi1 = __popcll(GE0) + __popcll(GE1 & below);        // i-stops strictly below
+        const int lb0 = __popcll(LE0 & below), lb1 = __popcll(LE0) + __popcll(LE1 & below);        // j-stops strictly below
+        const int a_0 = mi0 + (ge0 ? 1 : 0), b_0 = nJ - lb0 - (le0 ? 1 : 0);
+        const int a_1 = mi1 + (ge1 ? 1 : 0), b_1 = nJ - lb1 - (le1 ? 1 : 0);
+        const u64 C0 = __ballot(in0 && a_0 >= b_0), C1 = __ballot(in1 && a_1 >= b_1);            // never both empty: b(hi-1) = 0
+        const int px = ZT_U(C0 ? __ffsll((long long)C0) - 1 : WAVE + __ffsll((long long)C1) - 1);
+        // i-stops below px, j-stops above px
+        const u64 bl0 = px < WAVE ? ((1ull << px) - 1ull) : ~0ull, bl1 = px < WAVE ? 0ull : ((1ull << (px - WAVE)) - 1ull);
+        const u64 at0 = px < WAVE ? (1ull << px) : 0ull, at1 = px < WAVE ? 0ull : (1ull << (px - WAVE));
+        const int a_prev = __popcll(GE0 & bl0) + __popcll(GE1 & bl1);
+        const int b_at = __popcll(LE0 & ~bl0 & ~at0) + __popcll(LE1 & ~bl1 & ~at1);
+        const int Sw = ZT_U(a_prev > b_at ? a_prev : b_at);                                        // swaps of this partition
+        // the swaps reverse the sequence of elements at the Sw lowest i-stops and the Sw highest j-stops
+        const int mj0 = nJ - 1 - lb0, mj1 = nJ - 1 - lb1;                                          // rank among the j-stops, from the top
+        const bool swi0 = ge0 && mi0 < Sw, swj0 = le0 && mj0 < Sw, swi1 = ge1 && mi1 < Sw, swj1 = le1 && mj1 < Sw;
+        const int t0 = swi0 ? mi0 : 2 * Sw - 1 - mj0, t1 = swi1 ? mi1 : 2 * Sw - 1 - mj1;
+        if (swi0 || swj0) stage[2 * Sw - 1 - t0] = e0;
+        if (swi1 || swj1) stage[2 * Sw - 1 - t1] = e1;
+        wave_sync();
+        if (swi0 || swj0) e0 = stage[t0];
+        if (swi1 || swj1) e1 = stage[t1];
+        // where the i-scan ends: the first i-stop that did not swap, or the lowest swapped j-stop, or `hi`
+        const u64 st0 = GE0 & ~__ballot(swi0), st1 = GE1 & ~__ballot(swi1), sj0 = __ballot(swj0), sj1 = __ballot(swj1);
+        int ifin = st0 ? __ffsll((long long)st0) - 1 : (st1 ? WAVE + __ffsll((long long)st1) - 1 : hi);
+        const int jl = sj0 ? __ffsll((long long)sj0) - 1 : (sj1 ? WAVE + __ffsll((long long)sj1) - 1 : 1 << 30);
+        ifin = ZT_U(jl < ifin ? jl : ifin);
+        wave_sync();                                            // the stage is rewritten by the next partition
+        const int x = at(ifin);
+        e0 = p0 == ifin ? em : e0; e1 = p1 == ifin ? em : e1;   // pivot <-> ifin
+        e0 = p0 == hi ? x : e0; e1 = p1 == hi ? x : e1;
+        if (ifin >= drop) finish(ifin, ifin);
+        // ---- children: only those reaching the kept ranks matter ----
+        const int lhi = ifin - 1, rlo = ifin + 1;
+        const bool lneed = lhi >= lo && lhi >= drop, rneed = hi >= rlo && hi >= drop;
+        const bool lpart = lneed && lhi - lo >= 15, rpart = rneed && hi - rlo >= 15;
+        if (lneed && !lpart) finish(lo, lhi);
+        if (rneed && !rpart) finish(rlo, hi);
+        if (lpart) {
+            if (rpart) {                                        // push the right child
+                pend_hi = (pend_hi << 16) | (pend_lo >> 16);
+                pend_lo = (pend_lo << 16) | (unsigned)(rlo | (hi << 8));
+                ++depth;
+            }
+            hi = lhi;
+        } else if (rpart) {
+            lo = rlo;
+        } else if (depth > 0) {
+            lo = (int)(pend_lo & 0xffu); hi = (int)((pend_lo >> 8) & 0xffu);
+            pend_lo = (pend_lo >> 16) | (pend_hi << 16);
+            pend_hi >>= 16;
+            --depth;
+        } else {
+            work = false;
+        }
+    }
+    // ---- stable rank inside every finished segment that reaches the cut (insertion sort with strict <) ----
+    if (has0) E[p0] = (e0 & ~0xff) | p0;                        // (rank, current position): p < 128 fits the low byte
+    if (has1) E[p1] = (e1 & ~0xff) | p1;
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int p = h ? p1 : p0, e = h ? e1 : e0;
+        if (p >= n) continue;
+        const int slo = S.seg_lo[p], shi = S.seg_hi[p];
+        if (shi < slo) continue;
+        const int cp = (e & ~0xff) | p;
+        int rank = 0;
+        for (int q0 = slo; q0 <= shi; q0 += 8) {                // segments hold at most 15 entries
+            int x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = E[(q0 + t) <= shi ? (q0 + t) : shi];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rank += ((q0 + t) <= shi && x[t] < cp) ? 1 : 0;
+        }
+        const int f = slo + rank;
+        if (f >= drop) sel[f - drop] = e & 0xff;
+    }
+    wave_sync();
+#undef ZT_U
+    return 5;
+}
+
 // Wave-cooperative top-k selection.  On return sel[0..k) holds the indices of
 // np.argsort(a)[-k:] in that order.  Requires n > k.  `a` and `sel` are LDS
 // arrays owned by this wave.  Returns the path taken: 0 = rank fast path (no
@@ -615,6 +772,11 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
             topk_ties_reg(lt, n, k, sel, S);
             return 4;
         }
+    }
+    if (n > WAVE && n <= 2 * WAVE) {
+        // two candidates per lane (the pruning strategy's lists)
+        const double w0 = lane < n ? a[lane] : 0.0, w1 = lane + WAVE < n ? a[lane + WAVE] : 0.0;
+        if (__ballot(w0 != w0 || w1 != w1) == 0ull) return topk_select_wave128(a, n, k, sel, S);
     }
     // rank counting: every candidate c (strided over lanes) counts smaller /
     // equal values; all lanes read a[q] at the same address (LDS broadcast).
