@@ -487,8 +487,9 @@ def main():
             note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
                     "per-node chains; the binding resource is hops x hop latency, not HBM")
         elif name == "pruned_topk":
-            byts = ab["p1"] * bs / shard                   # one launch per model
-            note = "CSR tail reads + output rows per query (binary-search probes not counted)"
+            # ONE launch serves all M models: the CSR tails are read once, every model writes its output rows
+            byts = (ab["p1"] - 48 * k + M * 48 * k) * bs / shard
+            note = "CSR tail reads (once for all models) + output rows per query and model (search probes not counted)"
         elif name == "gru_update":
             byts = 2 * (4 * (2 * 100 + F + 100) + 8 * 100 + 4) * bs / shard
             note = None

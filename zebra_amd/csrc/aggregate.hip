@@ -687,9 +687,8 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_fc1_agg_d100(
 //   * bias + ReLU + w / sum(w) and the reduction over the k neighbours of a query row happen in registers: k is a
 //     multiple of 4, so the 4 rows a lane holds of an M-tile belong to one query row; partial sums per (query
 //     row, N-tile) are combined across the four 16-lane groups with two cross-lane adds at the end of the tile.
-// Time encoding: every argument goes through the float64 reduction (time_cosf_rev): arguments beyond 4e6 (old
-// neighbours: dt is seconds) are everyday data at stream scale, and the seven float64 instructions hide behind the
-// matrix pipe like everything else.
+// Time encoding: every argument goes through time_cosf_rev (below), whose reduction is exact enough for any dt the
+// stream produces: arguments beyond 4e6 (old neighbours: dt is seconds) are everyday data at stream scale.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float time_cosf_rev(float x)
 {
