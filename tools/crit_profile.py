@@ -42,3 +42,20 @@ arr = c[idx][:, 0]; pub = c[idx][:, 3]
 g = (arr[1:] > 0) & (pub[:-1] > 0)
 print("publication(t-1) -> row arrived(t) [clocks of two different waves, same CU]: %s" % p((arr[1:] - pub[:-1])[g]))
 print("publication(t) - publication(t-1): %s   mean %.0f" % (p(np.diff(pub)[(pub[1:] > 0) & (pub[:-1] > 0)]), np.diff(pub)[(pub[1:] > 0) & (pub[:-1] > 0)].mean()))
+d = np.diff(pub); okd = (pub[1:] > 0) & (pub[:-1] > 0)
+q = len(d) // 4
+print("hop to hop by quarter of the chain (median, mean): " + " | ".join("%.0f %.0f" % (np.median(d[a:a + q][okd[a:a + q]]), d[a:a + q][okd[a:a + q]].mean()) for a in range(0, 4 * q, q)))
+sec = (c[idx][:, 3] - c[idx][:, 0]); oks = (c[idx][:, 3] > 0) & (c[idx][:, 0] > 0)
+print("critical section by quarter (median): " + " | ".join("%.0f" % np.median(sec[a:a + q][oks[a:a + q]]) for a in range(0, 4 * q, q)))
+lean = c[idx][:, 7] == 1
+cl = c[idx][lean]
+if len(cl):
+    print("lean hops %d of %d: preparation (dequeue -> ready to wait) %s ; slack (ready -> row arrived; small = the wave was late) %s ; critical section %s ; tail (published -> hop done) %s ; whole hop %s" % (
+        len(cl), len(idx), p(cl[:, 5] - cl[:, 4]), p(cl[:, 0] - cl[:, 5]), p(cl[:, 3] - cl[:, 0]), p(cl[:, 6] - cl[:, 3]), p(cl[:, 6] - cl[:, 4])))
+    print("  mean: preparation %.0f, critical %.0f, tail %.0f, whole %.0f; late arrivals (slack < 300): %d" % ((cl[:, 5] - cl[:, 4]).mean(), (cl[:, 3] - cl[:, 0]).mean(), (cl[:, 6] - cl[:, 3]).mean(), (cl[:, 6] - cl[:, 4]).mean(), int(((cl[:, 0] - cl[:, 5]) < 300).sum())))
+ci = c[idx]
+dd = np.diff(ci[:, 3]); slow = np.where(dd > 4000)[0] + 1
+print("slow hops (> 4000 clocks after their predecessor's publication): %d, sum of their excess over the median %.0f clocks" % (len(slow), (dd[slow - 1] - np.median(dd)).sum()))
+for t in slow[:40]:
+    r = ci[t]
+    print("  t=%3d lean=%d fallback=%d  hop %6d  hand-off %6d  critical %6d  ready->arrival %7d  prep %6d" % (t, r[7] == 1, r[11], dd[t - 1], r[0] - ci[t - 1][3], r[3] - r[0], r[0] - r[5], r[5] - r[4]))

@@ -566,19 +566,36 @@ __device__ __forceinline__ unsigned load_row(const zt_tppr &h, int m, long long 
 {
     return load_row_at(h.rows + ((long long)m * h.N + x) * h.rg, h.k, lane, expect, r);
 }
-__device__ __forceinline__ unsigned load_row_at(const u64 *base, int k, int lane, unsigned expect, Row &r)
+// The granules of a row as they come from memory: load_row_issue starts the loads, row_from_raw (which waits for them)
+// unpacks and checks the tags -- apart, so that a chain wave can have the partner's row of its NEXT hop on its way
+// while it finishes the current one.
+struct RawRow {
+    u64 g0, g1, g2, g3, g4, g5, gh;
+};
+__device__ __forceinline__ void load_row_issue(const u64 *base, int k, int lane, RawRow &q)
 {
-    u64 g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0, gh = 0;
-    if (lane < 3) gh = ld_agent(base + lane);
+    q.g0 = q.g1 = q.g2 = q.g3 = q.g4 = q.g5 = q.gh = 0;
+    if (lane < 3) q.gh = ld_agent(base + lane);
     if (lane < k) {
         const u64 *e = base + HDR + lane;
-        g0 = ld_agent(e);
-        g1 = ld_agent(e + k);
-        g2 = ld_agent(e + 2 * k);
-        g3 = ld_agent(e + 3 * k);
-        g4 = ld_agent(e + 4 * k);
-        g5 = ld_agent(e + 5 * k);
+        q.g0 = ld_agent(e);
+        q.g1 = ld_agent(e + k);
+        q.g2 = ld_agent(e + 2 * k);
+        q.g3 = ld_agent(e + 3 * k);
+        q.g4 = ld_agent(e + 4 * k);
+        q.g5 = ld_agent(e + 5 * k);
     }
+}
+__device__ __forceinline__ unsigned row_from_raw(const RawRow &q, int k, int lane, unsigned expect, Row &r);
+__device__ __forceinline__ unsigned load_row_at(const u64 *base, int k, int lane, unsigned expect, Row &r)
+{
+    RawRow q;
+    load_row_issue(base, k, lane, q);
+    return row_from_raw(q, k, lane, expect, r);
+}
+__device__ __forceinline__ unsigned row_from_raw(const RawRow &q, int k, int lane, unsigned expect, Row &r)
+{
+    const u64 g0 = q.g0, g1 = q.g1, g2 = q.g2, g3 = q.g3, g4 = q.g4, g5 = q.g5, gh = q.gh;
     const unsigned h0 = (unsigned)__shfl((unsigned)gh, 0), h1 = (unsigned)__shfl((unsigned)gh, 1),
                    h2 = (unsigned)__shfl((unsigned)gh, 2);
     r.len = (int)h0;
@@ -809,6 +826,7 @@ struct Front {
 // EXPECTS while it waits for the mailbox; merge_front takes them if the norm that arrives is that one.
 struct PreScale {
     double norm, scale_s1, scale_s2;
+    double norm_next;  // norm * beta + beta
     bool valid;
 };
 
@@ -1038,39 +1056,50 @@ __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u
     B.ok = true;
 }
 
-// partner of this lane at distance D (lane ^ D) for one 32-bit register
+// One compare-exchange stage of the bitonic merge on (weight, home lane): of the lanes i and i ^ D the lower keeps the
+// smaller weight, the upper the larger; equal weights stay where they are.  The vector unit issues one instruction
+// every four cycles or so for the wave that holds the chain, so the stage is written for instruction count:
+//   D = 32, 16: v_permlane32/16_swap of a register with its own copy leaves BOTH members of every pair in both lanes
+//               (X = the lower member, Y = the upper one): one compare, the mask flipped for the upper lanes on the
+//               scalar unit, three selects;
+//   D < 16    : the partner's value comes by DPP (row_ror:8, bank-masked row_shl/shr:4, quad_perm); ONE compare: a
+//               pair exchanges iff the lower lane sees a smaller partner, and the upper lane's decision is the same
+//               bit, shifted by D on the scalar unit.
+// __builtin_amdgcn_inverse_ballot_w64 turns the uniform mask into a lane predicate without an instruction.
 template <int D>
-__device__ __forceinline__ int xor_lane(int v, int lane)
+__device__ __forceinline__ int dpp_xor(int v)
 {
-    if (D == 32) {
-        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);     // [0] = low half twice, [1] = high half twice
-        return lane < 32 ? r[1] : r[0];
-    } else if (D == 16) {
-        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);     // [0] = rows 0,0,2,2   [1] = rows 1,1,3,3
-        return (lane & 16) ? r[0] : r[1];
-    } else if (D == 8) {
-        return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);        // row_ror:8
-    } else if (D == 4) {
-        int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);       // row_shl:4 into banks 0, 2 (lane i <- i + 4)
-        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);        // row_shr:4 into banks 1, 3 (lane i <- i - 4)
-    } else if (D == 2) {
-        return __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false);         // quad_perm [2,3,0,1]
-    } else {
-        return __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
-    }
+    if (D == 8) return __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);           // row_ror:8
+    if (D == 2) return __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, true);            // quad_perm [2,3,0,1]
+    if (D == 1) return __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, true);            // quad_perm [1,0,3,2]
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);         // row_shl:4 into banks 0, 2 (lane i <- i + 4)
+    return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xf, 0xa, false);                // row_shr:4 into banks 1, 3 (lane i <- i - 4)
 }
 
-// one stage of the bitonic merge: the lower lane of a pair keeps the smaller weight, the upper one the larger
 template <int D>
-__device__ __forceinline__ void merge_stage(int lane, double &w, int &id)
+__device__ __forceinline__ void merge_stage(double &w, int &id)
 {
     const long long wb = __double_as_longlong(w);
-    const int plo = xor_lane<D>((int)(unsigned)(wb & 0xffffffffll), lane), phi = xor_lane<D>((int)(wb >> 32), lane);
-    const int pid = xor_lane<D>(id, lane);
-    const double pw = __longlong_as_double(((long long)phi << 32) | (unsigned)plo);
-    const bool take = (lane & D) ? (w < pw) : (pw < w);
-    w = take ? pw : w;
-    id = take ? pid : id;
+    const int lo = (int)(unsigned)(wb & 0xffffffffll), hi = (int)(wb >> 32);
+    if (D >= 16) {
+        const auto rl = D == 32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = D == 32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const auto ri = D == 32 ? __builtin_amdgcn_permlane32_swap(id, id, false, false) : __builtin_amdgcn_permlane16_swap(id, id, false, false);
+        const double X = __longlong_as_double(((long long)rh[0] << 32) | (unsigned)rl[0]);
+        const double Y = __longlong_as_double(((long long)rh[1] << 32) | (unsigned)rl[1]);
+        const u64 U = D == 32 ? 0xffffffff00000000ull : 0xffff0000ffff0000ull;       // the upper lanes of the pairs
+        const bool take_y = __builtin_amdgcn_inverse_ballot_w64(__ballot(Y < X) ^ U);   // lower: the minimum, upper: the maximum
+        w = take_y ? Y : X;
+        id = take_y ? ri[1] : ri[0];
+    } else {
+        const int plo = dpp_xor<D>(lo), phi = dpp_xor<D>(hi), pid = dpp_xor<D>(id);
+        const double pw = __longlong_as_double(((long long)phi << 32) | (unsigned)plo);
+        const u64 U = D == 8 ? 0xff00ff00ff00ff00ull : D == 4 ? 0xf0f0f0f0f0f0f0f0ull : D == 2 ? 0xccccccccccccccccull : 0xaaaaaaaaaaaaaaaaull;
+        const u64 ex = __ballot(pw < w) & ~U;                                        // lower lanes whose pair exchanges
+        const bool take = __builtin_amdgcn_inverse_ballot_w64(ex | (ex << D));
+        w = take ? pw : w;
+        id = take ? pid : id;
+    }
 }
 
 __device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &r1, const Row &r2, const PreB &B,
@@ -1088,18 +1117,23 @@ __device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &
     const bool in1 = lane < n1;
     const double w1 = r1.w * ps.scale_s1;                       // t_s1_PPR[key] = value * scale_s1
     const int len2 = B.len2;
-    if (len2 > 0 && n1 > 0) {
-        if (!table_ready) { FAILC(6); return false; }            // (slot collision among the partner's keys: general path)
-        const int cand = in1 ? L.htab[hash2 ? key_hash2(r1.key) : key_hash(r1.key)] : -1;
-        if (__ballot(cand >= 0) != 0ull) {                      // an occupied slot: compare the keys in full
+    const bool probe = len2 > 0 && n1 > 0;
+    if (probe && !table_ready) { FAILC(6); return false; }          // (slot collision among the partner's keys: general path)
+    // is a key of the hub's row in the partner's row?  The table read is issued here and looked at AFTER the merge network
+    // (verify): its LDS round trip hides behind the network, whose result is thrown away in the rare case of a match
+    const int cand = (probe && in1) ? L.htab[hash2 ? key_hash2(r1.key) : key_hash(r1.key)] : -1;
+    auto verify = [&]() -> bool {
+        bool bad = in1 && ((r1.key == newkey && r1.ts == newts) || w1 != w1);
+        if (__ballot(cand >= 0) != 0ull) {                       // an occupied slot: compare the keys in full
             const int src = cand >= 0 ? cand : 0;
             const u64 kj = __shfl(r2.key, src);
             const double tj = __shfl(r2.ts, src);
-            if (__ballot(in1 && cand >= 0 && kj == r1.key && tj == r1.ts) != 0ull) { FAILC(3); return false; }   // a real match
+            bad = bad || (in1 && cand >= 0 && kj == r1.key && tj == r1.ts);          // a real match
         }
-    }
-    if (__ballot(in1 && ((r1.key == newkey && r1.ts == newts) || w1 != w1)) != 0ull) { FAILC(4); return false; }
-    if (len2 > 0 && n1 > 0 && lane < len2) L.htab[B.h2] = -1;    // the table is clean again (merge_front does the same)
+        if (__ballot(bad) != 0ull) { FAILC(3); return false; }  // (the table stays as it is: merge_front uses it)
+        if (probe && lane < len2) L.htab[B.h2] = -1;             // the table is clean again (merge_front does the same)
+        return true;
+    };
     CRITP(5);
     const int nb = B.nb, n = n1 + nb;
     F.key = lane < 32 ? r1.key : B.cb_key;
@@ -1110,23 +1144,23 @@ __device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &
     F.pos_tail = lane < 32 ? lane : n1 + (lane - 32);           // place in the reference's dictionary order
     F.lt = 0; F.keep = false; F.touched = 0ull; F.claimed = 0u;
     F.fast = false; F.sp = -1; F.S = 0ull;
-    if (n <= k) { F.mode = FR_NOPRUNE; return true; }
+    if (n <= k) { F.mode = FR_NOPRUNE; return verify(); }
     CRITP(6);
     // ---- bitonic merge of (weight, home lane): hub entries ascending in lanes [0, n1), +inf up to lane 31 ----
     double sw = lane < 32 ? (in1 ? w1 : __longlong_as_double(0x7ff0000000000000ll)) : B.sw;
     int sid = lane < 32 ? lane : B.sid;
-    merge_stage<32>(lane, sw, sid);
-    merge_stage<16>(lane, sw, sid);
-    merge_stage<8>(lane, sw, sid);
-    merge_stage<4>(lane, sw, sid);
-    merge_stage<2>(lane, sw, sid);
-    merge_stage<1>(lane, sw, sid);
+    merge_stage<32>(sw, sid);
+    merge_stage<16>(sw, sid);
+    merge_stage<8>(sw, sid);
+    merge_stage<4>(sw, sid);
+    merge_stage<2>(sw, sid);
+    merge_stage<1>(sw, sid);
     // ---- runs of equal weights: a run starts where a lane differs from its left neighbour ----
     const long long swb = __double_as_longlong(sw);
-    const int llo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const int lhi = __builtin_amdgcn_update_dpp(0, (int)(swb >> 32), 0x138, 0xf, 0xf, false);
+    const int llo = __builtin_amdgcn_mov_dpp((int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, true);   // wave_shr:1 (lane 0: 0)
+    const int lhi = __builtin_amdgcn_mov_dpp((int)(swb >> 32), 0x138, 0xf, 0xf, true);
     const double left = __longlong_as_double(((long long)lhi << 32) | (unsigned)llo);
-    const u64 S = __ballot(lane == 0 || left != sw);
+    const u64 S = __ballot(left != sw) | 1ull;
     // number of strictly smaller candidates of the candidate at sorted lane p = lane of its run's start
     const u64 below = S & (((u64)2 << lane) - 1ull);            // run starts at or below this lane (never empty: bit 0)
     const int rs = 63 - __builtin_clzll(below);
@@ -1142,7 +1176,7 @@ __device__ inline bool merge_front_fast(WaveLds &L, int lane, int k, const Row &
     F.claimed = claimed;
     F.mode = full ? (claimed == (1u << k) - 1u ? FR_RANKS : FR_TIES) : FR_STRADDLE;
     CRITP(7);
-    return true;
+    return verify();
 }
 
 // The ORDER half: posA = dictionary position of this lane's s1 entry (lanes < n1).  Returns the slot of this
@@ -1348,16 +1382,36 @@ struct MailSlot {
     u64 key2[32];      // stage 2: keys / timestamps in dictionary order (the weights by slot are those of stage 1)
     double ts2[32];
     u64 alt_key[32];   // stage 1: the members of a straddling run that were NOT picked (see munc)
-    double norm;
-    int len;
-    unsigned unc;      // stage 1: bit s = the entry at provisional slot s may sit elsewhere in its run of equal weights
-    int munc;          // stage 1: slots [0, munc) hold a PICK of munc members out of a run of munc + n_alt equal
-    int n_alt;         //          weights that straddles the cut; which members stay is settled by the replay
-    int sorted;        // stage 1: the arrangement is ascending by weight (every pruned row; not a row that was never full)
+    // the header of stage 1 in ONE 16-byte word (one LDS instruction to write, one to read):
+    //   norm; meta = len | munc << 8 | n_alt << 16 | sorted << 24; unc
+    //   unc   : bit s = the entry at provisional slot s may sit elsewhere in its run of equal weights
+    //   munc  : slots [0, munc) hold a PICK of munc members out of a run of munc + n_alt equal weights that straddles
+    //           the cut; which members stay is settled by the replay
+    //   sorted: the arrangement is ascending by weight (every pruned row; not a row that was never full)
+    alignas(16) double norm;
+    unsigned meta;
+    unsigned unc;
     int seq_set;       // written last of stage 1
     int seq_ord;       // written last of stage 2
     int seq_free;      // = position of the READER once it is done with both stages: the slot may be rewritten
 };
+typedef unsigned mail_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mail_hdr_read(const MailSlot *sl, double &norm, int &len, unsigned &unc, int &munc, int &n_alt, int &sorted)
+{
+    const mail_v4u v = *reinterpret_cast<const mail_v4u *>(&sl->norm);
+    norm = __longlong_as_double((long long)(((u64)v.y << 32) | v.x));
+    len = (int)(v.z & 0xffu); munc = (int)((v.z >> 8) & 0xffu); n_alt = (int)((v.z >> 16) & 0xffu); sorted = (int)(v.z >> 24);
+    unc = v.w;
+}
+__device__ __forceinline__ void mail_hdr_write(MailSlot *sl, double norm, int len, unsigned unc, int munc, int n_alt, int sorted)
+{
+    const u64 nb = (u64)__double_as_longlong(norm);
+    mail_v4u v;
+    v.x = (unsigned)nb; v.y = (unsigned)(nb >> 32);
+    v.z = (unsigned)len | ((unsigned)munc << 8) | ((unsigned)n_alt << 16) | ((unsigned)sorted << 24);
+    v.w = unc;
+    *reinterpret_cast<mail_v4u *>(&sl->norm) = v;
+}
 struct Mail {
     MailSlot slot[MAIL_R];
     int head;          // next position of the chain's edge list
@@ -1602,12 +1656,8 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
 #endif
         // one batch of LDS reads: the row, its provisional marks, and whether my own ring slot is free again
         Row rm;
-        rm.len = in_slot->len; rm.norm = in_slot->norm;
+        mail_hdr_read(in_slot, rm.norm, rm.len, hub_unc, hub_munc, hub_nalt, hub_sorted);
         rm.key = in_slot->key[lane & 31]; rm.ts = in_slot->ts[lane & 31]; rm.w = in_slot->w[lane & 31];
-        hub_unc = in_slot->unc;
-        hub_munc = in_slot->munc;
-        hub_nalt = in_slot->n_alt;
-        hub_sorted = in_slot->sorted;
         hub_alt = in_slot->alt_key[lane & 31];
         free_seen = lds_load_seq(&out_slot->seq_free);
         if (hub_is_u) ru = rm; else rv = rm;
@@ -1680,10 +1730,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         };
         auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc = 0u, int munc = 0, int n_alt = 0, int sorted = 0) {
             if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
-            if (lane == 0) {
-                out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt;
-                out_slot->sorted = sorted;
-            }
+            if (lane == 0) mail_hdr_write(out_slot, new_norm, n, unc, munc, n_alt, sorted);
         };
         auto publish_seq = [&](bool set, bool ord) {
             // The mailbox lives in LDS and a wave's LDS instructions execute in program order: the sequence word, issued
@@ -1899,22 +1946,28 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
 // role, no third row, no emission: what is left between the arrival of the row and the publication of the new kept set
 // is the chain's critical path, and every scalar branch and register move on it is paid 200 times per batch.
 // Returns false when the hop is not of this kind (first hop, another writer in between, self-loop): process_edge takes it.
+// What a hop needs to know about its edge besides the rows, gathered ONCE per launch by the whole chain workgroup into
+// LDS (k_stream): from memory these are three levels of dependent loads (edge -> endpoints -> writer ordinals / reader
+// flags) at the start of every hop's preparation.
+struct HopRec {
+    int partner;       // the other endpoint (-1: self-loop)
+    int wo_h, wo_p;    // ordinal of the last earlier writer of the hub / of the partner (the tags to expect)
+    int pf_h;          // a reader of the hub's row that must be done before this hop may store it (-1: none)
+    int wo_prev;       // the same ordinal at the chain's previous edge
+    int wo_next, pf_next;   // ... and at its next edge (-1: there is none)
+};
+
 __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
-                                 long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint, int chain_idx)
+                                 long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint, int chain_idx,
+                                 const HopRec &rec)
 {
     if (prev_edge < 0 || h.k > 31) return false;
-    const int k = h.k, B = A.B;
+    const int k = h.k;
     const int m = A.m_lo + mo;
-    const long long role_stride = A.role_stride;
-    const long long u = A.nodes[i], v = A.nodes[role_stride + i];
-    if (u == v) return false;
-    const int role_h = u == hub ? 0 : 1, role_p = 1 - role_h;
-    const long long pnode = role_h == 0 ? v : u;
-    const int wo_h = h.wo[role_h * B + i], wo_p = h.wo[role_p * B + i];
-    {
-        const int prole = A.nodes[prev_edge] == hub ? 0 : 1;
-        if (h.wo[prole * B + prev_edge] + 1 != wo_h) return false;          // somebody else wrote the hub in between
-    }
+    if (rec.partner < 0) return false;
+    const long long pnode = rec.partner;
+    const int wo_h = rec.wo_h, wo_p = rec.wo_p;
+    if (rec.wo_prev + 1 != wo_h) return false;                                // somebody else wrote the hub in between
     const double alpha = h.alpha[m], beta = h.beta[m];
     unsigned *done = h.done + (long long)m * MAX_CHUNK;
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS, vtag = tag_base | 1u;
@@ -1922,21 +1975,23 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     long long crit_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     int wl_fail = 0;
+    CRIT(4);
     // a reader of the hub's row in memory that precedes this edge must have read it before this hop may store there
-    const int pf_h = h.pflag[role_h * B + i];
-    if (pf_h >= 0 && !wait_flag(done + pf_h, epoch, h.ctl + 2, pf_h)) wl_fail |= 1;
-    const double tnow = A.tsv[i];
-    const long long e = A.eidx[i];
-    bool hub_to_memory = true, next_by_mail = false;                        // see process_edge
-    if (next_edge >= 0) {
-        const int nrole = A.nodes[next_edge] == hub ? 0 : 1;
-        next_by_mail = h.wo[nrole * B + next_edge] == wo_h + 1;
-        hub_to_memory = !(next_by_mail && h.pflag[nrole * B + next_edge] < 0);
-    }
     // ---- the partner's row from memory (poll where a writer of this launch precedes us) ----
     Row rp;
     const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u;
-    if (load_row(h, m, pnode, lane, ptag, rp) != ptag)
+    RawRow praw;
+    load_row_issue(h.rows + ((long long)m * h.N + pnode) * h.rg, k, lane, praw);     // on its way while the rest is looked up
+    const double tnow = A.tsv[i];
+    const long long e = A.eidx[i];
+    const int pf_h = rec.pf_h;
+    if (pf_h >= 0 && !wait_flag(done + pf_h, epoch, h.ctl + 2, pf_h)) wl_fail |= 1;
+    bool hub_to_memory = true, next_by_mail = false;                        // see process_edge
+    if (next_edge >= 0) {
+        next_by_mail = rec.wo_next == wo_h + 1;
+        hub_to_memory = !(next_by_mail && rec.pf_next < 0);
+    }
+    if (row_from_raw(praw, k, lane, ptag, rp) != ptag)
         if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
     MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
@@ -1965,6 +2020,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         if (pn != 0.0) {
             const double nn = pn * beta + beta;
             pre_scale.norm = pn;
+            pre_scale.norm_next = nn;
             pre_scale.scale_s1 = pn / nn * beta;
             pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
             pre_scale.valid = true;
@@ -1974,9 +2030,10 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     PreB pre_b;
     pre_b.ok = false;
     if (pre_hash != 2) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b, h2slot);
-    // the rows that come from memory have arrived: the partner task may store the partner's new row
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the partner's row has arrived (its tags were looked at): the partner task may store the partner's new row.  (No
+    // s_waitcnt vmcnt(0) here: it would also wait for the write-through stores of this wave's previous hop.)
     st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
+    CRIT(5);
     // waves whose turn is two or more hops away doze (see process_edge)
     if (tpos >= 2) {
         const int *far = &mail->slot[(tpos - 2) % MAIL_R].seq_set;
@@ -1989,18 +2046,19 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
     __builtin_amdgcn_s_setprio(3);
     CRIT(0);
-    // ---- the hub's row: one batch of LDS reads ----
     Row rh;
-    rh.len = in_slot->len; rh.norm = in_slot->norm;
-    rh.key = in_slot->key[lane & 31]; rh.ts = in_slot->ts[lane & 31]; rh.w = in_slot->w[lane & 31];
-    unsigned hub_unc = in_slot->unc;
-    int hub_munc = in_slot->munc, hub_nalt = in_slot->n_alt;
-    const u64 hub_alt = in_slot->alt_key[lane & 31];
-    const int hub_sorted = in_slot->sorted;
-    const int free_seen = lds_load_seq(&out_slot->seq_free);
-    bool hub_ordered = hub_unc == 0u && hub_munc == 0, hub_final = hub_ordered;
+    unsigned hub_unc = 0u;
+    int hub_munc = 0, hub_nalt = 0, hub_sorted = 0;
+    u64 hub_alt = 0ull;
+    int free_seen = 0;
+    bool hub_ordered = false, hub_final = false;
     int hub_pos = lane;
-    CRIT(8);
+    Front F;
+    Cand c;
+    double new_norm = 0.0;
+    unsigned unc_in = 0u, unc_out = 0u;
+    int munc_out = 0, nalt_out = 0, n_new = 0, provslot = -1, trueslot = -1, pos_prov = lane;
+    bool set_out = false, final_out = false, mine = false;
     auto hub_order = [&]() {
         if (hub_ordered) return;
         if (!wait_seq(&in_slot->seq_ord, tpos, h.ctl + 2, i, -prev_edge - 2)) wl_fail |= 32;
@@ -2015,7 +2073,6 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         hub_final = true;
         hub_unc = 0u; hub_munc = 0; hub_nalt = 0;
     };
-    Cand c;
     auto ring_free = [&]() {
         if (tpos >= MAIL_R) {
             if (free_seen == tpos - MAIL_R + 1) asm volatile("" ::: "memory");
@@ -2024,20 +2081,154 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     };
     auto publish_set = [&](int sidx, int n, double new_norm, unsigned unc, int munc, int n_alt, int sorted) {
         if (sidx >= 0) { out_slot->key[sidx] = c.key; out_slot->ts[sidx] = c.ts; out_slot->w[sidx] = c.w; }
-        if (lane == 0) {
-            out_slot->len = n; out_slot->norm = new_norm; out_slot->unc = unc; out_slot->munc = munc; out_slot->n_alt = n_alt;
-            out_slot->sorted = sorted;
-        }
+        if (lane == 0) mail_hdr_write(out_slot, new_norm, n, unc, munc, n_alt, sorted);
     };
     auto publish_seq = [&](bool set, bool ord) {           // LDS only, in program order (see process_edge)
         asm volatile("" ::: "memory");
         if (lane == 0 && set) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane == 0 && ord) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
+    // ================= the lean critical section: the common case, written for instruction count =================
+    // The row is the sorted arrangement of a pruned row, its norm the predicted one, the partner's side prepared
+    // (prepare_b) and disjoint from it: ranks from the merge network, the kept set written to the mailbox from the
+    // lanes the candidates live in.  Every test that fails BEFORE anything is written leaves the hop to the general
+    // code below, which starts from the mailbox again.
+    bool lean_done = false;
+#ifndef ZT_NO_LEAN
+    if (pre_b.ok) {
+        lean_done = [&]() -> bool {
+            double hn;
+            int hlen_v, hmunc_v, hnalt_v, hsorted_v;
+            unsigned hunc_v;
+            mail_hdr_read(in_slot, hn, hlen_v, hunc_v, hmunc_v, hnalt_v, hsorted_v);
+            const bool low = __builtin_amdgcn_inverse_ballot_w64(0xffffffffull);        // lanes 0..31: the hub's entries
+            u64 ckey = pre_b.cb_key;
+            double cts = pre_b.cb_ts, cw = pre_b.cb_w, hw = 0.0;
+            if (low) { ckey = in_slot->key[lane]; cts = in_slot->ts[lane]; hw = in_slot->w[lane]; }
+            const int fs = lds_load_seq(&out_slot->seq_free);
+            const int n1 = __builtin_amdgcn_readfirstlane(hlen_v), munc = __builtin_amdgcn_readfirstlane(hmunc_v);
+            const int nalt = __builtin_amdgcn_readfirstlane(hnalt_v);
+            const unsigned hunc = (unsigned)__builtin_amdgcn_readfirstlane((int)hunc_v);
+            {   // sorted arrangement, predicted norm (bit patterns on the scalar unit: both are finite and positive)
+                const long long hb = __double_as_longlong(hn), pb = __double_as_longlong(pre_scale.norm);
+                const unsigned h0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb), h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32));
+                const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb), p1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32));
+                if (__builtin_amdgcn_readfirstlane(hsorted_v) == 0 || h0 != p0 || h1 != p1 || (h0 | h1) == 0u) return false;
+            }
+            const int nb = pre_b.nb, n = n1 + nb, drop = n - k;
+            if (n1 <= 0 || drop <= 0) return false;
+            const bool table = lenp > 0;
+            if (munc > 0) {
+                // members of a straddling run that were not picked may turn out to be in the row (see below)
+                const u64 alt = in_slot->alt_key[lane & 31];
+                bool t = lane < nalt && alt == nkey;
+                if (table) t = t || (lane < nalt && L.htab[pre_hash == 3 ? key_hash2(alt) : key_hash(alt)] >= 0);
+                if (__ballot(t) != 0ull) return false;
+            }
+            // is a key of the hub's row in the partner's row?  Read now, looked at after the network
+            const bool in1 = lane < n1;
+            const int cand = (table && in1) ? L.htab[pre_hash == 3 ? key_hash2(ckey) : key_hash(ckey)] : -1;
+            const double inf = __longlong_as_double(0x7ff0000000000000ll);
+            double sw = pre_b.sw;
+            int sid = pre_b.sid;
+            if (low) { cw = hw * pre_scale.scale_s1; sw = in1 ? cw : inf; sid = lane; }
+            merge_stage<32>(sw, sid);
+            merge_stage<16>(sw, sid);
+            merge_stage<8>(sw, sid);
+            merge_stage<4>(sw, sid);
+            merge_stage<2>(sw, sid);
+            merge_stage<1>(sw, sid);
+            const long long swb = __double_as_longlong(sw);
+            const int llo = __builtin_amdgcn_mov_dpp((int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, true);   // wave_shr:1
+            const int lhi = __builtin_amdgcn_mov_dpp((int)(swb >> 32), 0x138, 0xf, 0xf, true);
+            const u64 S = __ballot(__longlong_as_double(((long long)lhi << 32) | (unsigned)llo) != sw) | 1ull;     // run starts
+            const u64 below = S & (((u64)2 << lane) - 1ull);
+            const int rs = 63 - __builtin_clzll(below);
+            const int both = push_i32(rs | (lane << 8), sid);   // (smaller candidates, sorted position) to the candidate's lane
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the tests that were left for after the network ----
+            bool bad = in1 && ((ckey == nkey && cts == tnow) || cw != cw);
+            if (__ballot(cand >= 0) != 0ull) {                   // an occupied slot: compare the keys in full
+                const int src = cand >= 0 ? cand : 0;
+                const u64 kj = __shfl(rp.key, src);
+                const double tj = __shfl(rp.ts, src);
+                bad = bad || (in1 && cand >= 0 && kj == ckey && tj == cts);
+            }
+            if (__ballot(bad) != 0ull) return false;
+            CRIT(1);
+            const int lt = both & 0xff, sp = both >> 8;
+            const bool full = (S >> drop) & 1ull;               // the cut falls on a run start: exactly k candidates are kept
+            const unsigned kmask = (1u << k) - 1u;
+            const unsigned claimed = (unsigned)(S >> drop) & kmask;
+            const int mode = full ? (claimed == kmask ? FR_RANKS : FR_TIES) : FR_STRADDLE;
+            const u64 lowdrop = ((u64)2 << drop) - 1ull;        // positions 0 .. drop
+            const int rsG = 63 - __builtin_clzll(S & lowdrop);  // start of the run that holds position `drop`
+            if (munc > 0) {
+                // a picked member of the previous hop's straddling run that is kept here (or ties with the cut) needs the
+                // previous hop's replay first: the general code waits for it
+                const int thr = full ? drop : rsG;
+                if (__ballot(lane < munc && lt >= thr) != 0ull) return false;
+            }
+            // ---- provisional slots: the candidate at sorted position p >= drop takes slot p - drop ----
+            const u64 nmask = ((u64)2 << (n - 1)) - 1ull;       // positions 0 .. n-1 (n <= 63)
+            const u64 multi = (~S | ~(S >> 1)) & nmask;         // position p shares its run with p-1 or with p+1
+            const unsigned uo = (unsigned)(multi >> drop) & kmask;
+            int mo_ = 0, na_ = 0;
+            if (!full) {
+                const u64 above = S & ~lowdrop;                 // the next run starts here (the padding's at n, at the latest)
+                mo_ = __ffsll((long long)above) - 1 - drop;
+                na_ = drop - rsG;
+            }
+            const int ps = sp - drop;
+            const bool kept = (unsigned)ps < (unsigned)k;       // (padding lanes sort behind position n-1)
+            if (tpos >= MAIL_R && fs != tpos - MAIL_R + 1) {
+                if (!wait_seq(&out_slot->seq_free, tpos - MAIL_R + 1, h.ctl + 2, i, -1)) wl_fail |= 64;
+            }
+            if (kept) { out_slot->key[ps] = ckey; out_slot->ts[ps] = cts; out_slot->w[ps] = cw; }
+            if (!full && sp >= rsG && sp < drop) out_slot->alt_key[sp - rsG] = ckey;
+            const double nn = pre_scale.norm_next;
+            if (lane == 0) mail_hdr_write(out_slot, nn, k, uo, mo_, na_, 1);
+            const bool fin = mode == FR_RANKS;                   // (then uo == 0: all kept weights distinct)
+            if (fin && kept) out_slot->pos[ps] = ps;
+            CRIT(2);
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0 && fin) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            CRIT(3);
+            __builtin_amdgcn_s_setprio(0);                       // the rest of this hop is off the chain
+            // ---- what the tail needs ----
+            if (table && lane < lenp) L.htab[pre_b.h2] = -1;     // the table is clean again
+            hub_unc = hunc; hub_munc = munc; hub_nalt = nalt;
+            hub_ordered = hunc == 0u && munc == 0; hub_final = hub_ordered;
+            new_norm = nn;
+            F.key = ckey; F.ts = cts; F.w = cw;
+            F.live = ((1ull << n1) - 1ull) | (((1ull << nb) - 1ull) << 32);
+            F.n = n; F.n1 = n1;
+            F.pos_tail = lane < 32 ? lane : n1 + (lane - 32);
+            mine = (F.live >> lane) & 1ull;
+            F.lt = lt; F.keep = mine && lt >= drop; F.touched = 0ull; F.claimed = claimed;
+            F.fast = true; F.sp = sp; F.S = S; F.mode = mode;
+            c.key = ckey; c.ts = cts; c.w = cw;
+            unc_in = hunc; unc_out = uo; munc_out = mo_; nalt_out = na_;
+            pos_prov = F.pos_tail;
+            n_new = k;
+            provslot = (mine && kept) ? ps : -1;
+            set_out = true; final_out = fin;
+            if (fin) trueslot = provslot;
+            return true;
+        }();
+    }
+#endif
+    if (!lean_done) {
+    // ---- the hub's row: one batch of LDS reads ----
+    mail_hdr_read(in_slot, rh.norm, rh.len, hub_unc, hub_munc, hub_nalt, hub_sorted);
+    rh.key = in_slot->key[lane & 31]; rh.ts = in_slot->ts[lane & 31]; rh.w = in_slot->w[lane & 31];
+    hub_alt = in_slot->alt_key[lane & 31];
+    free_seen = lds_load_seq(&out_slot->seq_free);
+    hub_ordered = hub_unc == 0u && hub_munc == 0; hub_final = hub_ordered;
+    CRIT(8);
     CRIT(9);
-    const double new_norm = rh.norm * beta + beta;
-    hint->norm_out = new_norm; hint->tpos = tpos;
-    Front F;
+    new_norm = rh.norm * beta + beta;
     bool settled = hub_final;                                    // the row is known to be the dictionary
     if (!settled && hub_munc > 0) {
         // members of a straddling run that were not picked may turn out to be in the row (process_edge)
@@ -2076,15 +2267,12 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         }
     }
     CRIT(12);
-    const unsigned unc_in = settled ? 0u : hub_unc;              // provisional slots of the row as I used it
+    unc_in = settled ? 0u : hub_unc;                             // provisional slots of the row as I used it
     c.key = F.key; c.ts = F.ts; c.w = F.w;
-    const bool mine = (F.live >> lane) & 1ull;
-    const int pos_prov = lane < 32 ? lane : F.pos_tail;          // my candidate's place in the list as it arrived
+    mine = (F.live >> lane) & 1ull;
+    pos_prov = lane < 32 ? lane : F.pos_tail;                    // my candidate's place in the list as it arrived
     const int drop = F.n - k;
-    int n_new = F.n <= k ? F.n : k, provslot = -1, trueslot = -1;
-    unsigned unc_out = 0u;
-    int munc_out = 0, nalt_out = 0;
-    bool set_out = false, final_out = false;
+    n_new = F.n <= k ? F.n : k;
     ring_free();
     CRIT(13);
     if (F.mode == FR_NOPRUNE) {
@@ -2163,6 +2351,8 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         CRIT(3);
         __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
     }
+    }   // (!lean_done)
+    hint->norm_out = new_norm; hint->tpos = tpos;
     if (!final_out) {
         // ---- my own replay: final slot of every list POSITION (identity-free, see Mail) ----
         const int slot_c = merge_order(L, lane, k, F, lane, &n_new, -1);
@@ -2193,6 +2383,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (lane == 0)                                               // both stages of the incoming slot have been read
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef ZT_CRIT
+    if (lean_done) { CRIT(6); crit_t[7] = 1; }
     if (lane == 0 && mo == 0 && i < 8192)
         for (int q = 0; q < 16; ++q) g_crit[i * 16 + q] = crit_t[q];
 #endif
@@ -2278,6 +2469,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
 {
     __shared__ WaveLds lds[WAVES_PER_WG];
     __shared__ Mail mail;
+    __shared__ int ch_edge[CH_MAX], ch_partner[CH_MAX], ch_woh[CH_MAX], ch_wop[CH_MAX], ch_pfh[CH_MAX];   // chain workgroups: HopRec
     WaveLds &L = lds[threadIdx.x / WAVE];
     const int lane = lane_id();
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) {         // rejected by k_count: the state is not touched,
@@ -2308,23 +2500,43 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         int len = h.chain_len[c];
         len = len < CH_MAX ? len : CH_MAX;
         const int *edges = h.chain_edges + c * CH_MAX;
-        // (Four waves per chain instead of eight: 835 us -- a wave's whole hop, off-chain half included, is ~16 us.)
-        // Only chain_waves waves (one per SIMD) take hops, the others leave: what a hop needs besides the hub's update --
-        // the partner's update, the emission -- runs elsewhere (process_chain_partner), so four waves keep up with the
-        // chain and the wave that holds it never shares its SIMD with a busy mate.
+        // what every hop needs to know about its edge (HopRec), once, into LDS
+        for (int q = threadIdx.x; q < len; q += blockDim.x) {
+            const int e = edges[q];
+            const long long u = A.nodes[e], v = A.nodes[A.role_stride + e];
+            const int role_h = u == hub ? 0 : 1;
+            ch_edge[q] = e;
+            ch_partner[q] = u == v ? -1 : (int)(u == hub ? v : u);
+            ch_woh[q] = h.wo[role_h * A.B + e];
+            ch_wop[q] = h.wo[(1 - role_h) * A.B + e];
+            ch_pfh[q] = h.pflag[role_h * A.B + e];
+        }
+        __syncthreads();
+        // chain_waves (ZT_CHAIN_WAVES, default all eight) waves take hops: what a hop needs besides the hub's update -- the
+        // partner's update, the emission -- runs elsewhere (process_chain_partner), but a hop's preparation and its
+        // off-chain half (replay, order, stores) still add up to ~5 hop periods of one wave's time.
         if ((int)(threadIdx.x / WAVE) >= A.chain_waves) return;
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
         // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
-        // hops away -- was measured: the hops then run strictly one after the other, 10x slower.)
+        // hops away -- was measured: the hops then run strictly one after the other, 10x slower.  A wave claiming its next
+        // hop right after publishing, to have the partner's row requested early, was measured too: claims then follow
+        // the order of publication -- the same fixed rotation -- and a wave with a long off-chain half holds the chain up.)
         for (;;) {
             int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
-            const int pe = t > 0 ? edges[t - 1] : -1, ne = t + 1 < len ? edges[t + 1] : -1;
-            if (!chain_hop(h, A, L, lane, edges[t], mo, &mail, hub, pe, ne, t, &hint, c))
-                process_edge(h, A, L, lane, edges[t], mo, &mail, hub, pe, ne, t, &hint, c);
+#define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
+            const int pe = t > 0 ? ZT_U(ch_edge[t - 1]) : -1, ne = t + 1 < len ? ZT_U(ch_edge[t + 1]) : -1, ce = ZT_U(ch_edge[t]);
+            HopRec rec;
+            rec.partner = ZT_U(ch_partner[t]); rec.wo_h = ZT_U(ch_woh[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pf_h = ZT_U(ch_pfh[t]);
+            rec.wo_prev = t > 0 ? ZT_U(ch_woh[t - 1]) : -1;
+            rec.wo_next = t + 1 < len ? ZT_U(ch_woh[t + 1]) : -1;
+            rec.pf_next = t + 1 < len ? ZT_U(ch_pfh[t + 1]) : -1;
+#undef ZT_U
+            if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec))
+                process_edge(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c);
         }
         return;                                           // chain workgroups take no general tasks
     }
