@@ -239,9 +239,9 @@ def main():
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--profile-every", type=int, default=-1,
-                    help="record HIP events around every n-th launch of each kernel (default: every launch at "
-                         "bs >= 2048; every 4th for small batches, where two event records per kernel are a "
-                         "visible share of a 0.15 ms step)")
+                    help="record HIP events around every n-th launch of the main stream's kernels (default 4: two "
+                         "event records per kernel and step cost ~3 %% of the step; the T-PPR update, one launch per "
+                         "group of batches on its own stream, is timed at every launch)")
     ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
                          "(0 = no masks; default: whole XCDs -- 64 at bs >= 2048, else 32 -- for the streaming strategy, "
@@ -403,7 +403,7 @@ def main():
     run(prefill, a.warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
-        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else (1 if bs >= 2048 else 4))
+        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else 4)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -481,8 +481,7 @@ def main():
                              "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
         if name == "tppr_stream":
             # one k_stream launch covers all M models and `group` batches (fewer at the ends of the region)
-            every = a.profile_every if a.profile_every > 0 else (1 if bs >= 2048 else 4)
-            per_launch = (a.steps * bs / kern[name]["launches"]) if every == 1 else a.group * bs
+            per_launch = a.steps * bs / kern[name]["launches"]     # (every launch of the T-PPR update is timed)
             byts = ab["p1"] * M * per_launch
             note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
                     "per-node chains; the binding resource is hops x hop latency, not HBM")

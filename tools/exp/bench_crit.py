@@ -1,0 +1,35 @@
+# bench.py against the -DZT_CRIT library (tools/build_crit.sh), then the hub-hop stamps of the LAST T-PPR launch of the run:
+# hop times inside the pipeline (beside the aggregation, on the T-PPR stream's CUs), for the edges of the launch's first batch
+#   python3 tools/exp/bench_crit.py --steps 40 --cpu-edges 0
+import sys, runpy, ctypes as C
+import numpy as np
+sys.path.insert(0, '/root/repo')
+from zebra_amd import _capi
+_capi.LIB_PATH = '/root/repo/tools/out/libzebra_crit.so'
+sys.argv = ['bench.py'] + sys.argv[1:]
+try:
+    runpy.run_path('/root/repo/bench.py', run_name='__main__')
+except SystemExit:
+    pass
+lib = _capi.lib()
+c2 = np.zeros((8192, 16), np.int64)
+lib.zt_debug_crit(c2.ctypes.data_as(C.c_void_p), C.c_int(8192))
+p = lambda a: np.percentile(a, [10, 50, 90]).round(0)
+for mo in (0, 1):
+    c = c2[mo * 4096:(mo + 1) * 4096]
+    c = c[(c[:, 3] > 0) & (c[:, 0] > 0)]
+    c = c[np.argsort(c[:, 3])]
+    c = c[c[:, 3] > c[:, 3].max() - 3_000_000]        # stamps of the last launch over 3+ batches only (its first batch's edges)
+    ch = c[:, 15] // 100000
+    big = np.bincount(ch.astype(np.int64)).argmax()   # the hub's chain: the one with the most hops
+    c = c[ch == big]
+    c = c[np.argsort(c[:, 15])]
+    c = c[np.concatenate([[True], np.diff(c[:, 15]) == 1])]
+    d = np.diff(c[:, 3])
+    d = d[d < 60000]                                  # (hops of other batches' edges in between are not stamped)
+    lean = c[c[:, 7] == 1]
+    non = c[c[:, 7] != 1]
+    print("model %d: hops that did not take the lean section, by reason (1 partner side not prepared, 2 norm, 3 key match, 4 new key / NaN, 5 row not sorted, 6 table clash): %s" % (
+        mo, dict(zip(*np.unique(non[:, 11], return_counts=True)))))
+    print("model %d: %d stamped hops; publication to publication %s mean %.0f; critical section %s; lean %d: preparation %s slack %s tail %s" % (
+        mo, len(c), p(d), d.mean(), p(c[:, 3] - c[:, 0]), len(lean), p(lean[:, 5] - lean[:, 4]), p(lean[:, 0] - lean[:, 5]), p(lean[:, 6] - lean[:, 3])))

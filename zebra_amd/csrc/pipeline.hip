@@ -30,6 +30,8 @@ constexpr int MAX_GROUP = 4;
 struct zt_pipeline {
     zt_pipeline_desc d;
     hipStream_t side, main_s, plan_s;
+    hipStream_t msg_s;         // the message build of the current batch, beside its aggregation (reads the memory tables only)
+    hipEvent_t step_begin, msgs_done;
     int group;                 // batches per T-PPR launch (streaming)
     struct Slot {
         int32_t *nodes;        // [3 * cap]   src of every member | dst ... | neg ...   (role stride = Btot)
@@ -252,12 +254,19 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         void *a = nullptr, *b = nullptr;
         int rc = zt_stream_create_masked(&a, 0, tppr_cus);
         if (rc == ZT_OK) rc = zt_stream_create_masked(&b, tppr_cus, prop.multiProcessorCount);
+        // the message kernels are small (a few dozen registers, no LDS): they share the T-PPR stream's compute units, where
+        // they fit beside k_stream's workgroups -- the aggregation kernel fills the register files of its own
+        void *c = nullptr;
+        if (rc == ZT_OK) rc = zt_stream_create_masked(&c, 0, tppr_cus);
         if (rc != ZT_OK) { delete p; return rc; }
-        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b;
+        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c;
     } else {
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
+        ZT_HIP(hipStreamCreateWithFlags(&p->msg_s, hipStreamNonBlocking));
     }
+    ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
+    ZT_HIP(hipEventCreateWithFlags(&p->msgs_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipStreamCreateWithFlags(&p->plan_s, hipStreamNonBlocking));
     ZT_HIP(hipEventCreateWithFlags(&p->entry, hipEventDisableTiming | zt::sync_event_flags()));
     // a slot holds one batch of max_B edges, or a group of smaller ones up to what one T-PPR launch covers
@@ -290,7 +299,8 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
     (void)hipStreamDestroy(p->side); (void)hipStreamDestroy(p->main_s); (void)hipStreamDestroy(p->plan_s);
-    (void)hipEventDestroy(p->entry);
+    (void)hipStreamDestroy(p->msg_s);
+    (void)hipEventDestroy(p->entry); (void)hipEventDestroy(p->step_begin); (void)hipEventDestroy(p->msgs_done);
     delete p;
     return ZT_OK;
 }
@@ -420,17 +430,24 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         k_avg_topk<<<1, 256, 0, p->main_s>>>(ow, 2 * B, d.k, p->avg_topk);
         ZT_LAUNCH_CHECK();
     }
+    // ---- P3 (first half), on a stream of its own: the last messages of the endpoints at positions [pos_lo, pos_hi).  They
+    // read the memory tables as everything enqueued on the main stream so far leaves them (the previous batch's GRU, a
+    // caller's row exchange) and nothing the aggregation writes; the GRU below waits for them.
+    ZT_HIP(hipEventRecord(p->step_begin, p->main_s));
+    ZT_HIP(hipStreamWaitEvent(p->msg_s, p->step_begin, 0));
+    rc = zt::store_messages_ex(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
+                               cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
+                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->msg_s);
+    if (rc != ZT_OK) return rc;
+    ZT_HIP(hipEventRecord(p->msgs_done, p->msg_s));
     if (n_rows > 0) {
         rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                       od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
     }
-    // ---- P3: last messages of the endpoints at positions [pos_lo, pos_hi), GRU update, projected rows ----
-    rc = zt::store_messages_ex(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
-                               cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
-                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->main_s);
-    if (rc != ZT_OK) return rc;
+    // ---- P3: GRU update over the messages built beside the aggregation, projected rows ----
+    ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
     const int msg_dim = 2 * d.D + d.F + d.T;
     // the refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace
     const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)

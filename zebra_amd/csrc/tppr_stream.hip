@@ -83,7 +83,10 @@ long long g_prof_open[P_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // inde
 }  // namespace
 void prof_begin(hipStream_t s, int id)
 {
-    if ((g_prof_seen[id]++ % g_prof_every) != 0) return;      // not sampled: prof_end finds no open record
+    // the T-PPR update is one launch per group of batches on a stream of its own: every launch is timed; of the main
+    // stream's kernels every n-th (two event records per kernel are ~3 % of a step there)
+    const int every = id <= P_CLEANUP ? 1 : g_prof_every;
+    if ((g_prof_seen[id]++ % every) != 0) return;             // not sampled: prof_end finds no open record
     ProfRec r{prof_event(), prof_event(), id, true};
     if (!r.a || !r.b) return;
     (void)hipEventRecord(r.a, s);
@@ -2356,11 +2359,13 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (!final_out) {
         // ---- my own replay: final slot of every list POSITION (identity-free, see Mail) ----
         const int slot_c = merge_order(L, lane, k, F, lane, &n_new, -1);
+        CRIT(8);
         int *sig = L.sel;                                        // final slot by list position
         if (mine) sig[pos_prov] = slot_c;
         wave_sync();
         // ---- identities: where my candidate REALLY stood in the list ----
         if (unc_in != 0u) hub_order();
+        CRIT(9);
         const int truepos = lane < 32 ? hub_pos : F.pos_tail;    // hub_pos = lane when nothing was provisional
         trueslot = (mine && truepos >= 0) ? sig[truepos] : -1;
         wave_sync();
@@ -2375,6 +2380,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             if (provslot >= 0) out_slot->pos[provslot] = trueslot;
             publish_seq(false, true);
         }
+        CRIT(10);
     }
     c.slot = trueslot;
     if (hub_to_memory) store_row_scatter(h, m, hub, lane, n_new, c, new_norm, tag_base | (unsigned)(wo_h + 1));
@@ -2384,8 +2390,10 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef ZT_CRIT
     if (lean_done) { CRIT(6); crit_t[7] = 1; }
-    if (lane == 0 && mo == 0 && i < 8192)
-        for (int q = 0; q < 16; ++q) g_crit[i * 16 + q] = crit_t[q];
+    crit_t[15] = (long long)chain_idx * 100000 + tpos;
+    if (lane == 0 && mo < 2 && i < 4096 && (A.B <= 4096 || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
+                                                                 //  in a pipelined run the launches over 3+ batches only)
+        for (int q = 0; q < 16; ++q) g_crit[(mo * 4096 + i) * 16 + q] = crit_t[q];
 #endif
     (void)wl_fail;
     return true;
@@ -2538,7 +2546,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
             if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec))
                 process_edge(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c);
         }
-        return;                                           // chain workgroups take no general tasks
+        return;                                           // chain workgroups take no general tasks (letting them join the
+                                                          // general queue once their chain is done was measured: no difference)
     }
 
     // ---- general queue: every (edge, model) task not owned by a chain, in order ----
