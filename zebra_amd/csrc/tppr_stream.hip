@@ -1994,9 +1994,39 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         next_by_mail = rec.wo_next == wo_h + 1;
         hub_to_memory = !(next_by_mail && rec.pf_next < 0);
     }
+    MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
+    // (the two float64 divisions of the scale factors: while the partner's row is on its way)
+    PreScale pre_scale;
+    pre_scale.valid = false;
+    // the norm the hub's row will arrive with: norm <- norm * beta + beta from hop to hop, starting from this wave's own
+    // last hop or, if that is long ago (or never was), from the latest kept set in the ring
+    double pn = 0.0;
+    int psteps = -1;
+    if (hint->tpos >= 0 && tpos - hint->tpos <= 24) { pn = hint->norm_out; psteps = tpos - hint->tpos - 1; }
+    else {
+        for (int d = 2; d < MAIL_R && tpos - d >= 0; ++d) {       // (the slot of position tpos - d is not rewritten before my hop)
+            const MailSlot *sl = &mail->slot[(tpos - d) % MAIL_R];
+            if (lds_load_seq(&sl->seq_set) == tpos - d + 1) {
+                double hn; int a0, a1, a2, a3; unsigned a4;
+                mail_hdr_read(sl, hn, a0, a4, a1, a2, a3);
+                pn = hn; psteps = d - 1;
+                break;
+            }
+        }
+    }
+    if (psteps >= 0) {
+        for (int q = 0; q < psteps; ++q) pn = pn * beta + beta;
+        if (pn != 0.0) {
+            const double nn = pn * beta + beta;
+            pre_scale.norm = pn;
+            pre_scale.norm_next = nn;
+            pre_scale.scale_s1 = pn / nn * beta;
+            pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
+            pre_scale.valid = true;
+        }
+    }
     if (row_from_raw(praw, k, lane, ptag, rp) != ptag)
         if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
-    MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
     int pre_hash = 0;                           // 1 / 3: partner entered into this wave's hash table (slot function 1 / 2),
     int h2slot = 0;                             // 2: its keys collide under both
@@ -2013,20 +2043,6 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             if (clash && lane < lenp) L.htab[hs] = -1;           // (several lanes may clear one slot)
             wave_sync();
             if (!clash) { pre_hash = var == 0 ? 1 : 3; h2slot = hs; break; }
-        }
-    }
-    PreScale pre_scale;
-    pre_scale.valid = false;
-    if (hint->tpos >= 0 && tpos - hint->tpos <= 16) {
-        double pn = hint->norm_out;
-        for (int q = hint->tpos + 1; q < tpos; ++q) pn = pn * beta + beta;
-        if (pn != 0.0) {
-            const double nn = pn * beta + beta;
-            pre_scale.norm = pn;
-            pre_scale.norm_next = nn;
-            pre_scale.scale_s1 = pn / nn * beta;
-            pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
-            pre_scale.valid = true;
         }
     }
     const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)pnode;      // (edge_idx, partner, ts) enters the hub's dictionary
