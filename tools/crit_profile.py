@@ -71,3 +71,9 @@ rl = cl[cl[:, 8] > 0]
 if len(rl):
     print("off-chain half of the %d lean hops that replay: published -> replay done %s ; -> previous hop's order there %s ; -> own order published %s ; -> hop done (stores) %s" % (
         len(rl), p(rl[:, 8] - rl[:, 3]), p(rl[:, 9] - rl[:, 8]), p(rl[:, 10] - rl[:, 9]), p(rl[:, 6] - rl[:, 10])))
+cm = c[idx]; okm = (cm[:, 3] > 0) & (cm[:, 12] > 0)
+if okm.any():
+    t0k = cm[okm][:, 12].min(); first = cm[okm][:, 4].min(); lastp = cm[okm][:, 3].max()
+    kern_clk = 1e3 * ms.value / n.value * 2350.0
+    print("model 0: workgroup start -> first stamped hop starts %.0f clocks (%.1f us); -> last publication %.0f (%.1f us); average kernel %.1f us => %.1f us after the last publication (+ launch)" % (
+        first - t0k, (first - t0k) / 2350.0, lastp - t0k, (lastp - t0k) / 2350.0, kern_clk / 2350.0, (kern_clk - (lastp - t0k)) / 2350.0))

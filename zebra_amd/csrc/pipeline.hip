@@ -177,10 +177,10 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     if (s.used) ZT_HIP(hipStreamWaitEvent(st, s.consumed, 0));
     // the batches' tensors may have been produced on the caller's stream just before this call (the main stream is
     // ordered behind it): the staging copy must not read them earlier
-    if (st != p->main_s) {
-        ZT_HIP(hipEventRecord(p->entry, p->main_s));
-        ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
-    }
+    // (`entry` was recorded when the step call began -- BEFORE the main stream was told to wait for the current group's
+    //  T-PPR update: recorded here, behind that wait, it held the staging and the plan of the NEXT groups back until the
+    //  current update was done; a quarter of a millisecond at the start of a timed region)
+    if (st != p->main_s) ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
     k_stage_group<<<(unsigned)((g.Btot + 255) / 256), 256, 0, st>>>(g, s.nodes, s.nodes_m, s.ts,
                                                                      reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1);
     ZT_LAUNCH_CHECK();
@@ -365,6 +365,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         *hi = Bn == B ? row_hi : (row_hi * 3 * Bn) / (3 * B);
     };
     int rc, j = 0;
+    ZT_HIP(hipEventRecord(p->entry, p->main_s));           // everything the caller enqueued before this call (make_group)
     // ---- this batch's T-PPR query: made ahead by an earlier step, or now (with as many followers as allowed) ----
     zt_pipeline::Slot *s = find_slot(p, cur, &j);
     // (a batch nobody has queried ahead is queried ALONE: the aggregation waits for this launch, and a group would

@@ -1416,6 +1416,9 @@ __device__ __forceinline__ void mail_hdr_write(MailSlot *sl, double norm, int le
     *reinterpret_cast<mail_v4u *>(&sl->norm) = v;
 }
 struct Mail {
+#ifdef ZT_CRIT
+    long long t_start; // core clock when the workgroup started (diagnostic)
+#endif
     MailSlot slot[MAIL_R];
     int head;          // next position of the chain's edge list
 };
@@ -1442,12 +1445,12 @@ __device__ __forceinline__ int lds_load_seq(const int *p)
 }
 
 // spin until *p == want (an LDS word of this workgroup's mailbox); bounded like every other wait
-__device__ inline bool wait_seq(const int *p, int want, int *status, int what, int aux)
+__device__ inline bool wait_seq(const int *p, int want, int *status, int what, int aux, bool hot = false)
 {
     unsigned spins = 0;
     long long t0 = 0;
     while (lds_load_seq(p) != want) {
-        __builtin_amdgcn_s_sleep(1);
+        if (!hot) __builtin_amdgcn_s_sleep(1);           // hot: the next wave on a chain polls back to back
         if ((++spins & 4095u) == 0) {
             const long long now = (long long)wall_clock64();
             if (t0 == 0) t0 = now;
@@ -2062,7 +2065,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             if ((++spins & 1023u) == 0 && launch_failed(h.ctl + 2)) break;
         }
     }
-    if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge)) wl_fail |= 16;
+    if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge, true)) wl_fail |= 16;
     __builtin_amdgcn_s_setprio(3);
     CRIT(0);
     Row rh;
@@ -2407,6 +2410,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
 #ifdef ZT_CRIT
     if (lean_done) { CRIT(6); crit_t[7] = 1; }
     crit_t[15] = (long long)chain_idx * 100000 + tpos;
+    crit_t[12] = mail->t_start;
     if (lane == 0 && mo < 2 && i < 4096 && (A.B <= 4096 || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
                                                                  //  in a pipelined run the launches over 3+ batches only)
         for (int q = 0; q < 16; ++q) g_crit[(mo * 4096 + i) * 16 + q] = crit_t[q];
@@ -2512,6 +2516,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     if (threadIdx.x < MAIL_R) { mail.slot[threadIdx.x].seq_set = 0; mail.slot[threadIdx.x].seq_ord = 0; mail.slot[threadIdx.x].seq_free = 0; }
     if (threadIdx.x == 0) mail.head = 0;
+#ifdef ZT_CRIT
+    if (threadIdx.x == 0) mail.t_start = (long long)__builtin_readcyclecounter();
+#endif
     for (int q = lane; q < HTAB; q += WAVE) L.htab[q] = -1;
     __syncthreads();
     const int n_models = A.n_models;
