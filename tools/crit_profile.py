@@ -77,3 +77,10 @@ if okm.any():
     kern_clk = 1e3 * ms.value / n.value * 2350.0
     print("model 0: workgroup start -> first stamped hop starts %.0f clocks (%.1f us); -> last publication %.0f (%.1f us); average kernel %.1f us => %.1f us after the last publication (+ launch)" % (
         first - t0k, (first - t0k) / 2350.0, lastp - t0k, (lastp - t0k) / 2350.0, kern_clk / 2350.0, (kern_clk - (lastp - t0k)) / 2350.0))
+if okm.any():
+    print("         last partner task (model 0) done %.1f us after the last publication; last general wave left %.1f us after it" % (
+        (c2[8191][1] - lastp) / 2350.0, (c2[8191][0] - lastp) / 2350.0))
+lag = (cm[:, 14] - cm[:, 3])[(cm[:, 14] > cm[:, 3]) & (cm[:, 3] > 0) & (cm[:, 14] - cm[:, 3] < 2000000)] / 2350.0
+if len(lag):
+    qq = len(lag) // 4
+    print("partner task done - publication of its hop (us), by quarter of the chain (median): " + " | ".join("%.1f" % np.median(lag[a:a + qq]) for a in range(0, 4 * qq, qq)) + "   last ten: " + " ".join("%.0f" % x for x in lag[-10:]))

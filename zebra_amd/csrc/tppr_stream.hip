@@ -2413,7 +2413,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     crit_t[12] = mail->t_start;
     if (lane == 0 && mo < 2 && i < 4096 && (A.B <= 4096 || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
                                                                  //  in a pipelined run the launches over 3+ batches only)
-        for (int q = 0; q < 16; ++q) g_crit[(mo * 4096 + i) * 16 + q] = crit_t[q];
+        for (int q = 0; q < 16; ++q) if (q != 14) g_crit[(mo * 4096 + i) * 16 + q] = crit_t[q];
 #endif
     (void)wl_fail;
     return true;
@@ -2491,6 +2491,10 @@ __device__ inline void process_chain_partner(const zt_tppr &h, const StreamArgs 
         if (n_roles == 3 && !g_own) rg = (g == u) ? ru : rv;
         emit_edge(A, k, lane, i, mo, ru, rv, rg, tnow);
     }
+#ifdef ZT_CRIT
+    if (lane == 0 && mo == 0) atomicMax((unsigned long long *)&g_crit[8191 * 16 + 1], (unsigned long long)__builtin_readcyclecounter());
+    if (lane == 0 && mo == 0 && i < 4096) g_crit[i * 16 + 14] = (long long)__builtin_readcyclecounter();   // partner task done
+#endif
 }
 
 __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, StreamArgs A)
@@ -2583,7 +2587,14 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
         // body for the remaining lanes (seen in the ISA).
         int idx = atomicAdd(h.ctl + 1, lane == 0 ? 1 : 0);
         idx = __builtin_amdgcn_readfirstlane(idx);
+#ifdef ZT_CRIT
+        if (idx >= total) {                                // diagnostic: when the last general wave left, and who it was
+            if (lane == 0) atomicMax((unsigned long long *)&g_crit[8191 * 16 + 0], (unsigned long long)__builtin_readcyclecounter());
+            return;
+        }
+#else
         if (idx >= total) return;
+#endif
         const int i = idx / n_models;
         if (A.use_chains && h.owner_of[i] >= 0) {           // its chain applies the hub's update, this wave the rest
             process_chain_partner(h, A, L, lane, i, idx % n_models);
