@@ -447,6 +447,7 @@ def main():
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (separate
     # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction; see profiles/make_pmc_summary.py)
     pmc = {}
+    pmc_edges = None
     if world == 1:
         for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % a.workload)
@@ -455,8 +456,11 @@ def main():
                 pmc = summ.get("kernels", {})
                 # per-launch bytes of the T-PPR kernel belong to a launch SHAPE: a summary measured with another
                 # number of batches per launch says nothing about this run's launches
+                # (the kernel's traffic is per edge -- rows read and written, tag polls: a summary measured on launches
+                #  of another size is scaled by the edges per launch, and the roofline note says so)
                 on = summ.get("measured_on") or {}
-                if on.get("tppr_launch_group") not in (None, a.group):
+                pmc_edges = on.get("edges_per_k_stream_launch")
+                if on.get("tppr_launch_group") not in (None, a.group) and not pmc_edges:
                     pmc = {kk: vv for kk, vv in pmc.items() if kk != "tppr_stream"}
                 break
     ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
@@ -485,6 +489,9 @@ def main():
             byts = ab["p1"] * M * per_launch
             note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
                     "per-node chains; the binding resource is hops x hop latency, not HBM")
+            if tr is not None and pmc_edges and abs(pmc_edges - per_launch) > 1:
+                tr = tr * per_launch / pmc_edges
+                note += "; traffic: counters of %d-edge launches scaled to this run's %.0f edges per launch" % (pmc_edges, per_launch)
         elif name == "pruned_topk":
             # ONE launch serves all M models: the CSR tails are read once, every model writes its output rows
             byts = (ab["p1"] - 48 * k + M * 48 * k) * bs / shard
