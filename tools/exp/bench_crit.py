@@ -33,3 +33,18 @@ for mo in (0, 1):
         mo, dict(zip(*np.unique(non[:, 11], return_counts=True)))))
     print("model %d: %d stamped hops; publication to publication %s mean %.0f; critical section %s; lean %d: preparation %s slack %s tail %s" % (
         mo, len(c), p(d), d.mean(), p(c[:, 3] - c[:, 0]), len(lean), p(lean[:, 5] - lean[:, 4]), p(lean[:, 0] - lean[:, 5]), p(lean[:, 6] - lean[:, 3])))
+    # slow hops of the hub's chain: a long preparation = the partner's row was not there (a general task or another chain
+    # had to write it first); a normal preparation with no slack = every wave of the chain was busy
+    dd = np.diff(c[:, 3]); slow = np.where(dd > 4500)[0] + 1
+    prep = c[:, 5] - c[:, 4]
+    kind_wait = [t for t in slow if c[t, 7] == 1 and prep[t] > 9000]
+    kind_busy = [t for t in slow if c[t, 7] == 1 and prep[t] <= 9000]
+    kind_gen = [t for t in slow if c[t, 7] != 1]
+    ex = lambda ts: sum(dd[t - 1] - np.median(dd) for t in ts)
+    print("model %d: slow hops %d of %d (excess over the median %.0f clocks = %.0f %% of the chain): partner's row late %d (%.0f), waves busy %d (%.0f), general code %d (%.0f)" % (
+        mo, len(slow), len(c), ex(slow), 100 * ex(slow) / max(1, dd.sum()), len(kind_wait), ex(kind_wait), len(kind_busy), ex(kind_busy), len(kind_gen), ex(kind_gen)))
+    head = (c[:, 13] // 100000) / 2.0; edge = c[:, 13] % 100000          # (two models: task index / 2 = edge)
+    okh = c[:, 13] > 0
+    print("model %d: general queue head - this hop's edge, when the hop was ready to wait for its row (edges; > 0: the queue is ahead): %s" % (mo, p((head - edge)[okh])))
+    print("model %d: partner's side not prepared because (7 no norm prediction, 8 both slot functions clash, 9 NaN): %s; lean section left after the old front half would have succeeded: %d" % (
+        mo, dict(zip(*np.unique(non[:, 9], return_counts=True))), int((non[:, 11] == 0).sum())))

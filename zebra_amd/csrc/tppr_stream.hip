@@ -2017,7 +2017,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             }
         }
     }
-    if (psteps >= 0) {
+    auto set_scale = [&]() {
         for (int q = 0; q < psteps; ++q) pn = pn * beta + beta;
         if (pn != 0.0) {
             const double nn = pn * beta + beta;
@@ -2027,7 +2027,8 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
             pre_scale.scale_s2 = beta / nn * (1.0 - alpha);
             pre_scale.valid = true;
         }
-    }
+    };
+    if (psteps >= 0) set_scale();
     if (row_from_raw(praw, k, lane, ptag, rp) != ptag)
         if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
@@ -2056,6 +2057,10 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     // s_waitcnt vmcnt(0) here: it would also wait for the write-through stores of this wave's previous hop.)
     st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
     CRIT(5);
+#ifdef ZT_CRIT
+    crit_t[9] = !pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : (!pre_b.ok ? 9 : 0));     // why the partner's side is not prepared
+    crit_t[13] = (long long)ld_agent(h.ctl + 1) * 100000 + i;    // head of the general queue (task index) when this hop was ready, and its edge
+#endif
     // waves whose turn is two or more hops away doze (see process_edge)
     if (tpos >= 2) {
         const int *far = &mail->slot[(tpos - 2) % MAIL_R].seq_set;
@@ -2063,6 +2068,18 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         while (lds_load_seq(far) != tpos - 1 && lds_load_seq(&in_slot->seq_set) != tpos) {
             __builtin_amdgcn_s_sleep(8);
             if ((++spins & 1023u) == 0 && launch_failed(h.ctl + 2)) break;
+        }
+    }
+    // (a wave's first hop of a launch has no norm to start from until somebody has published: the kept set two positions
+    //  back is out now -- its successor is in its critical section --, which leaves time to prepare the partner's side)
+    if (!pre_scale.valid && tpos >= 2 && pre_hash != 2) {
+        const MailSlot *sl = &mail->slot[(tpos - 2) % MAIL_R];
+        if (lds_load_seq(&sl->seq_set) == tpos - 1) {
+            double hn; int a0, a1, a2, a3; unsigned a4;
+            mail_hdr_read(sl, hn, a0, a4, a1, a2, a3);
+            pn = hn; psteps = 1;
+            set_scale();
+            if (pre_scale.valid) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b, h2slot);
         }
     }
     if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge, true)) wl_fail |= 16;
@@ -2249,7 +2266,6 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     free_seen = lds_load_seq(&out_slot->seq_free);
     hub_ordered = hub_unc == 0u && hub_munc == 0; hub_final = hub_ordered;
     CRIT(8);
-    CRIT(9);
     new_norm = rh.norm * beta + beta;
     bool settled = hub_final;                                    // the row is known to be the dictionary
     if (!settled && hub_munc > 0) {
