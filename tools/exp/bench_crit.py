@@ -48,3 +48,5 @@ for mo in (0, 1):
     print("model %d: general queue head - this hop's edge, when the hop was ready to wait for its row (edges; > 0: the queue is ahead): %s" % (mo, p((head - edge)[okh])))
     print("model %d: partner's side not prepared because (7 no norm prediction, 8 both slot functions clash, 9 NaN): %s; lean section left after the old front half would have succeeded: %d" % (
         mo, dict(zip(*np.unique(non[:, 9], return_counts=True))), int((non[:, 11] == 0).sum())))
+    print("model %d: lean section left at (1 not sorted / norm, 2 no prune, 3 alternate may be in the row, 4 key match / NaN, 5 picked member kept): %s" % (
+        mo, dict(zip(*np.unique(non[non[:, 10] < 100][:, 10], return_counts=True)))))

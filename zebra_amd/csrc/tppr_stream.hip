@@ -2132,6 +2132,11 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     // (prepare_b) and disjoint from it: ranks from the merge network, the kept set written to the mailbox from the
     // lanes the candidates live in.  Every test that fails BEFORE anything is written leaves the hop to the general
     // code below, which starts from the mailbox again.
+#ifdef ZT_CRIT
+#define LEANC(c) do { crit_t[10] = (c); } while (0)
+#else
+#define LEANC(c) do { } while (0)
+#endif
     bool lean_done = false;
 #ifndef ZT_NO_LEAN
     if (pre_b.ok) {
@@ -2152,17 +2157,17 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
                 const long long hb = __double_as_longlong(hn), pb = __double_as_longlong(pre_scale.norm);
                 const unsigned h0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb), h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32));
                 const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb), p1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32));
-                if (__builtin_amdgcn_readfirstlane(hsorted_v) == 0 || h0 != p0 || h1 != p1 || (h0 | h1) == 0u) return false;
+                if (__builtin_amdgcn_readfirstlane(hsorted_v) == 0 || h0 != p0 || h1 != p1 || (h0 | h1) == 0u) { LEANC(1); return false; }
             }
             const int nb = pre_b.nb, n = n1 + nb, drop = n - k;
-            if (n1 <= 0 || drop <= 0) return false;
+            if (n1 <= 0 || drop <= 0) { LEANC(2); return false; }
             const bool table = lenp > 0;
             if (munc > 0) {
                 // members of a straddling run that were not picked may turn out to be in the row (see below)
                 const u64 alt = in_slot->alt_key[lane & 31];
                 bool t = lane < nalt && alt == nkey;
                 if (table) t = t || (lane < nalt && L.htab[pre_hash == 3 ? key_hash2(alt) : key_hash(alt)] >= 0);
-                if (__ballot(t) != 0ull) return false;
+                if (__ballot(t) != 0ull) { LEANC(3); return false; }
             }
             // is a key of the hub's row in the partner's row?  Read now, looked at after the network
             const bool in1 = lane < n1;
@@ -2193,7 +2198,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
                 const double tj = __shfl(rp.ts, src);
                 bad = bad || (in1 && cand >= 0 && kj == ckey && tj == cts);
             }
-            if (__ballot(bad) != 0ull) return false;
+            if (__ballot(bad) != 0ull) { LEANC(4); return false; }
             CRIT(1);
             const int lt = both & 0xff, sp = both >> 8;
             const bool full = (S >> drop) & 1ull;               // the cut falls on a run start: exactly k candidates are kept
@@ -2206,7 +2211,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
                 // a picked member of the previous hop's straddling run that is kept here (or ties with the cut) needs the
                 // previous hop's replay first: the general code waits for it
                 const int thr = full ? drop : rsG;
-                if (__ballot(lane < munc && lt >= thr) != 0ull) return false;
+                if (__ballot(lane < munc && lt >= thr) != 0ull) { LEANC(5); return false; }
             }
             // ---- provisional slots: the candidate at sorted position p >= drop takes slot p - drop ----
             const u64 nmask = ((u64)2 << (n - 1)) - 1ull;       // positions 0 .. n-1 (n <= 63)
