@@ -510,7 +510,7 @@ __global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 4 && threadIdx.x != 2)
 // The whole prepass as ONE workgroup, for launches of at most PRE_FUSED_MAX accesses (small batches: there the ten
 // launches above cost more on the host and in launch gaps than the work itself).  Same steps, same arrays, same
 // results; the steps are separated by workgroup barriers instead of kernel boundaries.
-constexpr int PRE_FUSED_MAX = 4096;
+constexpr int PRE_FUSED_MAX = 12288;
 constexpr int PRE_THREADS = 1024;
 __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
