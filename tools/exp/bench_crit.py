@@ -12,8 +12,8 @@ try:
 except SystemExit:
     pass
 lib = _capi.lib()
-c2 = np.zeros((8192, 16), np.int64)
-lib.zt_debug_crit(c2.ctypes.data_as(C.c_void_p), C.c_int(8192))
+c2 = np.zeros((8200, 16), np.int64)
+lib.zt_debug_crit(c2.ctypes.data_as(C.c_void_p), C.c_int(8200))
 p = lambda a: np.percentile(a, [10, 50, 90]).round(0)
 for mo in (0, 1):
     c = c2[mo * 4096:(mo + 1) * 4096]
@@ -50,3 +50,5 @@ for mo in (0, 1):
         mo, dict(zip(*np.unique(non[:, 9], return_counts=True))), int((non[:, 11] == 0).sum())))
     print("model %d: lean section left at (1 not sorted / norm, 2 no prune, 3 alternate may be in the row, 4 key match / NaN, 5 picked member kept): %s" % (
         mo, dict(zip(*np.unique(non[non[:, 10] < 100][:, 10], return_counts=True)))))
+r = c2[8199]
+print("model 0, all chains and launches since the library was loaded: lean %d; left at 1 not sorted / norm %d, 2 no prune %d, 3 alternate may be in the row %d, 4 key match / NaN %d, 5 picked member kept %d; lean not tried: prepared but left (sum of 1-5) %d, no norm prediction %d, slot functions clash %d, NaN / k %d" % tuple(int(x) for x in (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9])))

@@ -235,7 +235,7 @@ constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock:
 // -DZT_CRIT (diagnostic build, tools/crit_profile.py): core-clock readings at four points of a hub hop, kept in
 // registers and written out at the end of the hop -- the chain itself is not disturbed by stores
 #ifdef ZT_CRIT
-__device__ long long g_crit[8192 * 16];    // per hub edge (model 0): see tools/crit_profile.py
+__device__ long long g_crit[8200 * 16];    // per hub edge (model 0): see tools/crit_profile.py
 #define CRIT(j) do { crit_t[j] = (long long)__builtin_readcyclecounter(); } while (0)
 #define CRITP(j) do { if (crit_p) crit_p[j] = (long long)__builtin_readcyclecounter(); } while (0)
 #define CRIT_ARG , long long *crit_p = nullptr
@@ -286,6 +286,17 @@ __device__ __forceinline__ int key_hash(u64 key)
 __device__ __forceinline__ int key_hash2(u64 key)
 {
     return (int)((((unsigned)key * 0x85EBCA77u) ^ ((unsigned)(key >> 32) * 0xC2B2AE3Du)) >> 22);
+}
+
+// ... and a third (chain hops: both of the others clash for ~2 % of the partner rows)
+__device__ __forceinline__ int key_hash3(u64 key)
+{
+    return (int)((((unsigned)key * 0x27D4EB2Fu) ^ ((unsigned)(key >> 32) * 0x165667B1u)) >> 22);
+}
+// by the code chain_hop keeps in pre_hash: 1, 3, 5 = the table was filled with slot function 1, 2, 3
+__device__ __forceinline__ int key_hash_by(u64 key, int code)
+{
+    return code == 5 ? key_hash3(key) : (code == 3 ? key_hash2(key) : key_hash(key));
 }
 
 __host__ __device__ inline u64 granule(unsigned tag, unsigned payload) { return ((u64)tag << 32) | payload; }
@@ -2038,15 +2049,15 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (lenp > 0) {
         pre_hash = 2;
 #pragma unroll
-        for (int var = 0; var < 2; ++var) {
-            const int hs = var == 0 ? key_hash(rp.key) : key_hash2(rp.key);
+        for (int var = 0; var < 3; ++var) {
+            const int hs = key_hash_by(rp.key, 2 * var + 1);
             if (lane < lenp) L.htab[hs] = lane;
             wave_sync();
             const int back = lane < lenp ? L.htab[hs] : lane;
             const bool clash = __ballot(lane < lenp && back != lane) != 0ull;
             if (clash && lane < lenp) L.htab[hs] = -1;           // (several lanes may clear one slot)
             wave_sync();
-            if (!clash) { pre_hash = var == 0 ? 1 : 3; h2slot = hs; break; }
+            if (!clash) { pre_hash = 2 * var + 1; h2slot = hs; break; }
         }
     }
     const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)pnode;      // (edge_idx, partner, ts) enters the hub's dictionary
@@ -2133,7 +2144,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     // lanes the candidates live in.  Every test that fails BEFORE anything is written leaves the hop to the general
     // code below, which starts from the mailbox again.
 #ifdef ZT_CRIT
-#define LEANC(c) do { crit_t[10] = (c); } while (0)
+#define LEANC(c) do { crit_t[10] = (c); if (lane == 0 && mo == 0) atomicAdd((unsigned long long *)&g_crit[8199 * 16 + (c)], 1ull); } while (0)
 #else
 #define LEANC(c) do { } while (0)
 #endif
@@ -2166,12 +2177,12 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
                 // members of a straddling run that were not picked may turn out to be in the row (see below)
                 const u64 alt = in_slot->alt_key[lane & 31];
                 bool t = lane < nalt && alt == nkey;
-                if (table) t = t || (lane < nalt && L.htab[pre_hash == 3 ? key_hash2(alt) : key_hash(alt)] >= 0);
+                if (table) t = t || (lane < nalt && L.htab[key_hash_by(alt, pre_hash)] >= 0);
                 if (__ballot(t) != 0ull) { LEANC(3); return false; }
             }
             // is a key of the hub's row in the partner's row?  Read now, looked at after the network
             const bool in1 = lane < n1;
-            const int cand = (table && in1) ? L.htab[pre_hash == 3 ? key_hash2(ckey) : key_hash(ckey)] : -1;
+            const int cand = (table && in1) ? L.htab[key_hash_by(ckey, pre_hash)] : -1;
             const double inf = __longlong_as_double(0x7ff0000000000000ll);
             double sw = pre_b.sw;
             int sid = pre_b.sid;
@@ -2276,16 +2287,17 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (!settled && hub_munc > 0) {
         // members of a straddling run that were not picked may turn out to be in the row (process_edge)
         bool t = lane < hub_nalt && hub_alt == nkey;
-        if (pre_hash == 1 || pre_hash == 3) t = t || (lane < hub_nalt && L.htab[pre_hash == 3 ? key_hash2(hub_alt) : key_hash(hub_alt)] >= 0);
+        if (pre_hash == 1 || pre_hash == 3 || pre_hash == 5) t = t || (lane < hub_nalt && L.htab[key_hash_by(hub_alt, pre_hash)] >= 0);
         if (__ballot(t) != 0ull || pre_hash == 2) { hub_to_dict(); settled = true; }
     }
     CRIT(10);
 #ifdef ZT_CRIT
     crit_t[11] = hub_sorted ? 0 : 5;
 #endif
-    if (!(hub_sorted && merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_hash == 3 || lenp == 0,
-                                         pre_hash == 3, F CRIT_PASS))) {
-        if (pre_hash == 3) {                                     // merge_front probes with the first slot function: start it clean
+    if (!(hub_sorted && pre_hash != 5 &&
+          merge_front_fast(L, lane, k, rh, rp, pre_b, pre_scale, nkey, tnow, pre_hash == 1 || pre_hash == 3 || lenp == 0,
+                           pre_hash == 3, F CRIT_PASS))) {
+        if (pre_hash == 3 || pre_hash == 5) {                                     // merge_front probes with the first slot function: start it clean
             if (lane < lenp) L.htab[h2slot] = -1;
             wave_sync();
             pre_hash = 0;
@@ -2430,6 +2442,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef ZT_CRIT
     if (lean_done) { CRIT(6); crit_t[7] = 1; }
+    if (lane == 0 && mo == 0) atomicAdd((unsigned long long *)&g_crit[8199 * 16 + (lean_done ? 0 : (pre_b.ok ? 6 : (!pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : 9))))], 1ull);
     crit_t[15] = (long long)chain_idx * 100000 + tpos;
     crit_t[12] = mail->t_start;
     if (lane == 0 && mo < 2 && i < 4096 && (A.B <= 4096 || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
