@@ -107,6 +107,8 @@ def test_fill_and_snapshots(zt):
     dict(N=500, E=12000, bs=4096, k=20, al=[0.1, 0.1], be=[0.5, 0.95], kind="hub", seed=102),
     dict(N=3000, E=9000, bs=1000, k=40, al=[0.2], be=[0.8], kind="general", seed=103),
     dict(N=300, E=3000, bs=200, k=63, al=[0.0], be=[0.6], kind="general", seed=104),
+    dict(N=400, E=12288, bs=4096, k=30, al=[0.2, 0.0], be=[0.95, 0.5], kind="hub", seed=105),   # the largest k with hub chains
+    dict(N=400, E=12288, bs=4096, k=31, al=[0.2, 0.0], be=[0.95, 0.5], kind="hub", seed=106),   # ... and the first without
 ])
 def test_streaming_vs_oracle(zt, oracle, cfg):
     """Seeded streams at sizes the oracle finishes in seconds: every batch's
@@ -584,3 +586,13 @@ def test_grid_larger_than_the_run_stream(zt, oracle):
     finally:
         torch.cuda.synchronize()
         check(lib().zt_stream_destroy(hs))
+
+
+def test_randomised_soak(zt, oracle):
+    """A slice of tests/soak_tppr.py (random graph shapes, k, batch sizes up to 16384-edge launches, alpha / beta with
+    exact ties, self-loops, negatives on endpoints and hubs, repeated timestamps): every batch and the final state
+    bit-identical to the oracle.  Seed 1011 (k = 31, full partner rows) is the one that found the lane-63 bug."""
+    import soak_tppr
+    for seed in list(range(1000, 1050)) + [1011]:
+        err = soak_tppr.one(seed, zt, oracle)
+        assert err is None, err

@@ -184,7 +184,7 @@ struct zt_tppr {
     unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
     unsigned *cdone; // [M][MAX_CHUNK] the same for the CHAIN's reads of a chain-owned edge (hub + partner row)
     u64 *hubver;     // [M][MAX_CHAINS][CH_MAX + 1][rg]: version t of a chain's hub row = the row before chain position t
-                     // (dictionary order, tagged with the launch epoch), or nullptr (k > 31: no chains)
+                     // (dictionary order, tagged with the launch epoch), or nullptr (k > REG_K_MAX: no chains)
     // hub chains of the launch
     int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
     int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts
@@ -229,6 +229,10 @@ struct zt_tppr {
 namespace {
 
 constexpr int CAP = 128;          // candidates per merge: 2k+1 <= 127
+// The register-resident merge (and with it the hub chains) keeps s2's entries in lanes 32 + j, the new key behind them,
+// and uses lane 63 as the lane nobody reads in its cross-lane pushes: 32 + k <= 62.  (k = 31 put the new key of a full
+// partner row INTO lane 63 -- found by tests/soak_tppr.py, never by the fixed-size tests: k = 5, 20, 40, 63.)
+constexpr int REG_K_MAX = 30;
 constexpr int WAVES_PER_WG = 8;
 constexpr long long WAIT_TICKS = 400000000ll;  // 4 s of the 100 MHz wall clock: bound on any dependency wait
 
@@ -830,7 +834,7 @@ struct Front {
     u64 S;             // uniform: positions where a run of equal weights starts
 };
 
-// The same pair update with the candidate list held in REGISTERS, for k <= 31: s1's entries stay in lanes
+// The same pair update with the candidate list held in REGISTERS, for k <= REG_K_MAX = 30: s1's entries stay in lanes
 // [0, n1), s2's entries move to lanes 32 + j with ONE v_permlane32_swap per register (no LDS), the new key
 // sits behind them.  The top-k works on these register values (topk_reg: ranks by lane broadcasts, tie
 // test by a DPP OR-reduction, quicksort replay on the compacted ranks only when ties decide).  Compared
@@ -972,7 +976,7 @@ __device__ inline void merge_front(WaveLds &L, int lane, int k, double alpha, do
     u64 live = (n1 > 0 ? ((1ull << n1) - 1ull) : 0ull) | (um << 32);
     int pos = lane < 32 ? lane : n1 + __popcll((um << 32) & lanemask_lt());     // place in the reference's dictionary order
     if (!present) {
-        const int nl = 32 + len2;                                               // <= 63 (len2 <= k <= 31)
+        const int nl = 32 + len2;                                               // <= 62 (len2 <= k <= 30)
         if (lane == nl) { ck = newkey; ct = newts; cw = v; pos = n; }
         live |= 1ull << nl;
         ++n;
@@ -1028,7 +1032,7 @@ __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u
                                  const PreScale &ps, PreB &B, int h2slot)
 {
     B.ok = false;
-    if (!ps.valid || k > 31) return;
+    if (!ps.valid || k > REG_K_MAX) return;
     const int len2 = __builtin_amdgcn_readfirstlane((r2.norm != 0.0) ? r2.len : 0);
     const bool in2 = lane < len2;
     const double v = (alpha != 0.0) ? ps.scale_s2 * alpha : ps.scale_s2;           // :531 / :540-541
@@ -1735,7 +1739,7 @@ __device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveL
         const long long x1 = sw ? v : u, x2 = sw ? u : v;
         const int o1 = sw ? wo_v : wo_u, o2 = sw ? wo_u : wo_v;
         // (edge_idx, s2, ts) is the key entering s1's dictionary
-        const bool reg_path = k <= 31;          // 2k+1 candidates fit one wavefront: register-resident merge
+        const bool reg_path = k <= REG_K_MAX;   // 2k+1 candidates fit one wavefront: register-resident merge
         Cand c;
         // a slot of the ring is reused every MAIL_R positions: wait until the reader of its previous content
         // (chain position tpos - MAIL_R + 1) has let go of it
@@ -1978,7 +1982,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
                                  long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint, int chain_idx,
                                  const HopRec &rec)
 {
-    if (prev_edge < 0 || h.k > 31) return false;
+    if (prev_edge < 0 || h.k > REG_K_MAX) return false;
     const int k = h.k;
     const int m = A.m_lo + mo;
     if (rec.partner < 0) return false;
@@ -2679,7 +2683,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     ZT_HIP(hipMalloc(&h->cdone, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     ZT_HIP(hipMemset(h->cdone, 0, sizeof(unsigned) * (size_t)MAX_CHUNK * n_tppr));
     h->hubver = nullptr;
-    if (k <= 31) {                                    // hub chains (register-resident merge) exist for k <= 31 only
+    if (k <= REG_K_MAX) {                             // hub chains (register-resident merge) exist for k <= 30 only
         const size_t vb = (size_t)n_tppr * MAX_CHAINS * (CH_MAX + 1) * h->rg * sizeof(u64);
         ZT_HIP(hipMalloc(&h->hubver, vb));
         ZT_HIP(hipMemset(h->hubver, 0, vb));
@@ -2820,8 +2824,8 @@ static void launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *gr
     if (waves > max_waves) waves = max_waves;
     const int grid = (int)((waves + WAVES_PER_WG - 1) / WAVES_PER_WG);
     *grid_out = grid;
-    // the chain hand-off (two-stage mailbox) is built on the register-resident merge: k <= 31
-    *max_chains_out = h->k <= 31 ? chains_for_grid(grid, n_models) : 0;
+    // the chain hand-off (two-stage mailbox) is built on the register-resident merge: k <= 30
+    *max_chains_out = h->k <= REG_K_MAX ? chains_for_grid(grid, n_models) : 0;
 }
 
 // The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
