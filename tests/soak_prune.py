@@ -1,0 +1,90 @@
+"""Randomised parity soak of the pruning T-PPR (NeighborFinder.get_pruned_topk, k_pruned_topk) against the CPU oracle --
+test infrastructure, run on a GPU box:   python tests/soak_prune.py [seconds] [first seed]
+Random static graphs (power-law / dense / tiny), repeated timestamps (ties in time), width, depth, k (candidate lists of a
+few to > 128 entries: every selection path), alpha / beta with exact ties, query times inside and beyond the history,
+queries on nodes without history; single-model and multi-model launches must agree with the oracle bit for bit."""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def one(seed, tppr, pyoracle, torch):
+    rng = np.random.RandomState(seed)
+    N = int(rng.choice([8, 40, 500, 20000]))
+    E = int(rng.choice([50, 2000, 40000]))
+    width = int(rng.choice([1, 2, 3, 5, 10, 10]))
+    depth = int(rng.choice([1, 2, 2, 3]))
+    cap = sum(width ** d for d in range(1, depth + 1))
+    if cap > 1000:
+        depth = 2
+    k = int(rng.choice([1, 5, 10, 20, 40, 63]))
+    M = int(rng.choice([1, 2, 3]))
+    al = [float(rng.choice([0.0, 0.1, 0.3])) for _ in range(M)]
+    be = [float(rng.choice([0.5, 0.25, 0.8, 0.95])) for _ in range(M)]
+    expo = float(rng.choice([0.0, 0.8, 1.2]))
+    p = 1.0 / np.arange(1, N) ** expo
+    p /= p.sum()
+    perm = rng.permutation(N - 1) + 1
+    src = perm[rng.choice(N - 1, E, p=p)].astype(np.int32)
+    dst = perm[rng.choice(N - 1, E, p=p)].astype(np.int32)
+    ts = np.cumsum(rng.randint(0, int(rng.choice([2, 3, 40])), E)).astype(np.float64)
+    eidx = np.arange(1, E + 1, dtype=np.int64)
+    nf = tppr.get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+    csr = pyoracle.CsrOracle(src, dst, eidx, ts, nf.num_nodes)
+    nq = int(rng.choice([7, 300, 1500]))
+    q = rng.randint(0, nf.num_nodes, nq).astype(np.int32)            # (node 0 and nodes without history: empty dictionaries)
+    qt = rng.choice(np.concatenate([ts, [ts[-1] + 5.0, 0.0]]), nq).astype(np.float64)
+    tag = "seed %d: N=%d E=%d width=%d depth=%d k=%d M=%d alpha=%s beta=%s" % (seed, N, E, width, depth, k, M, al, be)
+    want = []
+    for m in range(M):
+        outs = [np.zeros((nq, k), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+        csr.get_pruned_topk(q, qt, width, depth, al[m], be[m], k, *outs)
+        want.append(outs)
+        got = [np.zeros((nq, k), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+        nf.get_pruned_topk(q, qt, width, depth, al[m], be[m], k, *got)
+        for x, y, nm in zip(got, outs, ("nodes", "eidx", "dt", "w")):
+            if not np.array_equal(x, y):
+                return "%s: %s differs (single-model launch, model %d)" % (tag, nm, m)
+    if os.environ.get("ZT_SOAK_VERBOSE"):
+        print(tag, "| rows with neighbours: %.2f, mean entries %.1f" % ((want[0][3] > 0).any(axis=1).mean(), (want[0][3] > 0).sum(axis=1).mean()), flush=True)
+    dev = torch.device("cuda")
+    qd, td = torch.from_numpy(q).to(dev), torch.from_numpy(qt).to(dev)
+    mo = [torch.zeros((M, nq, k), dtype=dt, device=dev) for dt in (torch.int32, torch.int32, torch.float32, torch.float32)]
+    nf.pruned_topk_multi_device(qd, td, width, depth, al, be, k, *mo)
+    for m in range(M):
+        for x, y, nm in zip(mo, want[m], ("nodes", "eidx", "dt", "w")):
+            if not np.array_equal(x[m].cpu().numpy(), y):
+                return "%s: %s differs (multi-model launch, model %d)" % (tag, nm, m)
+    return None
+
+
+def main():
+    import torch
+    assert torch.cuda.is_available()
+    from zebra_amd import tppr
+    import pyoracle
+    pyoracle.lib()
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+    t0, n = time.time(), 0
+    while time.time() - t0 < budget:
+        err = one(seed, tppr, pyoracle, torch)
+        if err:
+            print("FAIL", err)
+            sys.exit(1)
+        n += 1
+        seed += 1
+        if n % 20 == 0:
+            print("%d configurations bit-identical (%.0f s)" % (n, time.time() - t0), flush=True)
+    print("soak ok: %d configurations, seeds up to %d" % (n, seed - 1))
+
+
+if __name__ == "__main__":
+    main()

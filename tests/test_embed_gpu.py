@@ -1012,3 +1012,13 @@ def test_specialised_aggregate_equals_generic(F, k, n):
     plain = em.embed_device(tgn.memory.memory, nodes, *args).cpu().numpy()          # no table at all
     assert np.abs(fast - slow).max() <= 2e-5 * max(1.0, np.abs(slow).max())
     assert np.abs(fast - plain).max() <= 1e-4 * max(1.0, np.abs(plain).max())
+
+
+def test_randomised_pipeline_soak(oracle):
+    """A slice of tests/soak_pipeline.py: random node counts, batch sizes (ragged last batches), k, layer widths (every
+    aggregation kernel), feature widths, launch groups, CU masks, views ahead, shuffled ids -- the whole step through the
+    native pipeline against the oracle's protocol (embeddings <= 1e-4 per batch, T-PPR state bit-exact, memory tables)."""
+    import soak_pipeline
+    for seed in range(9000, 9030):
+        err = soak_pipeline.one(seed, torch, oracle)
+        assert err is None, err

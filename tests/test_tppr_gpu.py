@@ -596,3 +596,14 @@ def test_randomised_soak(zt, oracle):
     for seed in list(range(1000, 1050)) + [1011]:
         err = soak_tppr.one(seed, zt, oracle)
         assert err is None, err
+
+
+def test_randomised_prune_soak(zt, oracle):
+    """A slice of tests/soak_prune.py: random static graphs, width, depth, k (candidate lists from a few to > 128 entries),
+    alpha / beta with exact ties, ties in time, nodes without history; single-model and multi-model launches of
+    k_pruned_topk bit-identical to the oracle."""
+    import torch
+    import soak_prune
+    for seed in range(5000, 5200):
+        err = soak_prune.one(seed, zt, oracle, torch)
+        assert err is None, err
