@@ -49,15 +49,31 @@ def one(seed, tppr, pyoracle):
         print("seed %d: N=%d k=%d bs=%d nb=%d M=%d alpha=%s beta=%s expo=%.1f" % (seed, N, k, bs, nb, M, al, be, expo), flush=True)
     f = tppr.tppr_finder(N, k, M, al, be)
     o = pyoracle.TpprOracle(N, k, M, al, be)
+    variants = rng.random_sample() < 0.4                 # the other entry points of the finder, batch by batch
     for s in range(0, E, bs):
         e = s + bs
         nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
-        a = f.streaming_topk(nodes, ts[s:e], eidx[s:e])
-        b = o.streaming_topk(nodes, ts[s:e], eidx[s:e])
+        v = rng.randint(4) if variants else 0
+        if v == 1:                                       # utils/util.py:682-782
+            n2 = np.concatenate([src[s:e], dst[s:e]])
+            a, b = f.streaming_topk_no_fake(n2, ts[s:e], eidx[s:e]), o.streaming_topk_no_fake(n2, ts[s:e], eidx[s:e])
+        elif v == 2:                                     # utils/util.py:581-679, model after model
+            a, b = [[] for _ in range(4)], [[] for _ in range(4)]
+            for m in range(M):
+                ga = f.single_streaming_topk(nodes, ts[s:e], eidx[s:e], m)
+                gb = o.single_streaming_topk(nodes, ts[s:e], eidx[s:e], m)
+                for q in range(4):
+                    a[q].append(ga[q]); b[q].append(gb[q])
+        elif v == 3:                                     # utils/util.py:787-873: update only, nothing emitted
+            f.compute_val_tppr(src[s:e], dst[s:e], ts[s:e], eidx[s:e])
+            o.update_only(src[s:e], dst[s:e], ts[s:e], eidx[s:e])
+            continue
+        else:
+            a, b = f.streaming_topk(nodes, ts[s:e], eidx[s:e]), o.streaming_topk(nodes, ts[s:e], eidx[s:e])
         for x, y, nm in zip(a, b, ("nodes", "eidx", "dt", "w")):
             if not np.array_equal(np.stack(x), np.stack(y)):
-                return "seed %d: %s differs in the batch at %d (N=%d k=%d bs=%d M=%d alpha=%s beta=%s expo=%.1f)" % (
-                    seed, nm, s, N, k, bs, M, al, be, expo)
+                return "seed %d: %s differs in the batch at %d, entry point %d (N=%d k=%d bs=%d M=%d alpha=%s beta=%s expo=%.1f)" % (
+                    seed, nm, s, v, N, k, bs, M, al, be, expo)
     for m in range(M):
         ga, wa = f.export_state(m), o.export(m)
         for kk in ("len", "norm", "eidx", "node", "ts", "w"):
