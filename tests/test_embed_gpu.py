@@ -1022,3 +1022,13 @@ def test_randomised_pipeline_soak(oracle):
     for seed in range(9000, 9030):
         err = soak_pipeline.one(seed, torch, oracle)
         assert err is None, err
+
+
+def test_randomised_training_soak():
+    """A slice of tests/soak_train.py: the fused HIP training path (aggregation over the overlay, GRU rows, fc2, source
+    transform; forward and backward) against the torch composition on random shapes -- embeddings to 1e-5, every parameter
+    gradient to 1e-4 of its scale (ReLU units flipped by rounding are identified and set aside)."""
+    import soak_train
+    for seed in range(30000, 30060):
+        err = soak_train.one(seed, torch)
+        assert err is None, err
