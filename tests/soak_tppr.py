@@ -50,8 +50,18 @@ def one(seed, tppr, pyoracle):
     f = tppr.tppr_finder(N, k, M, al, be)
     o = pyoracle.TpprOracle(N, k, M, al, be)
     variants = rng.random_sample() < 0.4                 # the other entry points of the finder, batch by batch
+    reload_at = int(rng.randint(1, nb)) * bs if rng.random_sample() < 0.3 else -1
+    backup = None
     for s in range(0, E, bs):
         e = s + bs
+        if s == reload_at:
+            # checkpoint round trip in mid-stream: the rows of the touched nodes into a NEW finder (state_dict /
+            # load_state_dict), which carries on; and a snapshot (backup_tppr) that the old finder must get back later
+            touched = np.unique(np.concatenate([src[:s], dst[:s]])).astype(np.int64)
+            sd = f.state_dict(touched)
+            backup = (f, f.backup_tppr(), [f.export_state(m) for m in range(M)])
+            f = tppr.tppr_finder(N, k, M, al, be)
+            f.load_state_dict(sd)
         nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])
         v = rng.randint(4) if variants else 0
         if v == 1:                                       # utils/util.py:682-782
@@ -79,6 +89,16 @@ def one(seed, tppr, pyoracle):
         for kk in ("len", "norm", "eidx", "node", "ts", "w"):
             if not np.array_equal(ga[kk], wa[kk]):
                 return "seed %d: final state %s of model %d differs (N=%d k=%d bs=%d)" % (seed, kk, m, N, k, bs)
+    if backup is not None:                               # the old finder went on existing: restore its snapshot
+        f0, snap, want0 = backup
+        nodes = np.concatenate([src[:bs], dst[:bs], neg[:bs]])
+        f0.streaming_topk(nodes, ts[E - bs:E] + 1.0, eidx[:bs] + E)        # (disturb it first)
+        f0.restore_tppr(snap)
+        for m in range(M):
+            g0 = f0.export_state(m)
+            for kk in ("len", "norm", "eidx", "node", "ts", "w"):
+                if not np.array_equal(g0[kk], want0[m][kk]):
+                    return "seed %d: state %s of model %d differs after backup_tppr / restore_tppr" % (seed, kk, m)
     return None
 
 
