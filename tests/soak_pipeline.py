@@ -37,9 +37,11 @@ def one(seed, torch, pyoracle):
     look = int(rng.randint(0, 3 * group + 2))
     ragged = rng.random_sample() < 0.3
     perm = None if rng.random_sample() < 0.5 else int(rng.randint(1, 100))
+    strategy = "pruning" if rng.random_sample() < 0.3 else "streaming"
+    width, depth = [(10, 2), (5, 2), (3, 3), (10, 1)][rng.randint(4)]
     E = bs * nb - (int(rng.randint(1, bs)) if ragged and bs > 1 else 0)
-    tag = "seed %d: N=%d bs=%d nb=%d E=%d k=%d D=%d T=%d F=%d M=%d beta=%s group=%d cus=%d look=%d perm=%s" % (
-        seed, N, bs, nb, E, k, D, T, F, M, be, group, cus, look, perm)
+    tag = "seed %d: %s N=%d bs=%d nb=%d E=%d k=%d D=%d T=%d F=%d M=%d beta=%s group=%d cus=%d look=%d perm=%s width=%d depth=%d" % (
+        seed, strategy, N, bs, nb, E, k, D, T, F, M, be, group, cus, look, perm, width, depth)
     if os.environ.get("ZT_SOAK_VERBOSE"):
         print(tag, flush=True)
     bip = (max(1, N // 3), N - max(1, N // 3)) if rng.randint(2) else None
@@ -51,16 +53,23 @@ def one(seed, torch, pyoracle):
     dev = torch.device("cuda")
     t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
     batches = [tuple(x[b * bs:min(E, (b + 1) * bs)] for x in t) for b in range(nb)]
-    tgn = build_tgn(N + 1, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    nf = ref_nf = None
+    if strategy == "pruning":                       # the static graph of the whole stream (the reference's full_ngh_finder)
+        import types
+        from zebra_amd.tppr import get_neighbor_finder
+        nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+        ref_nf = pyoracle.CsrOracle(src, dst, eidx, ts, N + 1)
+    tgn = build_tgn(N + 1, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf, width=width, depth=depth).eval()
     tgn.enable_pipeline(tppr_cus=cus, group=group, max_batch=max(bs, 64))
-    p = pyoracle.ProtocolOracle(N + 1, D, F, T, k, al, be, w, efeat, tw, n_threads=8)
+    p = pyoracle.ProtocolOracle(N + 1, D, F, T, k, al, be, w, efeat, tw, strategy, ref_nf, width, depth, n_threads=8)
     embs = []
     try:
         with torch.cuda.stream(tgn.main_stream):
             for b, cur in enumerate(batches):
                 embs.append(tgn.step_device(*cur, ahead=batches[b + 1: b + 1 + look]).clone())
         torch.cuda.synchronize()
-        tgn.embedding_module.tppr_finder.check_status()
+        if strategy == "streaming":
+            tgn.embedding_module.tppr_finder.check_status()
         worst = 0.0
         for b in range(nb):
             s, e = b * bs, min(E, (b + 1) * bs)
@@ -68,8 +77,8 @@ def one(seed, torch, pyoracle):
             worst = max(worst, float(np.abs(embs[b].cpu().numpy() - ref).max()))
         if not worst <= TOL:
             return "%s: embeddings differ from the oracle by %g" % (tag, worst)
-        f = tgn.embedding_module.tppr_finder
-        for m in range(M):
+        f = tgn.embedding_module.tppr_finder if strategy == "streaming" else None
+        for m in range(M if strategy == "streaming" else 0):
             a, bb = f.export_state(m), p.tppr.export(m)
             for kk in a:
                 if not np.array_equal(a[kk], bb[kk]):
