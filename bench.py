@@ -238,6 +238,8 @@ def main():
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-clock-spin", action="store_true",
+                    help="skip the throw-away GPU work between the warm-state snapshot (seconds of host work, GPU idle) and the warm-up steps")
     ap.add_argument("--profile-every", type=int, default=-1,
                     help="record HIP events around every n-th launch of the main stream's kernels (default 4: two "
                          "event records per kernel and step cost ~3 %% of the step; the T-PPR update, one launch per "
@@ -400,6 +402,18 @@ def main():
             seen = (pos < len(touched)) & (touched[np.minimum(pos, len(touched) - 1)] == ends)
             ln = np.where(seen, snap["tppr"][0]["len"][np.minimum(pos, len(touched) - 1)], 0)
             fill = dict(mean_row_len=float(ln.mean()), frac_empty=float((ln == 0).mean()), frac_full=float((ln == k).mean()))
+    if cpu_nb and not a.no_clock_spin:
+        # the snapshot above left the GPU idle for seconds (host-side export of the warm state): its clocks have dropped,
+        # and W = 5 warm-up steps (2 ms) do not bring them back.  Throw-away matrix products for a third of a second, on
+        # data that has nothing to do with the stream, before the warm-up steps -- so that the timed region measures the
+        # path and not the clock ramp
+        xa = torch.randn((4096, 4096), device=device)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.35:
+            for _ in range(20):
+                xa = torch.mm(xa, xa).clamp_(-1.0, 1.0)
+            torch.cuda.synchronize()
+        del xa
     run(prefill, a.warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
