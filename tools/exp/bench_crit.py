@@ -1,7 +1,8 @@
 # bench.py against the -DZT_CRIT library (tools/build_crit.sh), then the hub-hop stamps of the LAST T-PPR launch of the run:
 # hop times inside the pipeline (beside the aggregation, on the T-PPR stream's CUs), for the edges of the launch's first batch
 #   python3 tools/exp/bench_crit.py --steps 40 --cpu-edges 0
-import sys, runpy, ctypes as C
+import os, sys, runpy, ctypes as C
+os.environ["ZT_CRIT_MULTI"] = "1"
 import numpy as np
 sys.path.insert(0, '/root/repo')
 from zebra_amd import _capi
@@ -19,7 +20,7 @@ for mo in (0, 1):
     c = c2[mo * 4096:(mo + 1) * 4096]
     c = c[(c[:, 3] > 0) & (c[:, 0] > 0)]
     c = c[np.argsort(c[:, 3])]
-    c = c[c[:, 3] > c[:, 3].max() - 3_000_000]        # stamps of the last launch over 3+ batches only (its first batch's edges)
+    c = c[c[:, 3] > c[:, 3].max() - 4_200_000]        # stamps of the last launch over 3+ batches only (its first batch's edges)
     ch = c[:, 15] // 100000
     big = np.bincount(ch.astype(np.int64)).argmax()   # the hub's chain: the one with the most hops
     c = c[ch == big]

@@ -1450,6 +1450,7 @@ struct StreamArgs {
     float *out_dt, *out_w;
     unsigned epoch;
     int chain_waves;   // waves of a chain workgroup that take chain hops (the others exit: the chain wave keeps its SIMD)
+    int crit_multi;    // diagnostic build: stamps of launches over 3+ batches only (ZT_CRIT_MULTI=1: tools/exp/bench_crit.py)
     int sub_B;         // > 0: the launch covers several consecutive batches of sub_B edges (the last may be shorter); the
                        // output rows of batch g form their own [n_models][n_roles][B_g][k] block, blocks back to back
 };
@@ -2449,7 +2450,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
     if (lane == 0 && mo == 0) atomicAdd((unsigned long long *)&g_crit[8199 * 16 + (lean_done ? 0 : (pre_b.ok ? 6 : (!pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : 9))))], 1ull);
     crit_t[15] = (long long)chain_idx * 100000 + tpos;
     crit_t[12] = mail->t_start;
-    if (lane == 0 && mo < 2 && i < 4096 && (A.B <= 4096 || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
+    if (lane == 0 && mo < 2 && i < 4096 && ((A.B <= 4096 && !A.crit_multi) || A.B >= 12288))   // (model 1 in the upper half: tools/crit_profile.py;
                                                                  //  in a pipelined run the launches over 3+ batches only)
         for (int q = 0; q < 16; ++q) if (q != 14) g_crit[(mo * 4096 + i) * 16 + q] = crit_t[q];
 #endif
@@ -2910,6 +2911,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.sub_B = sub_B;
     static const int chain_waves_env = getenv("ZT_CHAIN_WAVES") ? atoi(getenv("ZT_CHAIN_WAVES")) : 8;
     sa.chain_waves = chain_waves_env < 1 ? 1 : (chain_waves_env > WAVES_PER_WG ? WAVES_PER_WG : chain_waves_env);
+    static const int crit_multi_env = getenv("ZT_CRIT_MULTI") ? atoi(getenv("ZT_CRIT_MULTI")) : 0;
+    sa.crit_multi = crit_multi_env;
 #ifdef ZT_WAITLOG
     {
         void *wl = nullptr;
