@@ -84,3 +84,16 @@ lag = (cm[:, 14] - cm[:, 3])[(cm[:, 14] > cm[:, 3]) & (cm[:, 3] > 0) & (cm[:, 14
 if len(lag):
     qq = len(lag) // 4
     print("partner task done - publication of its hop (us), by quarter of the chain (median): " + " | ".join("%.1f" % np.median(lag[a:a + qq]) for a in range(0, 4 * qq, qq)) + "   last ten: " + " ".join("%.0f" % x for x in lag[-10:]))
+part = np.where(u[idx] == hub, v[idx], u[idx])
+dist = np.full(len(idx), 10 ** 6)
+for t in range(len(idx)):
+    w = np.where(part[max(0, t - 64):t] == part[t])[0]
+    if len(w):
+        dist[t] = t - (max(0, t - 64) + w[-1])
+hop = np.concatenate([[0], np.diff(c[idx][:, 3])])
+prep = c[idx][:, 5] - c[idx][:, 4]
+rec = np.where(dist <= 64)[0]
+print("hub hops whose partner was the partner of one of the previous 64 hub hops: %d of %d; their distance / preparation / hop time (clocks):" % (len(rec), len(idx)))
+print("   " + " | ".join("%d %d %d" % (dist[t], prep[t], hop[t]) for t in rec[:40]))
+ok2 = (hop > 0) & (hop < 400000)
+print("   time of these hops above the median hop: %.0f clocks = %.1f %% of the chain's span" % ((hop[rec][ok2[rec]] - np.median(hop[ok2])).clip(min=0).sum(), 100 * (hop[rec][ok2[rec]] - np.median(hop[ok2])).clip(min=0).sum() / hop[ok2].sum()))
