@@ -338,16 +338,12 @@ def main():
     else:
         step = tgn.step_device
 
-    if a.group < 1:
-        # as many batches per T-PPR launch as fit (<= 16384 edges, <= 4), fewer for a short timed region: the first and the
-        # last batches of a region are queried one by one, which a 20-step run pays for with large groups
-        a.group = max(1, min(4, 16384 // bs, max(1, a.steps // 10))) if wl["strategy"] == "streaming" else 1
+    # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
+    # its real shape against the oracle with exactly these settings)
+    cus, a.group = synth.pipeline_settings(wl, a.steps, a.tppr_cus, a.group)
     if not a.no_pipeline:
         # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
-        if a.tppr_cus < 0:
-            # whole XCDs (32 CUs, one L2 each): a mask that splits an XCD leaves the main stream a straggler XCD.
-            # Two XCDs for the T-PPR stream at C5's batch (its non-hub tasks need the waves), one for small batches.
-            a.tppr_cus = (96 if bs >= 2048 else 32) if wl["strategy"] == "streaming" else 0
+        a.tppr_cus = cus
         # Several ranks: the same masks.  torch.distributed runs the RCCL kernel of the row exchange on a stream of
         # its own (ProcessGroupNCCL orders it against the current stream with events), so the masks neither confine nor
         # block it; without them the T-PPR kernel shares CUs with the aggregation (N = 1: 0.665 instead of 0.585

@@ -133,6 +133,21 @@ class TpprOracle:
         if rc != 0:
             raise IndexError("zo_tppr_import_rows rc=%d" % rc)
 
+    def export_rows(self, m, ids):
+        ids = _c(ids, np.int64)
+        n, k = len(ids), self.k
+        ln = np.empty(n, np.int32)
+        norm = np.empty(n, np.float64)
+        e = np.empty((n, k), np.int64)
+        nd = np.empty((n, k), np.int64)
+        ts = np.empty((n, k), np.float64)
+        w = np.empty((n, k), np.float64)
+        rc = lib().zo_tppr_export_rows(self._h, C.c_int32(m), _p(ids), C.c_int64(n), _p(ln), _p(norm), _p(e), _p(nd),
+                                       _p(ts), _p(w))
+        if rc != 0:
+            raise IndexError("zo_tppr_export_rows rc=%d" % rc)
+        return dict(len=ln, norm=norm, eidx=e, node=nd, ts=ts, w=w)
+
     def update_only(self, sources, targets, timestamps, edge_idxs):
         nodes = np.concatenate([_c(sources, np.int32), _c(targets, np.int32)])
         self._stream(nodes, timestamps, edge_idxs, 2, False, -1)

@@ -67,6 +67,10 @@ int zo_tppr_stream(zo_tppr *h, const int32_t *nodes, const double *ts,
 void zo_tppr_export(const zo_tppr *h, int32_t m, int32_t *len, double *norm,
                     int64_t *eidx, int64_t *node, double *ts, double *w);
 
+/* the same arrays for the n nodes ids[0..n) only (full-size graphs: the touched rows). */
+int zo_tppr_export_rows(const zo_tppr *h, int32_t m, const int64_t *ids, int64_t n, int32_t *len, double *norm,
+                        int64_t *eidx, int64_t *node, double *ts, double *w);
+
 /* the same arrays for the n nodes ids[0..n) only, written INTO the state (bench.py: warm start). */
 int zo_tppr_import_rows(zo_tppr *h, int32_t m, const int64_t *ids, int64_t n, const int32_t *len,
                         const double *norm, const int64_t *eidx, const int64_t *node, const double *ts,

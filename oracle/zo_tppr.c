@@ -160,6 +160,25 @@ void zo_tppr_export(const zo_tppr *h, int32_t m, int32_t *len, double *norm,
     memcpy(w, h->w + off * h->k, h->N * h->k * sizeof(double));
 }
 
+/* the export for n chosen nodes (arrays [n], [n][k]): full-size graphs, where only the touched rows are compared */
+int zo_tppr_export_rows(const zo_tppr *h, int32_t m, const int64_t *ids, int64_t n, int32_t *len, double *norm,
+                        int64_t *eidx, int64_t *node, double *ts, double *w)
+{
+    if (m < 0 || m >= h->M) return -2;
+    const size_t k = (size_t)h->k;
+    for (int64_t q = 0; q < n; ++q) {
+        if (ids[q] < 0 || ids[q] >= h->N) return -1;
+        size_t row = (size_t)m * (size_t)h->N + (size_t)ids[q];
+        len[q] = h->len[row];
+        norm[q] = h->norm[row];
+        memcpy(eidx + (size_t)q * k, h->eidx + row * k, k * sizeof(int64_t));
+        memcpy(node + (size_t)q * k, h->node + row * k, k * sizeof(int64_t));
+        memcpy(ts + (size_t)q * k, h->ts + row * k, k * sizeof(double));
+        memcpy(w + (size_t)q * k, h->w + row * k, k * sizeof(double));
+    }
+    return 0;
+}
+
 /* inverse of the export for n chosen nodes (arrays [n], [n][k]); other rows stay.  Used to start the
  * timed CPU baseline from the same warm state as the GPU run (bench.py). */
 int zo_tppr_import_rows(zo_tppr *h, int32_t m, const int64_t *ids, int64_t n, const int32_t *len,

@@ -457,6 +457,14 @@ def main():
     gen_prune_embed()
     gen_epoch()
     bad = 0
+    if a.check:
+        # the tie order of every fixture comes from numba_semantics.numba_argsort: pin it (and the C oracle's
+        # zo_numba_argsort) to numba's own quicksort.py, loaded standalone (oracle/numba_pin.py)
+        import numba_pin
+        import pyoracle
+        n_arr, n_bad = numba_pin.compare(extra=[pyoracle.numba_argsort])
+        print("numba pin: %d tie-heavy arrays against %s, %d mismatches" % (n_arr, numba_pin.quicksort_path(), n_bad))
+        bad += n_bad
     for name, arrays in OUT.items():
         path = os.path.join(HERE, name + ".npz")
         if a.check:

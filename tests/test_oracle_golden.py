@@ -115,6 +115,21 @@ def test_numba_int_pow_matches_python_restatement(oracle):
             assert np.array_equal(oracle.numba_argsort(v), ns.numba_argsort(v))
 
 
+def test_argsort_restatements_match_numba_source(oracle):
+    """The tie order of every fixture (and of the C oracle, and through it of the HIP kernels) rests on the
+    restatement of numba's argsort quicksort.  numba's own numba/misc/quicksort.py (0.54.1, the copy on disk in the
+    build container) is pure Python: oracle/numba_pin.py loads it standalone and runs it beside both restatements on
+    5 240 tie-heavy arrays (n = 1..129, 155, 420).  Skipped where no numba tree exists (the GPU box)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import numba_pin
+    if numba_pin.quicksort_path() is None:
+        pytest.skip("no numba/misc/quicksort.py on this machine")
+    n, bad = numba_pin.compare(extra=[oracle.numba_argsort])
+    assert n >= 5000 and bad == 0, "%d of %d arrays sorted differently from numba's quicksort.py" % (bad, n)
+
+
 @pytest.mark.parametrize("name", list(I.EMBED_CASES))
 def test_embedding_and_memory_protocol(oracle, name):
     N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]

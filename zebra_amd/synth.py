@@ -83,3 +83,20 @@ WORKLOADS = {
     "c5": dict(bipartite=None, n_nodes=10_000_000, n_edges=100_000_000, F=1, bs=4096, k=20,
                strategy="streaming", alpha=[0.1, 0.1], beta=[0.5, 0.95]),
 }
+
+
+def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
+    """(tppr_cus, group) for TGN.enable_pipeline on workload ``wl`` over a timed region of ``steps`` batches:
+    the ONE place the choice is made -- bench.py and the per-config parity tests (tests/test_configs_gpu.py)
+    both call it, so the tests run exactly the launch configuration that is timed.
+    group: as many batches per T-PPR launch as fit (<= 16384 edges, <= 4), fewer for a short region (the first
+    and the last batches of a region are queried one by one, which a 20-step run pays for with large groups);
+    1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD leaves the
+    main stream a straggler XCD) -- three for the T-PPR stream at C5's batch (its non-hub tasks need the waves),
+    one for small batches; no masks for the pruning strategy, whose query kernel wants the whole chip."""
+    streaming = wl["strategy"] == "streaming"
+    if group < 1:
+        group = max(1, min(4, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
+    if tppr_cus < 0:
+        tppr_cus = (96 if wl["bs"] >= 2048 else 32) if streaming else 0
+    return tppr_cus, group
