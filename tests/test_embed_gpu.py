@@ -980,10 +980,13 @@ def test_fused_training_dropout(F, k):
     assert np.abs(Hf - H0).max() > 1e-3                                       # the mask does something
 
 
-@pytest.mark.parametrize("F,k,n", [(1, 20, 1001), (172, 10, 333), (4, 40, 257), (1, 40, 2)])
+@pytest.mark.parametrize("F,k,n", [(1, 20, 1001), (172, 10, 333), (4, 40, 257), (1, 40, 2),
+                                   (172, 20, 1001), (172, 20, 3), (172, 40, 257), (172, 40, 1), (172, 20, 7201)])
 def test_specialised_aggregate_equals_generic(F, k, n):
-    """k_fc1_agg_d100 (D = T = 100, k in {10, 20, 40}) against the generic table kernel (ZT_AGG_GENERIC=1) on the
-    same inputs: ragged last tile, empty rows (all-zero weights), time gaps on both sides of the 4e6 switch."""
+    """The specialised aggregate kernels -- k_fc1_agg_reg (F <= 4, k in {20, 40}), k_fc1_agg_wide (F = 172, k in
+    {20, 40}: weights resident in LDS, M-tile units, group partial sums), k_fc1_agg_d100 (the other D = T = 100
+    shapes) -- against the generic table kernel (ZT_AGG_GENERIC=1) on the same inputs: ragged last tile, empty rows
+    (all-zero weights), time gaps on both sides of the 4e6 switch."""
     import os
     D = T = 100
     N, E1 = 5000, 20000

@@ -20,6 +20,7 @@ SOURCES = {
     "tppr_stream.hip": ["-ffp-contract=off"],
     "tppr_prune.hip": ["-ffp-contract=off"],
     "aggregate.hip": [],
+    "aggregate_wide.hip": [],
     "aggregate_bwd.hip": [],
     "memory_update.hip": [],
     "train_ops.hip": [],

@@ -18,6 +18,8 @@
 //   k_embed_out fc2 on the reduced rows, transform_source on memory[nodes]
 //               (three D x D layers, also f32 MFMA) and the concat into out[N, D*(M+1)].
 // Arithmetic is float32 throughout (parity tolerance for embeddings: 1e-4).
+#include <atomic>
+
 #include "common.hpp"
 
 using namespace zt;
@@ -690,19 +692,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_fc1_agg_d100(
 // Time encoding: every argument goes through time_cosf_rev (below), whose reduction is exact enough for any dt the
 // stream produces: arguments beyond 4e6 (old neighbours: dt is seconds) are everyday data at stream scale.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float time_cosf_rev(float x)
-{
-    // cos(x) for |x| up to 3e8 (dt is seconds: 10 years) in SIX float32 instructions -- on this chip an f32 MFMA and
-    // vector instructions of the same SIMD do not overlap, so every vector instruction beside the MFMAs costs its
-    // full issue time (float64 ones twice that).  Revolutions x / 2pi with 1 / 2pi = c1 + c2 (two floats): the
-    // product x c1 and its rounding error (one FMA) are carried separately, so the FRACTION of the large term is
-    // exact; x c2 < 2 needs no such care.  rev = fract(x c1) + (err1 + x c2), then v_cos_f32 (argument in
-    // revolutions).  max |error| 9e-7 over |x| <= 3e8 (mean 7e-8): tools/exp/cos_rev_check.py.
-    const float c1 = 0x1.45f306p-3f, c2 = 0x1.b9391p-28f;
-    const float p1 = x * c1, e1 = fmaf(x, c1, -p1);
-    return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(p1) + fmaf(x, c2, e1));
-}
-
 __device__ unsigned long long g_regclk[4 * 1024];   // diagnostic (DBG builds): per wave: shader cycles, wall start, wall end (100 MHz), tiles
 constexpr int REG_NS = 26;       // MFMA k-steps: F + T <= 104
 constexpr int REG_NB = 7;        // N-tiles of the hidden layer (D = 100 -> 112 columns)
@@ -1019,7 +1008,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
     const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
     const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
     const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
-    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
+    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status, int hg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Dp = (D + 15) / 16 * 16, ldx = Dp + 4, NT = Dp / 16;
@@ -1089,7 +1078,15 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
         const int m = path - 1;
         for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
             const int g = fastdiv(f, mL), c = f - g * ldx;
-            X[f] = (g < nr && c < D) ? H[((size_t)m * N + r0 + g) * D + c] : 0.f;
+            float v = 0.f;
+            if (g < nr && c < D) {
+                // hg > 1 (k_fc1_agg_wide): H holds the partial sums of every group of four neighbour rows; a query row's
+                // groups are added first to last, whichever tile or shard computed them
+                const float *hp = H + (((size_t)m * N + r0 + g) * hg) * D + c;
+                v = hp[0];
+                for (int q = 1; q < hg; ++q) v += hp[(size_t)q * D];
+            }
+            X[f] = v;
         }
         __syncthreads();
         small_gemm(X, ldx, fc2_p, Dp, NT, wave, lane, acc);
@@ -1165,7 +1162,8 @@ struct EmbedPlan {
     // table path (k_fc1_agg<true>): the tile holds only [ef | cos]
     int K2p, lda2, mt2, rq2;
     size_t lds2;
-    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, total;
+    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, off_wl, total;
+    int hg;                                     // partial-sum groups per query row in H (k_fc1_agg_wide: k / 4; else 1)
 };
 
 // tile shape for a contraction over Kp columns: as many whole query rows as fit MAX_MT tiles / the LDS budget
@@ -1208,7 +1206,9 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     p.off_fc2st = take((size_t)p.Dp * p.Dp * 4);
     p.off_w1t = take((size_t)p.Dp * p.K2p * 4);
     p.off_wm = take((size_t)p.Dp * p.Dp * 4);
-    p.off_H = take((size_t)M * N * D * 4);
+    p.hg = fc1_agg_wide_supported(D, F, T, k) ? k / 4 : 1;
+    p.off_wl = take(p.hg > 1 ? fc1_agg_wide_weight_bytes() : 0);
+    p.off_H = take((size_t)M * N * D * 4 * p.hg);
     p.off_S = take((size_t)M * N * 4);
     p.total = o;
     return true;
@@ -1254,6 +1254,7 @@ static void embed_prepare(const zt_embed_weights *wt, int D, int F, int T, const
     pad(wt->fc2s_w, D, 0, D, p.off_fc2st, p.Dp);
     pad(wt->fc1_w, K1, D, F + T, p.off_w1t, p.K2p);       // the [ef | time] columns of fc1 (table path)
     pad(wt->fc1_w, K1, 0, D, p.off_wm, p.Dp);             // W_m: the memory columns of fc1 (k_project_rows)
+    if (p.hg > 1) fc1_agg_wide_pack(wt->fc1_w, wt->time_w, wt->fc1_b, reinterpret_cast<float *>(ws + p.off_wl), s);   // LDS image (aggregate_wide.hip)
 }
 
 const float *zt::embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
@@ -1295,28 +1296,29 @@ extern "C" int zt_project_memory(const float *memory_dev, int64_t num_nodes, int
     return ZT_OK;
 }
 
-// CUs the stream may use (CU-masked streams: the size of the mask), remembered per stream
+// CUs the stream may use (CU-masked streams: the size of the mask).  Queried per call: a cache keyed by the stream
+// handle goes stale when a pipeline is destroyed and the runtime hands the same handle value to a stream with another
+// mask (round-3 advisor); the query is microseconds next to the kernels it sizes.
 static int stream_cu_count(hipStream_t s)
 {
-    static hipStream_t last_s = nullptr;
-    static int last_n = 0, total = 0;
-    if (total == 0) {
+    static std::atomic<int> total{0};
+    int tot = total.load(std::memory_order_relaxed);
+    if (tot == 0) {
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        total = prop.multiProcessorCount;
+        tot = prop.multiProcessorCount;
+        total.store(tot, std::memory_order_relaxed);
     }
-    if (s == last_s && last_n > 0) return last_n;
     uint32_t mask[32] = {0};
-    int c = total;
+    int c = tot;
     if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
         int n = 0;
         for (int q = 0; q < 32; ++q) n += __builtin_popcount(mask[q]);
-        if (n > 0 && n < total) c = n;
+        if (n > 0 && n < tot) c = n;
     } else {
         (void)hipGetLastError();
     }
-    last_s = s; last_n = c;
     return c;
 }
 
@@ -1381,8 +1383,15 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     static const bool reg_ok = !(getenv("ZT_AGG_REG") && atoi(getenv("ZT_AGG_REG")) == 0);
     const bool regk = reg_ok && tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p == 112 &&
                       !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
+    // wide edge features (F = 172), D = T = 100, k in {20, 40}: weights resident in LDS (aggregate_wide.hip; ZT_AGG_WIDE=0: off)
+    const bool widek = tab && p.hg > 1 && !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
     ZT_PROF_BEGIN(s, P_FC1_AGG);
-    if (regk) {
+    if (widek) {
+        const int rc = fc1_agg_wide_launch(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, N, M, k, nbr_dev, eix_dev,
+                                           dt_dev, w_dev, reinterpret_cast<const float *>(ws + p.off_wl), wt->fc1_b, H, S,
+                                           status_dev, stream_cu_count(s), s);
+        if (rc != ZT_OK) return rc;
+    } else if (regk) {
         const long long rq = 80 / k, tiles = ((N + rq - 1) / rq) * M;
         long long wgs = (tiles + AGG_WAVES - 1) / AGG_WAVES;
         const int cus = stream_cu_count(s);
@@ -1424,7 +1433,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
     k_embed_out<<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>(
         memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
-        out_dev, status_dev);
+        out_dev, status_dev, widek ? p.hg : 1);
     ZT_PROF_END(s, P_EMBED_OUT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

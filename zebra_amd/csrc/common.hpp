@@ -39,6 +39,13 @@ int store_messages_ex(const float *memory_dev, const float *last_update_dev, con
                       int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
+// the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)
+bool fc1_agg_wide_supported(int D, int F, int T, int k);
+size_t fc1_agg_wide_weight_bytes();
+void fc1_agg_wide_pack(const float *fc1_w_dev, const float *time_w_dev, const float *fc1_b_dev, float *packed_dev, hipStream_t s);
+int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w, long long num_nodes, long long num_edges,
+                        long long N, int M, int k, const int *nbr, const int *eix, const float *dt, const float *w,
+                        const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s);
 constexpr int TPPR_MAX_LAUNCH = 16384;     // edges one T-PPR launch can cover (tppr_stream.hip: MAX_CHUNK)
 
 // extra flags for events that only order streams of this device (experiment knob: ZT_EVENT_FLAGS, hex)
@@ -172,6 +179,20 @@ __device__ __forceinline__ float time_cosf(float x)
     // against float64 cos on 4M arguments, tools/costest.hip.txt)
     const int q = (int)kf & 3;
     return __builtin_amdgcn_cosf(fmaf(r, 0.159154943f, 0.25f * (float)q));
+}
+
+// (aggregate.hip, aggregate_wide.hip: the time encoding computed in the MFMA operand lanes)
+__device__ __forceinline__ float time_cosf_rev(float x)
+{
+    // cos(x) for |x| up to 3e8 (dt is seconds: 10 years) in SIX float32 instructions -- on this chip an f32 MFMA and
+    // vector instructions of the same SIMD do not overlap, so every vector instruction beside the MFMAs costs its
+    // full issue time (float64 ones twice that).  Revolutions x / 2pi with 1 / 2pi = c1 + c2 (two floats): the
+    // product x c1 and its rounding error (one FMA) are carried separately, so the FRACTION of the large term is
+    // exact; x c2 < 2 needs no such care.  rev = fract(x c1) + (err1 + x c2), then v_cos_f32 (argument in
+    // revolutions).  max |error| 9e-7 over |x| <= 3e8 (mean 7e-8): tools/exp/cos_rev_check.py.
+    const float c1 = 0x1.45f306p-3f, c2 = 0x1.b9391p-28f;
+    const float p1 = x * c1, e1 = fmaf(x, c1, -p1);
+    return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(p1) + fmaf(x, c2, e1));
 }
 
 // Training dropout of the hidden layer (nn.Dropout(0.1) between fc1's ReLU and fc2, modules/embedding_module.py:89,
