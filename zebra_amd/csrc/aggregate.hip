@@ -960,6 +960,7 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
 constexpr int OUT_ROWS = 32;
 constexpr int OUT_MT = OUT_ROWS / 16;
 constexpr int SG_CH = 8;             // k-steps of weight fragments in flight (small_gemm)
+constexpr int EO_GU = 8;             // staged elements in flight per thread (k_embed_out)
 
 // acc[a][b] = X[a-th 16 rows] * W[b-th owned N-tile]^T   (X in LDS [32][ldx], W padded [Dp][Dp])
 __device__ __forceinline__ void small_gemm(const float *X, int ldx, const float *__restrict__ Wp, int Dp, int NT,
@@ -1004,11 +1005,12 @@ __device__ __forceinline__ void small_gemm(const float *X, int ldx, const float 
     }
 }
 
+template <int HG>                    // partial-sum groups per query row in H (k_fc1_agg_wide: k / 4; else 1)
 __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
     const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
     const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
     const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
-    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status, int hg)
+    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Dp = (D + 15) / 16 * 16, ldx = Dp + 4, NT = Dp / 16;
@@ -1037,9 +1039,18 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
         }
         __syncthreads();
         // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
-        for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
-            const int g = fastdiv(f, mL), c = f - g * ldx;
-            X[f] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+        // (EO_GU loads in flight per thread before the first LDS store: a load per iteration was a memory round trip
+        //  per iteration, 15 of them in a row)
+        for (int f0 = tid; f0 < OUT_ROWS * ldx; f0 += AGG_THREADS * EO_GU) {
+            float v[EO_GU];
+#pragma unroll
+            for (int u = 0; u < EO_GU; ++u) {
+                const int f = f0 + u * AGG_THREADS, g = fastdiv(f, mL), c = f - g * ldx;
+                v[u] = (f < OUT_ROWS * ldx && g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < EO_GU; ++u)
+                if (f0 + u * AGG_THREADS < OUT_ROWS * ldx) X[f0 + u * AGG_THREADS] = v[u];
         }
         __syncthreads();
         small_gemm(X, ldx, fc1s_p, Dp, NT, wave, lane, acc);
@@ -1076,17 +1087,24 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
     // ---- neighbour path: fc2 on the reduced rows of model m ----
     {
         const int m = path - 1;
-        for (int f = tid; f < OUT_ROWS * ldx; f += AGG_THREADS) {
-            const int g = fastdiv(f, mL), c = f - g * ldx;
-            float v = 0.f;
-            if (g < nr && c < D) {
-                // hg > 1 (k_fc1_agg_wide): H holds the partial sums of every group of four neighbour rows; a query row's
-                // groups are added first to last, whichever tile or shard computed them
-                const float *hp = H + (((size_t)m * N + r0 + g) * hg) * D + c;
-                v = hp[0];
-                for (int q = 1; q < hg; ++q) v += hp[(size_t)q * D];
+        for (int f0 = tid; f0 < OUT_ROWS * ldx; f0 += AGG_THREADS * EO_GU) {
+            float v[EO_GU];
+#pragma unroll
+            for (int u = 0; u < EO_GU; ++u) {
+                const int f = f0 + u * AGG_THREADS, g = fastdiv(f, mL), c = f - g * ldx;
+                v[u] = 0.f;
+                if (f < OUT_ROWS * ldx && g < nr && c < D) {
+                    // hg > 1 (k_fc1_agg_wide): H holds the partial sums of every group of four neighbour rows; a query row's
+                    // groups are added first to last, whichever tile or shard computed them
+                    const float *hp = H + (((size_t)m * N + r0 + g) * HG) * D + c;
+                    v[u] = hp[0];
+#pragma unroll
+                    for (int q = 1; q < HG; ++q) v[u] += hp[(size_t)q * D];
+                }
             }
-            X[f] = v;
+#pragma unroll
+            for (int u = 0; u < EO_GU; ++u)
+                if (f0 + u * AGG_THREADS < OUT_ROWS * ldx) X[f0 + u * AGG_THREADS] = v[u];
         }
         __syncthreads();
         small_gemm(X, ldx, fc2_p, Dp, NT, wave, lane, acc);
@@ -1104,6 +1122,133 @@ __global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
                         out[(size_t)(r0 + g) * OW + (size_t)D * (m + 1) + col] =
                             acc[a][b][j] + bias * S[(size_t)m * N + r0 + g];
                 }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_embed_out2: the same three layers, organised for LATENCY (round 4).  k_embed_out's time was never its arithmetic:
+// at C2's batch (600 rows) it ran 27 us for 40 MFLOP -- a chain of dependent memory round trips per workgroup (ids ->
+// row staging through LDS in a loop the compiler cannot unroll, one round trip per iteration -> weight fragments per
+// k-chunk -> second layer -> ...) on 57 workgroups.  Here one WAVE owns (16 rows, path, one N-tile of the output):
+//   * its weight fragments -- fc2's [16 x Dp] slice, for the source path also ALL of fc1s -- are requested first,
+//     before anything is looked at, and stay in registers while the wave strides over row tiles;
+//   * the A operand comes straight from memory into the MFMA lanes (lane (row r, k-slot g) loads float4 at columns
+//     16 c + 4 g -- the k order the padded weights already have), no LDS staging; partial-sum groups (k_fc1_agg_wide)
+//     are added first to last as they arrive;
+//   * the source path's hidden layer is computed by each of the NT waves of a row tile (0.4 MFLOP, redundant on purpose:
+//     sharing it would cost a barrier and a round trip through LDS or memory) and turned from the MFMA's output layout
+//     into its input layout through 7 KB of the wave's own LDS.
+// One memory round trip for the neighbour paths, two for the source path (ids, then rows).  D % 4 == 0.
+// ---------------------------------------------------------------------------
+template <int NT, int HG>
+__global__ __launch_bounds__(64) void k_embed_out2(
+    const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
+    const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
+    const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
+    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
+{
+    constexpr int Dp = NT * 16, KC = NT, ldy = Dp + 4;
+    __shared__ __attribute__((aligned(16))) float Y[16 * ldy];
+    const int lane = threadIdx.x, r16 = lane & 15, g4 = lane >> 4;
+    const int path = blockIdx.y, b = blockIdx.z;
+    const int col = 16 * b + r16, OW = D * (M + 1);
+    const long long tiles = (N + 15) / 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // columns this lane's float4 of chunk c covers: all four inside the row, or none (D % 4 == 0)
+    bool cin[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) cin[c] = 16 * c + 4 * g4 < D;
+
+    if (path == 0) {
+        f32x4 w1[NT][KC], w2[KC];
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) w1[bb][c] = *reinterpret_cast<const f32x4 *>(fc1s_p + (size_t)(16 * bb + r16) * Dp + 16 * c + 4 * g4);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) w2[c] = *reinterpret_cast<const f32x4 *>(fc2s_p + (size_t)col * Dp + 16 * c + 4 * g4);
+        float b1v[NT];
+#pragma unroll
+        for (int bb = 0; bb < NT; ++bb) b1v[bb] = 16 * bb + r16 < D ? fc1s_b[16 * bb + r16] : 0.f;
+        const float b2v = col < D ? fc2s_b[col] : 0.f;
+        long long t = blockIdx.x;
+        int nd = (t < tiles && t * 16 + r16 < N) ? nodes[t * 16 + r16] : 0;
+        for (; t < tiles; t += gridDim.x) {
+            const long long r0 = t * 16;
+            if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
+            const bool rin = r0 + r16 < N;
+            f32x4 a[KC];
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+                a[c] = (rin && cin[c]) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)nd * D + 16 * c + 4 * g4) : zero4;
+            const long long tn = t + gridDim.x;
+            nd = (tn < tiles && tn * 16 + r16 < N) ? nodes[tn * 16 + r16] : 0;      // the next tile's ids, a tile ahead
+            f32x4 acc1[NT];
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb) acc1[bb] = zero4;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int bb = 0; bb < NT; ++bb)
+                        acc1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], w1[bb][c][j], acc1[bb], 0, 0, 0);
+#pragma unroll
+            for (int bb = 0; bb < NT; ++bb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc1[bb][j] + b1v[bb];
+                    Y[(4 * g4 + j) * ldy + 16 * bb + r16] = (16 * bb + r16 < D && v > 0.f) ? v : 0.f;
+                }
+            wave_sync();
+            f32x4 acc = zero4;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(Y + r16 * ldy + 16 * c + 4 * g4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[j], w2[c][j], acc, 0, 0, 0);
+            }
+            if (col < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + col] = acc[j] + b2v;
+            }
+            wave_sync();                                                   // Y is free for the next tile
+        }
+        return;
+    }
+    // ---- neighbour path: fc2 on the reduced rows of model m ----
+    const int m = path - 1;
+    f32x4 w2[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w2[c] = *reinterpret_cast<const f32x4 *>(fc2_p + (size_t)col * Dp + 16 * c + 4 * g4);
+    const float b2v = col < D ? fc2_b[col] : 0.f;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long long r0 = t * 16;
+        const bool rin = r0 + r16 < N;
+        const float *hp = H + (((size_t)m * N + (rin ? r0 + r16 : 0)) * HG) * D + 4 * g4;
+        f32x4 g[HG][KC];
+#pragma unroll
+        for (int q = 0; q < HG; ++q)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) g[q][c] = (rin && cin[c]) ? *reinterpret_cast<const f32x4 *>(hp + (size_t)q * D + 16 * c) : zero4;
+        float sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sv[j] = r0 + 4 * g4 + j < N ? S[(size_t)m * N + r0 + 4 * g4 + j] : 0.f;
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            f32x4 a = g[0][c];
+#pragma unroll
+            for (int q = 1; q < HG; ++q) a += g[q][c];                     // a query row's groups, first to last
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w2[c][j], acc, 0, 0, 0);
+        }
+        if (col < D) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + (size_t)D * (m + 1) + col] = acc[j] + b2v * sv[j];
         }
     }
 }
@@ -1430,10 +1575,28 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     }
     ZT_PROF_END(s, P_FC1_AGG);
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
-    const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
-    k_embed_out<<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>(
-        memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b,
-        out_dev, status_dev, widek ? p.hg : 1);
+    const int hg = widek ? p.hg : 1;
+    // small batches: the latency-organised kernel (one wave per tile, path and N-tile; 1 - 2 memory round trips);
+    // large ones: the throughput-organised one (weights amortised over 32-row tiles, several workgroups per CU).
+    // ZT_EMBED_OUT2_MAX_ROWS moves the switch (tuning knob; both kernels give the same results to rounding).
+    static const long long eo2_max = getenv("ZT_EMBED_OUT2_MAX_ROWS") ? atoll(getenv("ZT_EMBED_OUT2_MAX_ROWS")) : 1024;
+    if (N <= eo2_max && D % 4 == 0 && (p.Dp == 112 || p.Dp == 128) && (hg == 1 || hg == 5 || hg == 10)) {
+        // one wave per (16 rows, path, N-tile), striding over the row tiles with its weights in registers
+        const long long tiles = (N + 15) / 16;
+        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256), (unsigned)(M + 1), (unsigned)(p.Dp / 16));
+#define ZT_EO2(NTV, HGV) k_embed_out2<NTV, HGV><<<grid, 64, 0, s>>>(memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, \
+            fc1st, wt->fc1s_b, fc2st, wt->fc2s_b, out_dev, status_dev)
+        if (p.Dp == 112) { if (hg == 1) ZT_EO2(7, 1); else if (hg == 5) ZT_EO2(7, 5); else ZT_EO2(7, 10); }
+        else             { if (hg == 1) ZT_EO2(8, 1); else if (hg == 5) ZT_EO2(8, 5); else ZT_EO2(8, 10); }
+#undef ZT_EO2
+    } else {
+        const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
+#define ZT_EO(HGV) k_embed_out<HGV><<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>( \
+            memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b, out_dev, status_dev)
+        if (hg == 1) ZT_EO(1); else if (hg == 5) ZT_EO(5); else if (hg == 10) ZT_EO(10);
+        else { set_error("zt_embed: %d partial-sum groups per row", hg); return ZT_ERR_UNSUPPORTED; }
+#undef ZT_EO
+    }
     ZT_PROF_END(s, P_EMBED_OUT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

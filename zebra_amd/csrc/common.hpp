@@ -30,13 +30,15 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
 int gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                   const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false);
+                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, void *select_stream = nullptr,
+                  bool select_done = false);
 // zt_store_messages_range that also zeroes one int (the GRU update's row counter: first word of its workspace)
 int store_messages_ex(const float *memory_dev, const float *last_update_dev, const float *efeat_dev, const float *time_w_dev,
                       int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,
                       const int32_t *dst_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
                       int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
-                      int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream);
+                      int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
+                      bool *zeroed_out = nullptr);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
 // the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)

@@ -398,8 +398,10 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
                           int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,
                           const int32_t *dst_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
                           int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
-                          int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream)
+                          int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
+                          bool *zeroed_out)
 {
+    if (zeroed_out) *zeroed_out = false;
     if (B < 0 || D <= 0 || F < 0 || T < 0 || !status_dev) { set_error("zt_store_messages: bad argument"); return ZT_ERR_ARG; }
     if (B == 0) return ZT_OK;
     if (!memory_dev || !last_update_dev || !efeat_dev || !time_w_dev || !src_dev || !dst_dev || !ts_dev || !eidx_dev ||
@@ -418,6 +420,7 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
         B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi);
     ZT_PROF_END(s, P_STORE_MSG);
     ZT_LAUNCH_CHECK();
+    if (zeroed_out) *zeroed_out = zero_word_dev != nullptr;      // k_last_pos ran: the word is zero for whatever follows on this stream
     return ZT_OK;
 }
 
@@ -443,7 +446,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
                              const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready, void *stream)
 {
     return zt::gru_update_ex(memory_dev, last_update_dev, messages_dev, msg_ts_dev, flags_dev, num_nodes, D, msg_dim, ids_dev,
-                             n_ids, n_ids_dev, wt, workspace_dev, weights_ready, nullptr, nullptr, stream, false);
+                             n_ids, n_ids_dev, wt, workspace_dev, weights_ready, nullptr, nullptr, stream, false, nullptr, false);
 }
 
 // zt_gru_update with the refresh of the projected table folded in (pipeline.hip): wm_p = W_m padded to [Dp][Dp]
@@ -451,7 +454,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
 int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                       uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                       const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed)
+                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, void *select_stream, bool select_done)
 {
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
@@ -470,10 +473,19 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     int *rows = reinterpret_cast<int *>(ws + p.off_rows);
     float *wih = reinterpret_cast<float *>(ws + p.off_wih);
     float *whh = reinterpret_cast<float *>(ws + p.off_whh);
-    if (!counter_zeroed) ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
+    // select_stream (pipeline.hip): the compaction of the flagged ids runs where the flags were set -- on the message
+    // stream, behind the message kernels and beside the aggregation -- instead of on the caller's stream in front of the
+    // GRU; the caller orders `stream` behind it
+    hipStream_t sel = select_stream ? (hipStream_t)select_stream : s;
+    if (!counter_zeroed && !select_done) ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), sel));
+    if (select_stream) {
+        k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, sel>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev, rows, cnt);
+        ZT_LAUNCH_CHECK();
+        return ZT_OK;                           // (the GRU itself: a second call with select_done)
+    }
     ZT_PROF_BEGIN(s, P_GRU);
-    k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev,
-                                                                      rows, cnt);
+    if (!select_done)
+        k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev, rows, cnt);
     if (!weights_ready) {                       // gate-packed, padded copies: once per weight change
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);

@@ -258,7 +258,13 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         // they fit beside k_stream's workgroups -- the aggregation kernel fills the register files of its own
         void *c = nullptr;
         if (rc == ZT_OK) rc = zt_stream_create_masked(&c, 0, tppr_cus);
-        if (rc != ZT_OK) { delete p; return rc; }
+        if (rc != ZT_OK) {                     // (round-3 advisor: the streams already created leaked here)
+            if (a) (void)zt_stream_destroy(a);
+            if (b) (void)zt_stream_destroy(b);
+            if (c) (void)zt_stream_destroy(c);
+            delete p;
+            return rc;
+        }
         p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c;
     } else {
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
@@ -436,9 +442,16 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // caller's row exchange) and nothing the aggregation writes; the GRU below waits for them.
     ZT_HIP(hipEventRecord(p->step_begin, p->main_s));
     ZT_HIP(hipStreamWaitEvent(p->msg_s, p->step_begin, 0));
+    bool cnt_zeroed = false;
     rc = zt::store_messages_ex(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
                                cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
-                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->msg_s);
+                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->msg_s, &cnt_zeroed);
+    if (rc != ZT_OK) return rc;
+    // ... and the compaction of the flagged endpoints (the GRU's row list) right behind them, on the same stream: one
+    // launch less between the aggregation and the GRU on the main stream
+    const int msg_dim = 2 * d.D + d.F + d.T;
+    rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
+                           nullptr, &d.gw, d.gru_ws, 1, nullptr, nullptr, p->main_s, cnt_zeroed, p->msg_s, false);
     if (rc != ZT_OK) return rc;
     ZT_HIP(hipEventRecord(p->msgs_done, p->msg_s));
     if (n_rows > 0) {
@@ -449,12 +462,12 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     }
     // ---- P3: GRU update over the messages built beside the aggregation, projected rows ----
     ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
-    const int msg_dim = 2 * d.D + d.F + d.T;
     // the refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace
     const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
                                                                      : nullptr;
     rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true);
+                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, nullptr,
+                           true);
     if (rc != ZT_OK) return rc;
     p->gru_ready = true;
     if (d.proj_table != nullptr && wm_p == nullptr) {
