@@ -487,6 +487,34 @@ int zt_temporal_attention(const float *src_dev, const float *src_time_dev,
                           void *stream);
 
 /* ------------------------------------------------------------------------ */
+/* Link scoring and link-prediction metrics      */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    const float *fc1_w, *fc1_b;  /* affinity_score.fc1 [H][2H], [H]   (MergeLayer, utils/util.py:14-26) */
+    const float *fc2_w, *fc2_b;  /* affinity_score.fc2 [1][H], [1]                                     */
+} zt_affinity_weights;           /* device pointers */
+
+/* TGN.compute_edge_probabilities' scorer (model/tgn_model.py:185-188):
+ *   emb_dev [3B][H] = the batch's embeddings [src | dst | neg], H = D * (n_tppr + 1) in {200, 300};
+ *   prob_dev [2B]   = sigmoid(fc2(relu(fc1([src | dst])))) for the B positive pairs, then the same for (src, neg).
+ * workspace_dev: zt_affinity_workspace_bytes(max_B, H) bytes (-1 = H unsupported), sized for ws_max_B >= B;
+ * weights_ready as for zt_embed (0 also clears the workspace's tile counters: use it for a fresh workspace). */
+int64_t zt_affinity_workspace_bytes(int64_t max_B, int32_t H);
+int zt_affinity(const float *emb_dev, int64_t B, int32_t H, const zt_affinity_weights *weights,
+                float *prob_dev, void *workspace_dev, int64_t ws_max_B, int32_t weights_ready,
+                void *stream);
+/* evaluation/evaluation.py:34-45 and train.py:218-227 without the host: out_dev[0..3) (float64) =
+ * (average_precision_score, roc_auc_score, mean(pos >= neg)) of B positive and B negative scores, scikit-learn's
+ * definitions (distinct thresholds, ties included); accumulate != 0 adds to out_dev.  2B <= 16384. */
+int zt_link_metrics(const float *pos_dev, const float *neg_dev, int64_t B, double *out_dev,
+                    int32_t accumulate, void *stream);
+/* The scorer as the tail of the native step: with non-NULL weights every zt_pipeline_step_ahead over a WHOLE batch
+ * (rows [0, 3B)) also writes that batch's 2B probabilities to prob_dev ([2 * max_B], overwritten every step; main
+ * stream).  workspace_dev as for zt_affinity with ws_max_B = the pipeline's max_B.  NULL weights: off. */
+int zt_pipeline_set_scoring(zt_pipeline *p, const zt_affinity_weights *weights, void *workspace_dev,
+                            float *prob_dev);
+
+/* ------------------------------------------------------------------------ */
 /* One-node multi-GPU exchange of touched rows.  The reference  */
 /* has no distributed code; this is the data-path step around the one RCCL     */
 /* all-gather per batch.  A row travels as float32                             */

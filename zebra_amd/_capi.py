@@ -27,6 +27,7 @@ SYMBOLS = [
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
     "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
+    "zt_affinity_workspace_bytes", "zt_affinity", "zt_link_metrics", "zt_pipeline_set_scoring",
 ]
 
 
@@ -41,6 +42,10 @@ class EmbedWeights(C.Structure):
 
 class AttnWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q_w", "k_w", "v_w", "in_b", "out_w", "out_b", "m1_w", "m1_b", "m2_w", "m2_b")]
+
+
+class AffinityWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
 class GruWeights(C.Structure):
@@ -80,7 +85,7 @@ def lib():
         if hasattr(_lib, "zt_pipeline_main_stream"):
             _lib.zt_pipeline_main_stream.restype = C.c_void_p
         _lib.zt_version.restype = C.c_char_p
-        for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_train_workspace_bytes", "zt_attention_workspace_bytes", "zt_project_table_bytes", "zt_agg_backward_workspace_bytes"):
+        for name in ("zt_embed_workspace_bytes", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_train_workspace_bytes", "zt_attention_workspace_bytes", "zt_project_table_bytes", "zt_agg_backward_workspace_bytes", "zt_affinity_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib

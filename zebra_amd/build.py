@@ -25,6 +25,7 @@ SOURCES = {
     "memory_update.hip": [],
     "train_ops.hip": [],
     "attention.hip": [],
+    "scoring.hip": [],
     "pipeline.hip": [],
     "test_hooks.hip": ["-ffp-contract=off"],
 }

@@ -89,12 +89,6 @@ struct Scal {            // per-row scalars of one M-tile: lanes 0..15 hold row 
     float dt, w, wq[2];  // second; entry l32 and, for k > 32, entry l32 + 32)
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-
 template <int KK>
 __global__ __launch_bounds__(WIDE_THREADS, 1) void k_fc1_agg_wide(
     const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,

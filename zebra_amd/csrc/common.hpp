@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 // an event pair is recorded on the launch stream around the kernel; elapsed
 // times are summed per kernel name when the profile is read.
 enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_AGG, P_EMBED_OUT, P_STORE_MSG, P_GRU,
-              P_COUNT };
+              P_SCORE, P_COUNT };
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, int id);
 void prof_end(hipStream_t s, int id);
@@ -94,6 +94,13 @@ __device__ __forceinline__ void wave_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// v from the lane a DPP control selects (0x120 | n: row_ror:n -- rotation inside each row of 16 lanes)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }

@@ -61,6 +61,11 @@ struct zt_pipeline {
     bool embed_ready, gru_ready;
     hipEvent_t entry;          // main stream at the moment a group is staged: the batches' tensors are written by then
     float *avg_topk;           // zt_pipeline_set_stats: mean row sum of model 0's weights over [src | dst] (or NULL)
+    // zt_pipeline_set_scoring: the link scorer behind the aggregation of every whole-batch step (or off)
+    zt_affinity_weights aff;
+    void *aff_ws;
+    float *prob;
+    bool aff_on, aff_ready;
 };
 
 namespace {
@@ -330,6 +335,23 @@ extern "C" int zt_pipeline_set_stats(zt_pipeline *p, float *avg_topk_dev)
     return ZT_OK;
 }
 
+extern "C" int zt_pipeline_set_scoring(zt_pipeline *p, const zt_affinity_weights *weights, void *workspace_dev, float *prob_dev)
+{
+    if (!p) return ZT_ERR_ARG;
+    if (weights == nullptr) { p->aff_on = false; return ZT_OK; }
+    if (!workspace_dev || !prob_dev || !weights->fc1_w || !weights->fc1_b || !weights->fc2_w || !weights->fc2_b) {
+        set_error("zt_pipeline_set_scoring: NULL buffer");
+        return ZT_ERR_ARG;
+    }
+    if (zt_affinity_workspace_bytes(p->d.max_B, p->d.D * (p->d.M + 1)) < 0) {
+        set_error("zt_pipeline_set_scoring: hidden width %d unsupported", p->d.D * (p->d.M + 1));
+        return ZT_ERR_UNSUPPORTED;
+    }
+    p->aff = *weights; p->aff_ws = workspace_dev; p->prob = prob_dev;
+    p->aff_on = true; p->aff_ready = false;              // (every call = new weights or a new workspace: packed again)
+    return ZT_OK;
+}
+
 extern "C" int zt_pipeline_set_group(zt_pipeline *p, int32_t group)
 {
     if (!p || group < 1 || group > MAX_GROUP) { set_error("zt_pipeline_set_group: 1 <= group <= %d", MAX_GROUP); return ZT_ERR_ARG; }
@@ -459,6 +481,11 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
                       od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
+        if (p->aff_on && whole) {                // compute_edge_probabilities' scorer (model/tgn_model.py:185-188) on the rows just written
+            rc = zt_affinity(out_emb_dev, B, d.D * (d.M + 1), &p->aff, p->prob, p->aff_ws, d.max_B, p->aff_ready ? 1 : 0, p->main_s);
+            if (rc != ZT_OK) return rc;
+            p->aff_ready = true;
+        }
     }
     // ---- P3: GRU update over the messages built beside the aggregation, projected rows ----
     ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));

@@ -69,7 +69,7 @@ std::vector<hipEvent_t> g_prof_pool;
 double g_prof_ms[P_COUNT];
 long long g_prof_n[P_COUNT];
 const char *const g_prof_names[P_COUNT] = {"tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk",
-                                           "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update"};
+                                           "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update", "score"};
 hipEvent_t prof_event()
 {
     hipEvent_t e;

@@ -63,6 +63,26 @@ def accuracy(pos, neg):
     return (pos.reshape(-1) >= neg.reshape(-1)).to(torch.float64).mean()
 
 
+def link_metrics(pos, neg, out=None):
+    """(average_precision, roc_auc, accuracy) of one batch as a float64[3] tensor on the scores' device.  CUDA scores of
+    up to 8192 pairs go through ONE HIP kernel (zt_link_metrics, csrc/scoring.hip: bitonic sort in LDS + the two curve
+    sums; ``out`` given: the values are ADDED to it there, no extra op); anything else through the torch ops above --
+    the same definitions, which the CPU tests hold against scikit-learn and the GPU tests against each other."""
+    pos, neg = pos.reshape(-1), neg.reshape(-1)
+    if pos.is_cuda and pos.dtype == torch.float32 and neg.dtype == torch.float32 and 0 < pos.numel() == neg.numel() <= 8192:
+        import ctypes as C
+        from ._capi import check, lib, ptr, stream_ptr
+        acc = out if out is not None else torch.zeros(3, dtype=torch.float64, device=pos.device)
+        check(lib().zt_link_metrics(ptr(pos.contiguous()), ptr(neg.contiguous()), C.c_int64(pos.numel()), ptr(acc),
+                                    C.c_int32(1 if out is not None else 0), stream_ptr()), "zt_link_metrics")
+        return acc
+    m = torch.stack([average_precision(pos, neg), roc_auc(pos, neg), accuracy(pos, neg)])
+    if out is not None:
+        out += m
+        return out
+    return m
+
+
 @torch.no_grad()
 def eval_edge_prediction(model, negative_edge_sampler, data, n_neighbors, batch_size):
     """evaluation/evaluation.py:7-48 with the same protocol and return value (mean AP, mean AUC, mean
@@ -78,7 +98,8 @@ def eval_edge_prediction(model, negative_edge_sampler, data, n_neighbors, batch_
         _, negatives = negative_edge_sampler.sample(e - s)
         pos, neg = model.compute_edge_probabilities(data.sources[s:e], data.destinations[s:e], negatives,
                                                     data.timestamps[s:e], data.edge_idxs[s:e], n_neighbors, train=False)
-        m = torch.stack([average_precision(pos, neg), roc_auc(pos, neg), accuracy(pos, neg)])
-        acc = m if acc is None else acc + m
+        if acc is None:
+            acc = torch.zeros(3, dtype=torch.float64, device=pos.device)
+        link_metrics(pos, neg, out=acc)
     out = (acc / nb).cpu().numpy()
     return float(out[0]), float(out[1]), float(out[2])

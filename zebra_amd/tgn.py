@@ -101,6 +101,66 @@ class TGN(torch.nn.Module):
                                       None, ptr(self._status), stream_ptr()), "zt_store_messages")
         return B
 
+    # ------------------------------------------------------------------ link scorer (tgn_model.py:185-188) on the device
+    def _affinity_state(self, max_B):
+        """(workspace, weights struct, weights_ready) of the HIP scorer; None when the hidden width has no kernel."""
+        a = self.affinity_score
+        H = a.fc1.weight.shape[0]
+        need = lib().zt_affinity_workspace_bytes(C.c_int64(max(1, max_B)), C.c_int32(H))
+        if need < 0:
+            return None
+        st = getattr(self, "_aff", None)
+        key = tuple((t.data_ptr(), t._version) for t in (a.fc1.weight, a.fc1.bias, a.fc2.weight, a.fc2.bias))
+        if st is None or st["ws"].numel() < need or st["max_B"] < max_B:
+            st = self._aff = dict(ws=torch.empty(int(need), dtype=torch.uint8, device=self.device), max_B=int(max_B), key=None)
+        w = _capi.AffinityWeights()
+        w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b = (a.fc1.weight.data_ptr(), a.fc1.bias.data_ptr(), a.fc2.weight.data_ptr(),
+                                              a.fc2.bias.data_ptr())
+        ready = st["key"] == key
+        st["key"] = key
+        return st, w, ready
+
+    @torch.no_grad()
+    def score_device(self, emb):
+        """sigmoid(affinity_score([src | src], [dst | neg])) for the [3B, H] embeddings of a batch -> float32 [2B]:
+        the B positive probabilities, then the B negative ones (compute_edge_probabilities' tail, eval mode)."""
+        B = emb.shape[0] // 3
+        st = self._affinity_state(B)
+        if st is None:
+            score = self.affinity_score(torch.cat([emb[:B], emb[:B]]), emb[B:]).squeeze(1)
+            return score.sigmoid()
+        st, w, ready = st
+        prob = torch.empty(2 * B, dtype=torch.float32, device=self.device)
+        check(lib().zt_affinity(ptr(emb.contiguous()), C.c_int64(B), C.c_int32(emb.shape[1]), C.byref(w), ptr(prob), ptr(st["ws"]),
+                                C.c_int64(st["max_B"]), C.c_int32(1 if ready else 0), stream_ptr()), "zt_affinity")
+        return prob
+
+    def enable_scoring(self, on=True):
+        """With the native pipeline: every whole-batch step also scores its 2B pairs (zt_pipeline_set_scoring);
+        ``self.last_prob`` is then a [2 * max_batch] float32 buffer whose first 2B entries belong to the last step
+        (overwritten by the next one)."""
+        self._score_on = bool(on)
+        self._pipe_scoring_sync(force=True)
+
+    def _pipe_scoring_sync(self, force=False):
+        if getattr(self, "_pipe", None) is None:
+            return
+        if not getattr(self, "_score_on", False):
+            if force:
+                check(lib().zt_pipeline_set_scoring(self._pipe, None, None, None), "zt_pipeline_set_scoring")
+            return
+        max_b = self._pipe_args[1]
+        st = self._affinity_state(max_b)
+        if st is None:
+            raise ValueError("no HIP scorer for hidden width %d" % self.affinity_score.fc1.weight.shape[0])
+        st, w, ready = st
+        if ready and not force and getattr(self, "_pipe_score_set", False):
+            return
+        if getattr(self, "last_prob", None) is None or self.last_prob.numel() < 2 * max_b:
+            self.last_prob = torch.zeros(2 * max_b, dtype=torch.float32, device=self.device)
+        check(lib().zt_pipeline_set_scoring(self._pipe, C.byref(w), ptr(st["ws"]), ptr(self.last_prob)), "zt_pipeline_set_scoring")
+        self._pipe_score_set = True
+
     # -- the step as ONE native call (csrc/pipeline.hip): P1 of batch b+1 on a side stream beside P2 + P3 of batch b
     def enable_pipeline(self, on=True, tppr_cus=0, max_batch=16384, group=1):
         """Create (or drop) the native step pipeline.  ``tppr_cus`` > 0 pins the T-PPR stream to the first
@@ -123,6 +183,8 @@ class TGN(torch.nn.Module):
         self._pipe_args = (int(tppr_cus), int(max_batch))
         self._pipe_group = int(group)
         self._pipe_refresh(create=True)
+        self._pipe_score_set = False
+        self._pipe_scoring_sync(force=True)
 
     def _pipe_signature(self):
         """Everything the native pipeline holds pointers to: (tables, weight versions)."""
@@ -255,6 +317,8 @@ class TGN(torch.nn.Module):
 
     def _pipe_step_main(self, batch, ahead, rows, positions):
         self._pipe_refresh()
+        if getattr(self, "_score_on", False):
+            self._pipe_scoring_sync()
         B = batch[0].numel()
         r0, r1 = rows if rows is not None else (0, 3 * B)
         p0, p1 = positions if positions is not None else (0, 2 * B)
@@ -352,6 +416,7 @@ class TGN(torch.nn.Module):
             self.update_memory(self.memory, unique_positives)
             with torch.no_grad():
                 self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
+        self._last_node_embedding = node_embedding if edge_sel is None else None
         return (node_embedding[:n_samples], node_embedding[n_samples:2 * n_samples], node_embedding[2 * n_samples:])
 
     def compute_edge_probabilities(self, source_nodes, destination_nodes, negative_nodes, edge_times, edge_idxs,
@@ -359,6 +424,13 @@ class TGN(torch.nn.Module):
         n_samples = len(source_nodes)
         s, dd, n = self.compute_temporal_embeddings(source_nodes, destination_nodes, negative_nodes, edge_times,
                                                     edge_idxs, n_neighbors, train)
+        if not train and not torch.is_grad_enabled() and s.is_cuda:
+            # eval: the HIP scorer (csrc/scoring.hip) on the [3B, H] block the step returned; same shapes as below
+            full = getattr(self, "_last_node_embedding", None)           # the [3B, H] block s / dd / n are slices of
+            if full is None or full.data_ptr() != s.data_ptr() or full.shape[0] != 3 * n_samples:
+                full = torch.cat([s, dd, n])
+            prob = self.score_device(full)
+            return prob[:n_samples].unsqueeze(1), prob[n_samples:].unsqueeze(1)
         score = self.affinity_score(torch.cat([s, s], dim=0), torch.cat([dd, n])).squeeze(dim=0)
         return score[:n_samples].sigmoid(), score[n_samples:].sigmoid()
 
