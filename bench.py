@@ -39,6 +39,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_TORCH_DEFAULT_THREADS = None
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # dense f32 MFMA
 
@@ -149,6 +150,10 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     import torch
+    global _TORCH_DEFAULT_THREADS
+    if _TORCH_DEFAULT_THREADS is None:
+        _TORCH_DEFAULT_THREADS = torch.get_num_threads()
+    default_threads = _TORCH_DEFAULT_THREADS
     torch.set_num_threads(n_threads)
     bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
     D = T = 100
@@ -169,16 +174,24 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
     p.mem.timestamps[ids] = snap["timestamps"]
     p.mem.flags[ids] = snap["flags"]
     p.test_mode = True                              # the GPU leg flushed pending messages before its warm-up
-    half = max(1, len(batches) // 2)
-    t_p1 = [0.0, 0.0]
-    t_all = [0.0, 0.0]
-    n_e = [0, 0]
+    # three parts of the sample: (0) torch-CPU P2/P3 on n_threads threads = `value`; (1) the C port on n_threads OpenMP
+    # threads, P1 with one thread per model; (2) torch-CPU P2/P3 on torch's DEFAULT thread count for this host (what
+    # `import torch` picks: the host's cores) -- reported beside `value`, since 16 threads are not what the host can do
+    nb = len(batches)
+    cut1, cut2 = max(1, (2 * nb) // 5), max(2, (4 * nb) // 5)
+    t_p1 = [0.0, 0.0, 0.0]
+    t_all = [0.0, 0.0, 0.0]
+    n_e = [0, 0, 0]
     single = p.tppr.streaming_topk if p.tppr is not None else None
     for b, (src, dst, neg, ts, eidx) in enumerate(batches):
-        part = 0 if b < half else 1
-        p.p23 = "torch" if part == 0 else "c"
+        part = 0 if b < cut1 else (1 if b < cut2 else 2)
+        p.p23 = "c" if part == 1 else "torch"
+        if part == 2 and b == cut2:
+            torch.set_num_threads(default_threads)
+            p._t23 = None                            # (the torch-CPU module is rebuilt for the new thread count)
+            p.n_threads = default_threads
         if p.tppr is not None:
-            p.tppr.streaming_topk = single if part == 0 else p.tppr.streaming_topk_threads
+            p.tppr.streaming_topk = p.tppr.streaming_topk_threads if part == 1 else single
         t0 = time.perf_counter()
         nodes = np.concatenate([src, dst, neg]).astype(np.int32)
         on = p.topk(nodes, ts, eidx)
@@ -190,22 +203,27 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
         n_e[part] += len(src)
     if p.tppr is not None:
         p.tppr.streaming_topk = single
-    out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=torch.get_num_threads(), kind="port",
-               host_cpus=os.cpu_count(), torch_num_threads=torch.get_num_threads(),
+    out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=n_threads, kind="port",
+               host_cpus=os.cpu_count(), torch_num_threads=n_threads,
                value_is="P1: C port on 1 thread; P2/P3: torch-CPU ops (oracle/torch_cpu.py)",
                p1_edges_per_s_1thread=n_e[0] / max(t_p1[0], 1e-9),
                p23_edges_per_s_torch_cpu=n_e[0] / max(t_all[0] - t_p1[0], 1e-9),
                sample="%d batches (%d edges) of the same stream starting from the GPU run's state after the prefill "
                       "(where its warm-up steps start); value = first %d batches: T-PPR loop (C port) on 1 thread as "
-                      "the reference's Numba loop, aggregation / messages / GRU as torch-CPU ops on %d threads; the other "
-                      "batches: T-PPR with one thread per model, aggregation / GRU by the C port on %d OpenMP threads"
-                      % (len(batches), n_e[0] + n_e[1], half, torch.get_num_threads(), n_threads))
+                      "the reference's Numba loop, aggregation / messages / GRU as torch-CPU ops on %d threads; the next %d: "
+                      "T-PPR with one thread per model, aggregation / GRU by the C port on %d OpenMP threads; the last %d: as "
+                      "the first with torch's default thread count (%d)"
+                      % (nb, sum(n_e), cut1, n_threads, cut2 - cut1, n_threads, nb - cut2, default_threads))
     if n_e[1]:
         out["value_c_port"] = n_e[1] / t_all[1]
         out["c_port_threads"] = n_threads
         out["p1_threads"] = M if wl["strategy"] == "streaming" else 1
         out["p1_edges_per_s_threads"] = n_e[1] / max(t_p1[1], 1e-9)
         out["p23_edges_per_s_c_port"] = n_e[1] / max(t_all[1] - t_p1[1], 1e-9)
+    if n_e[2]:
+        out["value_default_threads"] = n_e[2] / t_all[2]
+        out["default_threads"] = default_threads
+    torch.set_num_threads(default_threads)
     return out
 
 
@@ -228,16 +246,358 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+CRIT_SECTION_NS = 970.0    # the hub chain's critical section: 2280 core clocks (median, tools/crit_profile.py)
+
+
+def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edges):
+    """One workload: build the model, prefill, warm up, time `steps` steps, read the per-kernel events, run the CPU leg
+    (world == 1).  Returns the dict of the JSON line (headline) or of a `workloads` entry."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from zebra_amd import _capi, synth
+
+    wl = dict(synth.WORKLOADS[name])
+    bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
+    # SURVEY.md 8d: the first 10 % of the stream is the untimed warm-up, so that T-PPR rows are full
+    prefill = a.prefill_steps if (a.prefill_steps >= 0 and headline) else (wl["n_edges"] // 10) // bs
+    # two timed regions: the metric's step (embeddings + T-PPR and memory updates: SURVEY.md 8d) and, behind it, the same
+    # step with compute_edge_probabilities' scorer at its tail (model/tgn_model.py:185-188; 5 warm-up steps in between)
+    scored = world == 1 and not a.no_score and not (a.no_pipeline and headline)
+    n_steps_total = prefill + warmup + steps + ((5 + steps) if scored else 0)
+    n_edges = n_steps_total * bs
+    if n_edges > wl["n_edges"]:
+        raise SystemExit("stream of %d edges is shorter than prefill+warmup+steps" % wl["n_edges"])
+
+    src, dst, neg, ts, eidx = make_stream(wl, n_edges, perm_seed=None if a.perm_seed < 0 else a.perm_seed)
+    n_edge_rows = (wl["n_edges"] if F == 1 else n_edges) + 1      # F=1: the full |E|+1 zero table is cheap
+    tgn = build_model(wl, device, n_edge_rows)
+    if wl["strategy"] == "pruning":
+        import types
+        from zebra_amd.tppr import get_neighbor_finder
+        tgn.set_neighbor_finder(get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst,
+                                                                          edge_idxs=eidx, timestamps=ts)))
+    src_d = torch.from_numpy(src).to(device)
+    dst_d = torch.from_numpy(dst).to(device)
+    neg_d = torch.from_numpy(neg).to(device)
+    ts_d = torch.from_numpy(ts).to(device)
+    eidx_d = torch.from_numpy(eidx).to(device)
+
+    if world > 1:
+        from zebra_amd.distributed import ShardedTGN
+        runner = ShardedTGN(tgn, rank, world)
+        step = runner.step_device
+    else:
+        step = tgn.step_device
+
+    # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
+    # its real shape against the oracle with exactly these settings)
+    tppr_cus, group = synth.pipeline_settings(wl, steps, a.tppr_cus if headline else -1, a.group if headline else -1)
+    no_pipeline = a.no_pipeline and headline
+    if not no_pipeline:
+        # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b.  Several ranks: the same masks.
+        # torch.distributed runs the RCCL kernel of the row exchange on a stream of its own (ProcessGroupNCCL orders it
+        # against the current stream with events), so the masks neither confine nor block it.  ZT_BENCH_NO_MASKS=1
+        # switches them off.
+        if os.environ.get("ZT_BENCH_NO_MASKS") == "1":
+            tppr_cus = 0
+        try:
+            tgn.enable_pipeline(tppr_cus=tppr_cus, group=group)
+        except Exception as exc:                       # no CU-mask support: plain streams
+            sys.stderr.write("[bench] CU-masked streams unavailable (%s); using plain streams\n" % exc)
+            tppr_cus = 0
+            tgn.enable_pipeline(tppr_cus=0, group=group)
+    else:
+        tppr_cus = 0
+    main_stream = getattr(tgn, "main_stream", None)
+
+    # views of every batch, made once: slicing tensors is host work that is not part of the path
+    batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
+                ts_d[b * bs:(b + 1) * bs], eidx_d[b * bs:(b + 1) * bs]) for b in range(n_steps_total)]
+    look = 3 * group                            # batches in sight: the rest of this group, the next group, the one after
+                                                # it, and one more (a group is only full while a follower is in sight)
+
+    def run(b0, nb):
+        # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)
+        ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
+        with ctx:
+            for b in range(b0, b0 + nb):
+                ahead = [] if no_pipeline else batches[b + 1: min(b + 1 + look, b0 + nb)]
+                step(*batches[b], ahead=ahead)
+
+    lib = _capi.lib()
+    run(0, prefill)
+    tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
+    torch.cuda.synchronize()
+    # ---- warm state for the CPU leg (the state after the 10 % prefill, where the GPU leg's warm-up steps start)
+    # and row-fill statistics.  Taken BEFORE the warm-up so that the W warm-up steps run right before the timed
+    # region (the snapshot idles the GPU for seconds).
+    e0 = prefill * bs
+    cpu_nb = 0
+    if world == 1 and cpu_edges != 0:
+        cpu_nb = max(2, min(steps + warmup, cpu_edges // bs))
+    snap, fill = None, None
+    if cpu_nb:
+        touched = np.unique(np.concatenate([src[:e0], dst[:e0]])) if e0 else np.zeros(0, np.int64)
+        snap = snapshot_state(tgn, wl, touched)
+        if wl["strategy"] == "streaming" and len(touched):
+            ends = np.concatenate([src[e0:e0 + bs], dst[e0:e0 + bs], neg[e0:e0 + bs]])
+            pos = np.searchsorted(touched, ends)
+            seen = (pos < len(touched)) & (touched[np.minimum(pos, len(touched) - 1)] == ends)
+            ln = np.where(seen, snap["tppr"][0]["len"][np.minimum(pos, len(touched) - 1)], 0)
+            fill = dict(mean_row_len=float(ln.mean()), frac_empty=float((ln == 0).mean()), frac_full=float((ln == k).mean()))
+    spun = False
+    if cpu_nb and not a.no_clock_spin:
+        # the snapshot above left the GPU idle for seconds (host-side export of the warm state): its clocks have dropped,
+        # and W = 5 warm-up steps (2 ms) do not bring them back.  Throw-away matrix products for a third of a second, on
+        # data that has nothing to do with the stream, before the warm-up steps -- so that the timed region measures the
+        # path and not the clock ramp
+        xa = torch.randn((4096, 4096), device=device)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.35:
+            for _ in range(20):
+                xa = torch.mm(xa, xa).clamp_(-1.0, 1.0)
+            torch.cuda.synchronize()
+        del xa
+        spun = True
+    run(prefill, warmup)
+    if not a.no_profile:
+        lib.zt_profile_reset()
+        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else 4)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(prefill + warmup, steps)
+    t_host = time.perf_counter() - t0          # host time to enqueue the timed steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sys.stderr.write("[bench] %s: host enqueue %.3f ms/step, wall %.3f ms/step\n" % (name, 1e3 * t_host / steps, 1e3 * dt / steps))
+    lib.zt_profile_enable(0)
+    # ---- the second region: the same step + the link scorer (sharded runs score nothing: a rank holds a row shard) ----
+    with_scorer = None
+    if scored:
+        kern_a = {}
+        if not a.no_profile:
+            for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg", "embed_out",
+                       "store_messages", "gru_update"):
+                n, ms = C.c_int64(), C.c_double()
+                lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
+                if n.value:
+                    kern_a[kn] = dict(launches=n.value, avg_us=1e3 * ms.value / n.value)
+        tgn.enable_scoring()
+        b1 = prefill + warmup + steps
+        run(b1, 5)
+        if not a.no_profile:
+            lib.zt_profile_reset()
+            lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else 4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(b1 + 5, steps)
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t1
+        lib.zt_profile_enable(0)
+        n, ms = C.c_int64(), C.c_double()
+        lib.zt_profile_read(b"score", C.byref(n), C.byref(ms))
+        with_scorer = dict(value=steps * bs / dt_s, unit="edges/s", ms_per_step=1e3 * dt_s / steps, steps=steps,
+                           score_kernel_us=(1e3 * ms.value / n.value) if n.value else None,
+                           note="the step above + compute_edge_probabilities' scorer (zt_affinity) at its tail, timed over the "
+                                "next %d batches after 5 warm-up steps; `value` is the metric's step (embeddings + T-PPR and "
+                                "memory updates)" % steps)
+        sys.stderr.write("[bench] %s: with the scorer %.3f ms/step\n" % (name, 1e3 * dt_s / steps))
+    if wl["strategy"] == "streaming":
+        tgn.embedding_module.tppr_finder.check_status()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    torch.cuda.synchronize()
+    use_proj = bool(getattr(tgn.embedding_module, "use_projection", False))
+    weights = time_w = efeat_host = None
+    if cpu_nb:
+        weights, time_w = model_weights(tgn)
+        if F != 1:
+            efeat_host = tgn.edge_raw_features.cpu().numpy()
+    if not no_pipeline:
+        tgn.enable_pipeline(False)      # give the CU-masked streams back before the runtime shuts down (or the next workload)
+
+    # ---- per-kernel HIP-event times over the timed region ----
+    kern = {}
+    if scored:
+        kern = kern_a
+    elif not a.no_profile:
+        for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg",
+                   "embed_out", "store_messages", "gru_update"):
+            n, ms = C.c_int64(), C.c_double()
+            lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
+            if n.value:
+                kern[kn] = dict(launches=n.value, avg_us=1e3 * ms.value / n.value)
+    cus_total = torch.cuda.get_device_properties(device).multi_processor_count
+    # the model's tables are the bulk of the device memory: gone before the next workload (or the CPU leg's host arrays)
+    del tgn, batches, src_d, dst_d, neg_d, ts_d, eidx_d
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    edges = steps * bs
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (separate
+    # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction; see profiles/make_pmc_summary.py)
+    pmc = {}
+    pmc_edges = None
+    if world == 1:
+        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % name)
+            if os.path.isfile(pj):
+                summ = json.load(open(pj))
+                pmc = summ.get("kernels", {})
+                # per-launch bytes of the T-PPR kernel belong to a launch SHAPE: a summary measured on launches of another
+                # size is scaled by the edges per launch (the kernel's traffic is per edge -- rows read and written, tag
+                # polls), and the roofline note says so
+                on = summ.get("measured_on") or {}
+                pmc_edges = on.get("edges_per_k_stream_launch")
+                if on.get("tppr_launch_group") not in (None, group) and not pmc_edges:
+                    pmc = {kk: vv for kk, vv in pmc.items() if kk != "tppr_stream"}
+                break
+    ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
+    af = algorithmic_flops(k, F, M)
+    ex = executed_flops(k, F, M, projected=use_proj)
+
+    def kernel_roofline(kn):
+        """achieved = ALGORITHMIC bytes (or EXECUTED flops) of one launch / its average HIP-event time."""
+        us = kern[kn]["avg_us"] * 1e-6
+        shard = world if kn in ("fc1_agg", "embed_out", "pruned_topk") and world > 1 else 1
+        tr = pmc.get(kn, {}).get("traffic")
+        if kn in ("fc1_agg", "embed_out"):
+            ach = ex[kn] * bs / shard / us / 1e12
+            # the main stream is confined to the CUs the T-PPR stream does not own (CU masks): the whole-chip peak is
+            # the contract's `peak`; the share of the CUs the kernel can run on is given beside it
+            cus_used = cus_total - (tppr_cus if (not no_pipeline and tppr_cus > 0) else 0)
+            return dict(kernel=kn, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr, cus=cus_used,
+                        frac_of_own_cus=ach / (MFMA_F32_PEAK_TF * cus_used / cus_total),
+                        note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
+                             "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if kn == "fc1_agg" else None)
+        if kn == "tppr_stream":
+            # one k_stream launch covers all M models and `group` batches (fewer at the ends of the region)
+            per_launch = steps * bs / kern[kn]["launches"]     # (every launch of the T-PPR update is timed)
+            byts = ab["p1"] * M * per_launch
+            note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
+                    "per-node chains; the binding resource is hops x hop latency, not HBM")
+            if tr is not None and pmc_edges and abs(pmc_edges - per_launch) > 1:
+                tr = tr * per_launch / pmc_edges
+                note += "; traffic: counters of %d-edge launches scaled to this run's %.0f edges per launch" % (pmc_edges, per_launch)
+        elif kn == "pruned_topk":
+            # ONE launch serves all M models: the CSR tails are read once, every model writes its output rows
+            byts = (ab["p1"] - 48 * k + M * 48 * k) * bs / shard
+            note = "CSR tail reads (once for all models) + output rows per query and model (search probes not counted)"
+        elif kn == "gru_update":
+            byts = 2 * (4 * (2 * 100 + F + 100) + 8 * 100 + 4) * bs / shard
+            note = None
+        else:
+            byts = ab["p3"] * bs / shard
+            note = None
+        ach = byts / us / 1e9
+        # the streaming T-PPR kernel is bound by (hops of the longest per-node chain) x (latency of one hop), not by
+        # HBM: `achieved` / `peak` / `frac` are still its algorithmic bytes against the HBM peak, for the record
+        out_r = dict(kernel=kn, bound="latency" if kn == "tppr_stream" else "hbm", achieved=ach, peak=HBM_PEAK_GBS,
+                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, note=note)
+        if kn == "tppr_stream":
+            out_r["edges_per_launch"] = per_launch
+            # the yardstick that fits: the longest chain of edges through ONE node in a launch (every edge that touches
+            # the node is a hop of its chain: they are applied one after the other) x the chain's critical section
+            tb0 = prefill + warmup
+            hops = []
+            for g0 in range(tb0, tb0 + steps, group):
+                g1 = min(g0 + group, tb0 + steps)
+                ends = np.concatenate([src[g0 * bs:g1 * bs], dst[g0 * bs:g1 * bs][src[g0 * bs:g1 * bs] != dst[g0 * bs:g1 * bs]]])
+                hops.append(int(np.bincount(ends).max()))
+            ch = float(np.mean(hops))
+            kt_ns = kern[kn]["avg_us"] * 1e3
+            out_r["latency_model"] = dict(
+                critical_hops=ch, ns_per_hop=kt_ns / ch, floor_ns_per_hop=CRIT_SECTION_NS, frac=ch * CRIT_SECTION_NS / kt_ns,
+                note="critical_hops: edges through the most-touched node of a launch (mean over the region's nominal launches "
+                     "of %d batches), applied in stream order; floor: the hub chain's critical section (2280 core clocks, median, "
+                     "tools/crit_profile.py); frac = hops x floor / kernel time" % group)
+        return out_r
+
+    # dominant kernel = the one with the largest total time in the timed region
+    roof = roof2 = None
+    if kern:
+        dom = max(kern, key=lambda n: kern[n]["avg_us"] * kern[n]["launches"])
+        roof = kernel_roofline(dom)
+        # the largest THROUGHPUT kernel as well, when the dominant one is the latency-bound T-PPR chain
+        if dom != "fc1_agg" and "fc1_agg" in kern:
+            roof2 = kernel_roofline("fc1_agg")
+
+    cpu = None
+    if cpu_nb:
+        b0 = prefill
+        cb = [(src[b * bs:(b + 1) * bs], dst[b * bs:(b + 1) * bs], neg[b * bs:(b + 1) * bs], ts[b * bs:(b + 1) * bs],
+               eidx[b * bs:(b + 1) * bs]) for b in range(b0, b0 + cpu_nb)]
+        extra = dict(src=src, dst=dst, eidx=eidx, ts=ts)
+        if F != 1:
+            extra["efeat"] = efeat_host
+        cpu = cpu_baseline(wl, snap, weights, time_w, cb, extra, min(16, os.cpu_count() or 1))
+
+    value = edges / dt
+    out = {
+        "metric": "temporal edges/sec embedded (k=%d, 2-layer)" % k if M == 2 else
+                  "temporal edges/sec embedded (k=%d, %d T-PPR models)" % (k, M),
+        "value": value, "unit": "edges/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64+f32", "data": "synthetic",
+        "config": {"workload": "%s: synthetic %s stream, %d nodes, bs=%d, k=%d, alpha=%s beta=%s, %s T-PPR, F=%d, "
+                               "prefill %d + warmup %d batches" % (name, "bipartite" if wl["bipartite"] else
+                                                                   "power-law", wl["n_nodes"], bs, k, wl["alpha"],
+                                                                   wl["beta"], wl["strategy"], F, prefill, warmup),
+                   "global_batch": bs, "tppr_launch_group": group, "tppr_cus": tppr_cus,
+                   "clock_spin": spun,
+                   "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
+                   "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
+        "host_enqueue_ms_per_step": 1e3 * t_host / steps,
+        "with_scorer": with_scorer,
+        "roofline": roof,
+        "roofline_throughput_kernel": roof2,
+        "cpu_baseline": cpu,
+        "row_fill": fill,
+        # flops_per_edge: SURVEY.md 8(d)'s figure = the REFERENCE's formulation (fc2 per neighbour, W_m memory per
+        # gathered row, scorer included: `value`'s step ends with the embeddings, `with_scorer` times the scorer too);
+        # executed_flops_per_edge: what the kernels of `value`'s step execute; the scorer kernel adds
+        # scorer_executed_flops_per_edge (W_a src shared by an edge's two pairs: 3/4 of the reference's)
+        "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
+                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"],
+                        "scorer_flops_per_edge": af["scorer"], "scorer_executed_flops_per_edge": af["scorer"] * 3 // 4,
+                        "hbm_gbs_at_value": ab["total"] * value / 1e9,
+                        "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
+                        "reference_formulation_tflops_at_value": af["total"] * value / 1e12,
+                        "reference_formulation_mfma_frac_at_value": af["total"] * value / 1e12 / MFMA_F32_PEAK_TF},
+        "kernels": kern,
+    }
+    out["algorithmic"]["executed_mfma_frac_at_value"] = out["algorithmic"]["executed_flops_per_edge"] * value / 1e12 / MFMA_F32_PEAK_TF
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c5", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c5", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--legs", default="default",
+                    help="further workloads timed after the headline one and printed under \"workloads\" of the same JSON "
+                         "line, each with its own ms_per_step / roofline / cpu_baseline: comma-separated names, 'none', or "
+                         "'default' = c2,c3,c4 behind the c5 headline (nothing behind another --workload)")
+    ap.add_argument("--leg-steps", type=int, default=100, help="timed steps of every leg (warm-up 10)")
     ap.add_argument("--prefill-steps", type=int, default=-1,
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-score", action="store_true", help="skip the second timed region (the step with the link scorer at its tail)")
     ap.add_argument("--no-clock-spin", action="store_true",
                     help="skip the throw-away GPU work between the warm-state snapshot (seconds of host work, GPU idle) and the warm-up steps")
     ap.add_argument("--profile-every", type=int, default=-1,
@@ -246,7 +606,7 @@ def main():
                          "group of batches on its own stream, is timed at every launch)")
     ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
-                         "(0 = no masks; default: whole XCDs -- 64 at bs >= 2048, else 32 -- for the streaming strategy, "
+                         "(0 = no masks; default: whole XCDs -- 96 at bs >= 2048, else 32 -- for the streaming strategy, "
                          "0 for the pruning strategy, whose query kernel wants the whole chip)")
     ap.add_argument("--group", type=int, default=-1,
                     help="consecutive batches whose streaming T-PPR update runs as ONE launch (zt_pipeline_set_group); "
@@ -288,9 +648,6 @@ def main():
                               "dry_run": True, "launched_by": "bench.py" if os.environ.get("ZT_BENCH_LAUNCHED") else "launcher"}))
         return
 
-    from zebra_amd import _capi, synth
-    import ctypes as C
-
     # rehearsal on a one-GPU box: ZT_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
     rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -307,274 +664,25 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    wl = dict(synth.WORKLOADS[a.workload])
-    bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
-    # the first 10 % of the stream is the untimed warm-up, so that T-PPR rows are full
-    prefill = a.prefill_steps if a.prefill_steps >= 0 else (wl["n_edges"] // 10) // bs
-    n_steps_total = prefill + a.warmup + a.steps
-    n_edges = n_steps_total * bs
-    stream_edges = min(wl["n_edges"], max(n_edges, 1))
-    if n_edges > wl["n_edges"]:
-        raise SystemExit("stream of %d edges is shorter than prefill+warmup+steps" % wl["n_edges"])
-
-    src, dst, neg, ts, eidx = make_stream(wl, n_edges, perm_seed=None if a.perm_seed < 0 else a.perm_seed)
-    n_edge_rows = (wl["n_edges"] if F == 1 else n_edges) + 1      # F=1: the full |E|+1 zero table is cheap
-    tgn = build_model(wl, device, n_edge_rows)
-    if wl["strategy"] == "pruning":
-        import types
-        from zebra_amd.tppr import get_neighbor_finder
-        tgn.set_neighbor_finder(get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst,
-                                                                          edge_idxs=eidx, timestamps=ts)))
-    src_d = torch.from_numpy(src).to(device)
-    dst_d = torch.from_numpy(dst).to(device)
-    neg_d = torch.from_numpy(neg).to(device)
-    ts_d = torch.from_numpy(ts).to(device)
-    eidx_d = torch.from_numpy(eidx).to(device)
-
-    if world > 1:
-        from zebra_amd.distributed import ShardedTGN
-        runner = ShardedTGN(tgn, rank, world)
-        step = runner.step_device
-    else:
-        step = tgn.step_device
-
-    # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
-    # its real shape against the oracle with exactly these settings)
-    cus, a.group = synth.pipeline_settings(wl, a.steps, a.tppr_cus, a.group)
-    if not a.no_pipeline:
-        # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b
-        a.tppr_cus = cus
-        # Several ranks: the same masks.  torch.distributed runs the RCCL kernel of the row exchange on a stream of
-        # its own (ProcessGroupNCCL orders it against the current stream with events), so the masks neither confine nor
-        # block it; without them the T-PPR kernel shares CUs with the aggregation (N = 1: 0.665 instead of 0.585
-        # ms/step).  ZT_BENCH_NO_MASKS=1 switches them off.
-        if os.environ.get("ZT_BENCH_NO_MASKS") == "1":
-            a.tppr_cus = 0
-        try:
-            tgn.enable_pipeline(tppr_cus=a.tppr_cus, group=a.group)
-        except Exception as exc:                       # no CU-mask support: plain streams
-            sys.stderr.write("[bench] CU-masked streams unavailable (%s); using plain streams\n" % exc)
-            a.tppr_cus = 0
-            tgn.enable_pipeline(tppr_cus=0, group=a.group)
-    main_stream = getattr(tgn, "main_stream", None)
-
-    # views of every batch, made once: slicing tensors is host work that is not part of the path
-    batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
-                ts_d[b * bs:(b + 1) * bs], eidx_d[b * bs:(b + 1) * bs]) for b in range(n_steps_total)]
-
-    def batch(b):
-        return batches[b]
-
-    look = 3 * a.group                          # batches in sight: the rest of this group, the next group, the one after
-                                                # it, and one more (a group is only full while a follower is in sight)
-
-    def run(b0, nb):
-        # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)
-        ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
-        with ctx:
-            for b in range(b0, b0 + nb):
-                ahead = [] if a.no_pipeline else batches[b + 1: min(b + 1 + look, b0 + nb)]
-                step(*batch(b), ahead=ahead)
-
-    lib = _capi.lib()
-    run(0, prefill)
-    tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
-    torch.cuda.synchronize()
-    # ---- warm state for the CPU leg (the state after the 10 % prefill, where the GPU leg's warm-up steps start)
-    # and row-fill statistics.  Taken BEFORE the warm-up so that the W warm-up steps run right before the timed
-    # region (the snapshot idles the GPU for seconds).
-    e0 = prefill * bs
-    cpu_nb = 0
-    if world == 1 and a.cpu_edges != 0:
-        ce = a.cpu_edges if a.cpu_edges > 0 else {"c5": 48 * bs, "c3": 40 * bs, "c2": 60 * bs, "c4": 20 * bs}[a.workload]
-        cpu_nb = max(2, min(a.steps + a.warmup, ce // bs))
-    snap, fill = None, None
-    if cpu_nb:
-        touched = np.unique(np.concatenate([src[:e0], dst[:e0]])) if e0 else np.zeros(0, np.int64)
-        snap = snapshot_state(tgn, wl, touched)
-        if wl["strategy"] == "streaming" and len(touched):
-            ends = np.concatenate([src[e0:e0 + bs], dst[e0:e0 + bs], neg[e0:e0 + bs]])
-            pos = np.searchsorted(touched, ends)
-            seen = (pos < len(touched)) & (touched[np.minimum(pos, len(touched) - 1)] == ends)
-            ln = np.where(seen, snap["tppr"][0]["len"][np.minimum(pos, len(touched) - 1)], 0)
-            fill = dict(mean_row_len=float(ln.mean()), frac_empty=float((ln == 0).mean()), frac_full=float((ln == k).mean()))
-    if cpu_nb and not a.no_clock_spin:
-        # the snapshot above left the GPU idle for seconds (host-side export of the warm state): its clocks have dropped,
-        # and W = 5 warm-up steps (2 ms) do not bring them back.  Throw-away matrix products for a third of a second, on
-        # data that has nothing to do with the stream, before the warm-up steps -- so that the timed region measures the
-        # path and not the clock ramp
-        xa = torch.randn((4096, 4096), device=device)
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 0.35:
-            for _ in range(20):
-                xa = torch.mm(xa, xa).clamp_(-1.0, 1.0)
-            torch.cuda.synchronize()
-        del xa
-    run(prefill, a.warmup)
-    if not a.no_profile:
-        lib.zt_profile_reset()
-        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else 4)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(prefill + a.warmup, a.steps)
-    t_host = time.perf_counter() - t0          # host time to enqueue the timed steps
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    sys.stderr.write("[bench] host enqueue %.3f ms/step, wall %.3f ms/step\n" % (1e3 * t_host / a.steps, 1e3 * dt / a.steps))
-    lib.zt_profile_enable(0)
-    if wl["strategy"] == "streaming":
-        tgn.embedding_module.tppr_finder.check_status()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    torch.cuda.synchronize()
-    if not a.no_pipeline:
-        tgn.enable_pipeline(False)      # give the CU-masked streams back before the runtime shuts down
-
-    # ---- per-kernel HIP-event times over the timed region ----
-    kern = {}
-    if not a.no_profile:
-        for name in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg",
-                     "embed_out", "store_messages", "gru_update"):
-            n, ms = C.c_int64(), C.c_double()
-            lib.zt_profile_read(name.encode(), C.byref(n), C.byref(ms))
-            if n.value:
-                kern[name] = dict(launches=n.value, avg_us=1e3 * ms.value / n.value)
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    edges = a.steps * bs
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (separate
-    # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction; see profiles/make_pmc_summary.py)
-    pmc = {}
-    pmc_edges = None
-    if world == 1:
-        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-            pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % a.workload)
-            if os.path.isfile(pj):
-                summ = json.load(open(pj))
-                pmc = summ.get("kernels", {})
-                # per-launch bytes of the T-PPR kernel belong to a launch SHAPE: a summary measured with another
-                # number of batches per launch says nothing about this run's launches
-                # (the kernel's traffic is per edge -- rows read and written, tag polls: a summary measured on launches
-                #  of another size is scaled by the edges per launch, and the roofline note says so)
-                on = summ.get("measured_on") or {}
-                pmc_edges = on.get("edges_per_k_stream_launch")
-                if on.get("tppr_launch_group") not in (None, a.group) and not pmc_edges:
-                    pmc = {kk: vv for kk, vv in pmc.items() if kk != "tppr_stream"}
-                break
-    ab = algorithmic_bytes(k, F, M, strategy=wl["strategy"], width=wl.get("width", 10), depth=wl.get("depth", 2))
-    af = algorithmic_flops(k, F, M)
-    ex = executed_flops(k, F, M, projected=bool(getattr(tgn.embedding_module, "use_projection", False)))
-
-    def kernel_roofline(name):
-        """achieved = ALGORITHMIC bytes (or EXECUTED flops) of one launch / its average HIP-event time."""
-        us = kern[name]["avg_us"] * 1e-6
-        shard = world if name in ("fc1_agg", "embed_out", "pruned_topk") and world > 1 else 1
-        tr = pmc.get(name, {}).get("traffic")
-        if name in ("fc1_agg", "embed_out"):
-            ach = ex[name] * bs / shard / us / 1e12
-            # the main stream is confined to the CUs the T-PPR stream does not own (CU masks): the whole-chip peak is
-            # the contract's `peak`; the share of the CUs the kernel can run on is given beside it
-            cus_total = torch.cuda.get_device_properties(device).multi_processor_count
-            cus_used = cus_total - (a.tppr_cus if (not a.no_pipeline and a.tppr_cus > 0) else 0)
-            return dict(kernel=name, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr, cus=cus_used,
-                        frac_of_own_cus=ach / (MFMA_F32_PEAK_TF * cus_used / cus_total),
-                        note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
-                             "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if name == "fc1_agg" else None)
-        if name == "tppr_stream":
-            # one k_stream launch covers all M models and `group` batches (fewer at the ends of the region)
-            per_launch = a.steps * bs / kern[name]["launches"]     # (every launch of the T-PPR update is timed)
-            byts = ab["p1"] * M * per_launch
-            note = ("dependency/latency-bound phase (SURVEY.md 8d P1): edges of a batch are applied in order along "
-                    "per-node chains; the binding resource is hops x hop latency, not HBM")
-            if tr is not None and pmc_edges and abs(pmc_edges - per_launch) > 1:
-                tr = tr * per_launch / pmc_edges
-                note += "; traffic: counters of %d-edge launches scaled to this run's %.0f edges per launch" % (pmc_edges, per_launch)
-        elif name == "pruned_topk":
-            # ONE launch serves all M models: the CSR tails are read once, every model writes its output rows
-            byts = (ab["p1"] - 48 * k + M * 48 * k) * bs / shard
-            note = "CSR tail reads (once for all models) + output rows per query and model (search probes not counted)"
-        elif name == "gru_update":
-            byts = 2 * (4 * (2 * 100 + F + 100) + 8 * 100 + 4) * bs / shard
-            note = None
-        else:
-            byts = ab["p3"] * bs / shard
-            note = None
-        ach = byts / us / 1e9
-        # the streaming T-PPR kernel is bound by (hops of the longest per-node chain) x (latency of one hop), not by
-        # HBM: `achieved` / `peak` / `frac` are still its algorithmic bytes against the HBM peak, for the record
-        out_r = dict(kernel=name, bound="latency" if name == "tppr_stream" else "hbm", achieved=ach, peak=HBM_PEAK_GBS,
-                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, note=note)
-        if name == "tppr_stream":
-            out_r["edges_per_launch"] = per_launch
-        return out_r
-
-    # dominant kernel = the one with the largest total time in the timed region
-    roof = roof2 = None
-    if kern:
-        dom = max(kern, key=lambda n: kern[n]["avg_us"] * kern[n]["launches"])
-        roof = kernel_roofline(dom)
-        # the largest THROUGHPUT kernel as well, when the dominant one is the latency-bound T-PPR chain
-        if dom != "fc1_agg" and "fc1_agg" in kern:
-            roof2 = kernel_roofline("fc1_agg")
-
-    cpu = None
-    if cpu_nb:
-        n_threads = min(16, os.cpu_count() or 1)
-        weights, time_w = model_weights(tgn)
-        b0 = prefill
-        batches = [(src[b * bs:(b + 1) * bs], dst[b * bs:(b + 1) * bs], neg[b * bs:(b + 1) * bs], ts[b * bs:(b + 1) * bs],
-                    eidx[b * bs:(b + 1) * bs]) for b in range(b0, b0 + cpu_nb)]
-        extra = dict(src=src, dst=dst, eidx=eidx, ts=ts)
-        if F != 1:
-            extra["efeat"] = tgn.edge_raw_features.cpu().numpy()
-        cpu = cpu_baseline(wl, snap, weights, time_w, batches, extra, n_threads)
-
-    value = edges / dt
-    out = {
-        "metric": "temporal edges/sec embedded (k=%d, 2-layer)" % k if M == 2 else
-                  "temporal edges/sec embedded (k=%d, %d T-PPR models)" % (k, M),
-        "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64+f32", "data": "synthetic",
-        "config": {"workload": "%s: synthetic %s stream, %d nodes, bs=%d, k=%d, alpha=%s beta=%s, %s T-PPR, F=%d, "
-                               "prefill %d + warmup %d batches" % (a.workload, "bipartite" if wl["bipartite"] else
-                                                                   "power-law", wl["n_nodes"], bs, k, wl["alpha"],
-                                                                   wl["beta"], wl["strategy"], F, prefill, a.warmup),
-                   "global_batch": bs, "tppr_launch_group": a.group, "tppr_cus": a.tppr_cus,
-                   "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
-                   "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
-        "rccl_ranks": world if (world > 1 and not rehearsal) else 0,
-        "roofline": roof,
-        "roofline_throughput_kernel": roof2,
-        "cpu_baseline": cpu,
-        "row_fill": fill,
-        # flops_per_edge: SURVEY.md 8(d)'s figure = the REFERENCE's formulation (fc2 per neighbour, W_m memory per
-        # gathered row, scorer included); executed_flops_per_edge: what the step's kernels execute (no scorer: the
-        # timed step ends with the embeddings, as TGN.compute_temporal_embeddings does)
-        "algorithmic": {"bytes_per_edge": ab["total"], "flops_per_edge": af["total"],
-                        "executed_flops_per_edge": ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"],
-                        "hbm_gbs_at_value": ab["total"] * value / 1e9,
-                        "hbm_frac_at_value": ab["total"] * value / 1e9 / HBM_PEAK_GBS,
-                        "reference_formulation_tflops_at_value": af["total"] * value / 1e12,
-                        "reference_formulation_mfma_frac_at_value": af["total"] * value / 1e12 / MFMA_F32_PEAK_TF,
-                        "executed_mfma_frac_at_value": (ex["fc1_agg"] + ex["embed_out"] + ex["project_rows"] + af["gru"])
-                                                       * value / 1e12 / MFMA_F32_PEAK_TF},
-        "kernels": kern,
-    }
-    print(json.dumps(out))
+    cpu_default = {"c5": 48 * 4096, "c3": 40 * 600, "c2": 60 * 200, "c1": 60 * 200, "c4": 20 * 1000}
+    ce = a.cpu_edges if a.cpu_edges >= 0 else cpu_default[a.workload]
+    out = run_workload(a, a.workload, a.steps, a.warmup, world, rank, device, True, ce)
+    legs = a.legs
+    if legs == "default":
+        legs = "c2,c3,c4" if a.workload == "c5" else "none"
+    res = {}
+    for name in [x for x in legs.split(",") if x and x != "none"]:
+        # the other BASELINE configs, short: the driver's one run times all four (CPU legs bounded to ~2-4 s each)
+        leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
+        r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
+        if r is not None:
+            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "with_scorer",
+                                              "roofline", "roofline_throughput_kernel", "cpu_baseline", "algorithmic", "kernels")}
+    if rank == 0:
+        out["rccl_ranks"] = world if (world > 1 and not rehearsal) else 0
+        if res:
+            out["workloads"] = res
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

@@ -509,10 +509,13 @@ int zt_affinity(const float *emb_dev, int64_t B, int32_t H, const zt_affinity_we
 int zt_link_metrics(const float *pos_dev, const float *neg_dev, int64_t B, double *out_dev,
                     int32_t accumulate, void *stream);
 /* The scorer as the tail of the native step: with non-NULL weights every zt_pipeline_step_ahead over a WHOLE batch
- * (rows [0, 3B)) also writes that batch's 2B probabilities to prob_dev ([2 * max_B], overwritten every step; main
- * stream).  workspace_dev as for zt_affinity with ws_max_B = the pipeline's max_B.  NULL weights: off. */
+ * (rows [0, 3B)) also scores that batch's 2B pairs behind its aggregation (main stream).  prob_dev: [2][2 * max_B]
+ * floats, consecutive steps alternate between the halves.  workspace_dev as for
+ * zt_affinity with ws_max_B = the pipeline's max_B.  NULL weights: off.
+ * zt_pipeline_last_scores: makes `stream` wait for the last scoring and returns where its 2B probabilities are. */
 int zt_pipeline_set_scoring(zt_pipeline *p, const zt_affinity_weights *weights, void *workspace_dev,
                             float *prob_dev);
+int zt_pipeline_last_scores(zt_pipeline *p, void *stream, float **prob_out, int64_t *B_out);
 
 /* ------------------------------------------------------------------------ */
 /* One-node multi-GPU exchange of touched rows.  The reference  */

@@ -110,14 +110,130 @@ __global__ __launch_bounds__(64) void k_affinity(const float *__restrict__ emb, 
             __threadfence();
             if (lane < 32) {
                 const int e = lane & 15, which = lane >> 4;
-                float sc = 0.f;
+                float pv[NT];                                            // all of them requested before the first is looked at
+#pragma unroll
                 for (int q = 0; q < NT; ++q)
-                    sc += __int_as_float(ld_agent(reinterpret_cast<const int *>(part + ((size_t)q * 2 + which) * Bp + e0 + e)));
+                    pv[q] = __int_as_float(ld_agent(reinterpret_cast<const int *>(part + ((size_t)q * 2 + which) * Bp + e0 + e)));
+                float sc = 0.f;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) sc += pv[q];
                 sc += b2v;
                 if (e0 + e < B) prob[(size_t)which * B + e0 + e] = 1.f / (1.f + expf(-sc));
             }
             if (lane == 0) atomicExch(&counters[t], 0);                 // ready for the next launch
         }
+    }
+}
+
+// Large batches (B > 2048: C5).  The wave-per-N-tile kernel above reads every embedding row once per N-tile (19 x) and
+// runs one wave per SIMD: 190 us at B = 4096.  Here a workgroup of four waves owns 32 edges: their 96 embedding rows are
+// staged in LDS once (118 KB, every load in flight before the first store), each wave takes every fourth N-tile with all
+// six row tiles in accumulators (120 registers) and streams its own slice of W_a / W_b from L2 a k-chunk ahead -- each
+// weight is read once per workgroup, each embedding row once per launch.  The waves' partial scores meet in LDS and
+// are added in wave order.
+template <int KC, int ET>           // ET: edges per workgroup, 16 (mid-size batches: more workgroups) or 32
+__global__ __launch_bounds__(256, ET == 16 ? 2 : 1) void k_affinity_tiled(const float *__restrict__ emb, long long B, int H, const float *__restrict__ packed,
+                                                           const float *__restrict__ fc2_b, float *__restrict__ prob)
+{
+    constexpr int Hp = KC * 16, NT = KC, NQ = (NT + 3) / 4, ldA = Hp + 4, ROWS = 3 * ET, H4MAX = Hp / 4, EM = ET / 16, MTS = 3 * EM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *A = reinterpret_cast<float *>(smem);                          // [3 ET][ldA]: src rows, dst rows, neg rows of the tile
+    float *part = A + ROWS * ldA;                                        // [4 waves][2][ET]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const float *Wa = packed, *Wb = packed + (size_t)Hp * Hp, *b1p = Wb + (size_t)Hp * Hp, *w2p = b1p + Hp;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long e0 = (long long)blockIdx.x * ET;
+    const int h4 = H / 4;                                                // float4 per row (H % 4 == 0)
+    // ---- stage the 96 rows: zero beyond the batch and beyond H ----
+    constexpr int NST = (ROWS * H4MAX + 255) / 256;
+    f32x4 st[NST];
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int f = tid + q * 256, row = f / H4MAX, c4 = f - row * H4MAX;
+        const long long e = e0 + (row & (ET - 1));
+        const bool ok = row < ROWS && c4 < h4 && e < B;
+        st[q] = ok ? *reinterpret_cast<const f32x4 *>(emb + ((size_t)(row / ET) * B + e) * H + 4 * c4) : zero4;
+    }
+    // this wave's first weight chunk rides with the staging loads
+    bool live[NQ];
+    int colq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { live[q] = wave + 4 * q < NT; colq[q] = 16 * (live[q] ? wave + 4 * q : 0) + r16; }
+    f32x4 wa[2][NQ], wb[2][NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        wa[0][q] = *reinterpret_cast<const f32x4 *>(Wa + (size_t)colq[q] * Hp + 4 * g4);
+        wb[0][q] = *reinterpret_cast<const f32x4 *>(Wb + (size_t)colq[q] * Hp + 4 * g4);
+    }
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+        const int f = tid + q * 256, row = f / H4MAX, c4 = f - row * H4MAX;
+        if (row < ROWS) *reinterpret_cast<f32x4 *>(A + row * ldA + 4 * c4) = st[q];
+    }
+    __syncthreads();
+    f32x4 acc[MTS][NQ];
+#pragma unroll
+    for (int mt = 0; mt < MTS; ++mt)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[mt][q] = zero4;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        if (c + 1 < KC) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                wa[(c + 1) & 1][q] = *reinterpret_cast<const f32x4 *>(Wa + (size_t)colq[q] * Hp + 16 * (c + 1) + 4 * g4);
+                wb[(c + 1) & 1][q] = *reinterpret_cast<const f32x4 *>(Wb + (size_t)colq[q] * Hp + 16 * (c + 1) + 4 * g4);
+            }
+        }
+        f32x4 a[MTS];
+#pragma unroll
+        for (int mt = 0; mt < MTS; ++mt) a[mt] = *reinterpret_cast<const f32x4 *>(A + (16 * mt + r16) * ldA + 16 * c + 4 * g4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (!live[q]) continue;
+#pragma unroll
+                for (int mt = 0; mt < MTS; ++mt)
+                    acc[mt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][j], mt < EM ? wa[c & 1][q][j] : wb[c & 1][q][j], acc[mt][q], 0, 0, 0);
+            }
+    }
+    // ---- relu(fc1) x fc2's weight over this wave's columns: lane (column, edges 16 et + 4 g4 + j) ----
+    float sp[EM][4], sn[EM][4];
+#pragma unroll
+    for (int et = 0; et < EM; ++et)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sp[et][j] = 0.f; sn[et][j] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (!live[q]) continue;
+        const float b1v = b1p[colq[q]], w2v = w2p[colq[q]];
+#pragma unroll
+        for (int et = 0; et < EM; ++et)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hp = acc[et][q][j] + acc[EM + et][q][j] + b1v, hn = acc[et][q][j] + acc[2 * EM + et][q][j] + b1v;
+                sp[et][j] += (hp > 0.f ? hp : 0.f) * w2v;
+                sn[et][j] += (hn > 0.f ? hn : 0.f) * w2v;
+            }
+    }
+#pragma unroll
+    for (int et = 0; et < EM; ++et)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = sp[et][j], y = sn[et][j];
+            x += dpp_f<0x128>(x); x += dpp_f<0x124>(x); x += dpp_f<0x122>(x); x += dpp_f<0x121>(x);
+            y += dpp_f<0x128>(y); y += dpp_f<0x124>(y); y += dpp_f<0x122>(y); y += dpp_f<0x121>(y);
+            if (r16 == 0) { part[(wave * 2 + 0) * ET + 16 * et + 4 * g4 + j] = x; part[(wave * 2 + 1) * ET + 16 * et + 4 * g4 + j] = y; }
+        }
+    __syncthreads();
+    if (tid < 2 * ET) {
+        const int e = tid & (ET - 1), which = tid / ET;
+        float sc = part[(0 * 2 + which) * ET + e];
+#pragma unroll
+        for (int wv = 1; wv < 4; ++wv) sc += part[(wv * 2 + which) * ET + e];
+        sc += fc2_b[0];
+        if (e0 + e < B) prob[(size_t)which * B + e0 + e] = 1.f / (1.f + expf(-sc));
     }
 }
 
@@ -275,9 +391,29 @@ extern "C" int zt_affinity(const float *emb_dev, int64_t B, int32_t H, const zt_
     const dim3 grid((unsigned)(tiles < 160 ? tiles : 160), (unsigned)(p.Hp / 16));
     float *part = reinterpret_cast<float *>(ws + p.off_part);
     int *cnt = reinterpret_cast<int *>(ws + p.off_cnt);
+    // small batches: the latency-organised kernel; large ones: the tiled one (ZT_AFFINITY_TILED_MIN_B moves the switch:
+    // a tuning knob, both give the same probabilities to rounding)
+    static const long long tiled_min = getenv("ZT_AFFINITY_TILED_MIN_B") ? atoll(getenv("ZT_AFFINITY_TILED_MIN_B")) : 512;
     ZT_PROF_BEGIN(s, P_SCORE);
-    if (p.Hp == 304) k_affinity<19><<<grid, 64, 0, s>>>(emb_dev, B, H, packed, wt->fc2_b, part, cnt, prob_dev);
-    else             k_affinity<13><<<grid, 64, 0, s>>>(emb_dev, B, H, packed, wt->fc2_b, part, cnt, prob_dev);
+    if (B >= tiled_min) {
+        // 16 edges per workgroup while that fills the chip once (two workgroups fit a CU), 32 beyond
+        const int et = B <= 16 * 512 ? 16 : 32;
+        const size_t lds = ((size_t)3 * et * (p.Hp + 4) + 4 * 2 * et) * 4;
+        static size_t attr[4] = {0, 0, 0, 0};
+        const int ki = (p.Hp == 304 ? 0 : 1) * 2 + (et == 16 ? 0 : 1);
+        const void *fns[4] = {reinterpret_cast<const void *>(k_affinity_tiled<19, 16>), reinterpret_cast<const void *>(k_affinity_tiled<19, 32>),
+                              reinterpret_cast<const void *>(k_affinity_tiled<13, 16>), reinterpret_cast<const void *>(k_affinity_tiled<13, 32>)};
+        if (lds > attr[ki]) {
+            ZT_HIP(hipFuncSetAttribute(fns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[ki] = lds;
+        }
+        const unsigned wgs = (unsigned)((B + et - 1) / et);
+        if (ki == 0)      k_affinity_tiled<19, 16><<<wgs, 256, lds, s>>>(emb_dev, B, H, packed, wt->fc2_b, prob_dev);
+        else if (ki == 1) k_affinity_tiled<19, 32><<<wgs, 256, lds, s>>>(emb_dev, B, H, packed, wt->fc2_b, prob_dev);
+        else if (ki == 2) k_affinity_tiled<13, 16><<<wgs, 256, lds, s>>>(emb_dev, B, H, packed, wt->fc2_b, prob_dev);
+        else              k_affinity_tiled<13, 32><<<wgs, 256, lds, s>>>(emb_dev, B, H, packed, wt->fc2_b, prob_dev);
+    } else if (p.Hp == 304) k_affinity<19><<<grid, 64, 0, s>>>(emb_dev, B, H, packed, wt->fc2_b, part, cnt, prob_dev);
+    else                    k_affinity<13><<<grid, 64, 0, s>>>(emb_dev, B, H, packed, wt->fc2_b, part, cnt, prob_dev);
     ZT_PROF_END(s, P_SCORE);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

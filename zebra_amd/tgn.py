@@ -136,11 +136,18 @@ class TGN(torch.nn.Module):
         return prob
 
     def enable_scoring(self, on=True):
-        """With the native pipeline: every whole-batch step also scores its 2B pairs (zt_pipeline_set_scoring);
-        ``self.last_prob`` is then a [2 * max_batch] float32 buffer whose first 2B entries belong to the last step
-        (overwritten by the next one)."""
+        """With the native pipeline: every whole-batch step also scores its 2B pairs behind its aggregation
+        (zt_pipeline_set_scoring); ``last_prob()`` returns the last step's probabilities."""
         self._score_on = bool(on)
         self._pipe_scoring_sync(force=True)
+
+    def last_prob(self):
+        """float32 [2B] view of the last scored step's probabilities (B positive pairs, then B negative ones), valid on
+        the caller's current stream; the buffer is reused two steps later."""
+        out, B = C.c_void_p(), C.c_int64()
+        check(lib().zt_pipeline_last_scores(self._pipe, stream_ptr(), C.byref(out), C.byref(B)), "zt_pipeline_last_scores")
+        off = (out.value - self._prob_buf.data_ptr()) // 4
+        return self._prob_buf[off: off + 2 * B.value]
 
     def _pipe_scoring_sync(self, force=False):
         if getattr(self, "_pipe", None) is None:
@@ -156,9 +163,9 @@ class TGN(torch.nn.Module):
         st, w, ready = st
         if ready and not force and getattr(self, "_pipe_score_set", False):
             return
-        if getattr(self, "last_prob", None) is None or self.last_prob.numel() < 2 * max_b:
-            self.last_prob = torch.zeros(2 * max_b, dtype=torch.float32, device=self.device)
-        check(lib().zt_pipeline_set_scoring(self._pipe, C.byref(w), ptr(st["ws"]), ptr(self.last_prob)), "zt_pipeline_set_scoring")
+        if getattr(self, "_prob_buf", None) is None or self._prob_buf.numel() < 4 * max_b:
+            self._prob_buf = torch.zeros(4 * max_b, dtype=torch.float32, device=self.device)
+        check(lib().zt_pipeline_set_scoring(self._pipe, C.byref(w), ptr(st["ws"]), ptr(self._prob_buf)), "zt_pipeline_set_scoring")
         self._pipe_score_set = True
 
     # -- the step as ONE native call (csrc/pipeline.hip): P1 of batch b+1 on a side stream beside P2 + P3 of batch b
