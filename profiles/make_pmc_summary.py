@@ -40,14 +40,18 @@ def main():
                                   "tppr_launch_group": cfg.get("tppr_launch_group"), "tppr_cus": cfg.get("tppr_cus"),
                                   "steps": d.get("steps"),
                                   "edges_per_k_stream_launch": (cfg.get("tppr_launch_group") or 1) * (cfg.get("global_batch") or 0)}
-    names = {"k_stream": "tppr_stream", "k_fc1_agg_reg<20, 0>": "fc1_agg", "k_fc1_agg_reg<40, 0>": "fc1_agg", "k_fc1_agg_d100<20>": "fc1_agg", "k_fc1_agg_d100<40>": "fc1_agg", "k_fc1_agg_d100<10>": "fc1_agg",
-             "k_fc1_agg<true>": "fc1_agg_generic", "k_fc1_agg<false>": "fc1_agg_full", "k_embed_out": "embed_out",
-             "k_gru": "gru_update", "k_build_messages": "store_messages", "k_pruned_topk": "pruned_topk", "k_deps": "tppr_prepass",
-             "k_project_rows": "project_rows"}
-    for k, n in names.items():
-        if k in f or k in w:
-            fr, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
-            out["kernels"][n] = {"fetch_raw": fr, "write": wr, "traffic": 2 * fr + wr}
+    # kernel-name prefix -> bench.py's name (template arguments vary with the workload)
+    prefixes = [("k_stream", "tppr_stream"), ("k_fc1_agg_reg", "fc1_agg"), ("k_fc1_agg_wide", "fc1_agg"), ("k_fc1_agg_d100", "fc1_agg"),
+                ("k_fc1_agg<true>", "fc1_agg_generic"), ("k_fc1_agg<false>", "fc1_agg_full"), ("k_embed_out", "embed_out"),
+                ("k_gru", "gru_update"), ("k_build_messages", "store_messages"), ("k_pruned_topk", "pruned_topk"),
+                ("k_deps", "tppr_prepass"), ("k_prepass_fused", "tppr_prepass"), ("k_project_rows", "project_rows"),
+                ("k_affinity", "score")]
+    for k in sorted(set(f) | set(w)):
+        for pre, n in prefixes:
+            if k.startswith(pre) and n not in out["kernels"]:
+                fr, wr = f.get(k, 0.0) * 1024, w.get(k, 0.0) * 1024
+                out["kernels"][n] = {"kernel": k, "fetch_raw": fr, "write": wr, "traffic": 2 * fr + wr}
+                break
     print(json.dumps(out, indent=1))
 
 
