@@ -560,6 +560,10 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                    "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
                    "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
         "host_enqueue_ms_per_step": 1e3 * t_host / steps,
+        # the replicated part of a multi-GPU step: every rank replays the whole batch's T-PPR chain (streaming strategy), so
+        # this much of the step does not shrink with N -- a flat curve is explained by the line itself
+        "chain_bound_ms_per_step": (kern["tppr_stream"]["avg_us"] * kern["tppr_stream"]["launches"] / steps / 1e3)
+                                   if "tppr_stream" in kern else None,
         "with_scorer": with_scorer,
         "roofline": roof,
         "roofline_throughput_kernel": roof2,
@@ -676,7 +680,7 @@ def main():
         leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
         r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
         if r is not None:
-            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "with_scorer",
+            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "chain_bound_ms_per_step", "with_scorer",
                                               "roofline", "roofline_throughput_kernel", "cpu_baseline", "algorithmic", "kernels")}
     if rank == 0:
         out["rccl_ranks"] = world if (world > 1 and not rehearsal) else 0

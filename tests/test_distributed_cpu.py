@@ -51,12 +51,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, shape=(200, 8, 11, 32)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        N, D, W, B = 200, 8, 11, 32
+        N, D, W, B = shape
         rng = np.random.RandomState(5)                       # same on every rank: replicated tables
         mem = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32))
         lu = torch.zeros(N)
@@ -78,10 +79,10 @@ def _worker(rank, world, port, out):
         n = exchange_touched_rows([mem, lu, msg], ids, torch.tensor([len(mine)], dtype=torch.int32), cap)
         assert n == len(last)
         # every replica must now hold every winner's row
-        for v in last:
-            assert torch.equal(mem[v], torch.full((D,), float(v)))
-            assert lu[v] == v + 0.5
-            assert torch.equal(msg[v], torch.arange(W, dtype=torch.float32) + v)
+        vs = torch.tensor(sorted(last), dtype=torch.int64)
+        assert torch.equal(mem[vs], vs.to(torch.float32).reshape(-1, 1).expand(-1, D))
+        assert torch.equal(lu[vs], vs.to(torch.float32) + 0.5)
+        assert torch.equal(msg[vs], torch.arange(W, dtype=torch.float32).reshape(1, -1) + vs.to(torch.float32).reshape(-1, 1))
         # replicas are identical
         digest = torch.cat([mem.reshape(-1), lu, msg.reshape(-1)])
         gathered = [torch.empty_like(digest) for _ in range(world)]
@@ -92,11 +93,16 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_exchange_touched_rows_gloo(world):
+@pytest.mark.parametrize("world,shape", [(2, (200, 8, 11, 32)), (3, (200, 8, 11, 32)),
+                                         (8, (20000, 100, 301, 4096)),      # C5's step: 8 192 positions, rows of 100 + 1 + 301 floats
+                                         (8, (20000, 100, 301, 4059))])     # ... and a ragged last batch (positions not divisible by 8)
+def test_exchange_touched_rows_gloo(world, shape):
+    """The touched-row exchange of a sharded step over gloo: world 2 and 3 on a toy shape, world 8 at
+    C5's sizes -- every rank owns the winners at its slice of the 2B positions, one fixed-size all-gather, every replica
+    ends up with every winner's rows and all replicas are identical."""
     mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, shape), nprocs=world, join=True)
     assert sorted(out.keys()) == list(range(world))
 
 

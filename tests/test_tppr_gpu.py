@@ -235,7 +235,7 @@ def test_exact_topk_selection_paths(zt, oracle, n, k):
             continue
         sel = torch.full((cases, k), -1, dtype=torch.int32, device="cuda")
         path = torch.full((cases,), -1, dtype=torch.int32, device="cuda")
-        _capi.check(_capi.lib().zt_test_topk(_capi.ptr(dv), C.c_int32(n), C.c_int32(k), C.c_int32(cases),
+        _capi.check(_capi.hooks_lib().zt_test_topk(_capi.ptr(dv), C.c_int32(n), C.c_int32(k), C.c_int32(cases),
                                              C.c_int32(mode), _capi.ptr(sel), _capi.ptr(path), _capi.stream_ptr()))
         got = sel.cpu().numpy()
         bad = np.where((got != want).any(axis=1))[0]
@@ -267,7 +267,7 @@ def test_large_single_call_and_epoch_wrap(zt, oracle):
     for x, y in zip(a, b):
         assert np.array_equal(np.stack(x), np.stack(y))
     # jump next to the epoch wrap and keep streaming across it
-    _capi.check(_capi.lib().zt_test_set_epoch(f._live.h, C.c_uint32((1 << 17) - 4)))
+    _capi.check(_capi.hooks_lib().zt_test_set_epoch(f._live.h, C.c_uint32((1 << 17) - 4)))
     for s in range(20000, 30000, 1000):
         e = s + 1000
         nodes = np.concatenate([src[s:e], dst[s:e], neg[s:e]])

@@ -26,7 +26,7 @@ SYMBOLS = [
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
-    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention", "zt_test_topk", "zt_test_set_epoch",
+    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention",
     "zt_affinity_workspace_bytes", "zt_affinity", "zt_link_metrics", "zt_pipeline_set_scoring", "zt_pipeline_last_scores",
 ]
 
@@ -89,6 +89,22 @@ def lib():
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_int64
     return _lib
+
+
+_hooks = None
+
+
+def hooks_lib():
+    """libzebra_amd_testhooks.so: direct access to device primitives for the TESTS (zt_test_topk, zt_test_set_epoch;
+    zebra_amd/csrc/test_hooks.h).  Not part of the product library; the product never loads it."""
+    global _hooks
+    if _hooks is None:
+        lib()                                           # the hooks resolve their symbols against the product library
+        path = os.path.join(os.path.dirname(LIB_PATH), "libzebra_amd_testhooks.so")
+        if not os.path.exists(path):
+            raise ImportError("zebra_amd: %s not found (python -m zebra_amd.build)" % path)
+        _hooks = C.CDLL(path)
+    return _hooks
 
 
 class ZebraError(RuntimeError):

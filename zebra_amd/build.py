@@ -17,7 +17,10 @@ LIB = os.path.join(LIBDIR, "libzebra_amd.so")
 
 # file -> extra flags
 SOURCES = {
+    "runtime.hip": [],
+    "tppr_prepass.hip": [],
     "tppr_stream.hip": ["-ffp-contract=off"],
+    "tppr_io.hip": [],
     "tppr_prune.hip": ["-ffp-contract=off"],
     "aggregate.hip": [],
     "aggregate_wide.hip": [],
@@ -27,8 +30,10 @@ SOURCES = {
     "attention.hip": [],
     "scoring.hip": [],
     "pipeline.hip": [],
-    "test_hooks.hip": ["-ffp-contract=off"],
 }
+# NOT part of the product library: direct access to device primitives for the tests (tests load it beside the library)
+HOOK_SOURCES = {"test_hooks.hip": ["-ffp-contract=off"]}
+HOOKS_LIB = os.path.join(LIBDIR, "libzebra_amd_testhooks.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -60,6 +65,18 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+    # the test hooks: their own shared object, resolved against the product library next to it
+    hobjs, hrebuilt = [], False
+    for src, extra in HOOK_SOURCES.items():
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        if force or _newer(sp, op) or any(_newer(h, op) for h in headers):
+            subprocess.run([hipcc] + COMMON + extra + ["-c", sp, "-o", op], check=True)
+            hrebuilt = True
+        hobjs.append(op)
+    if hrebuilt or rebuilt or not os.path.exists(HOOKS_LIB):
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HOOKS_LIB] + hobjs +
+                       ["-L" + LIBDIR, "-lzebra_amd", "-Wl,-rpath,$ORIGIN"], check=True)
     return LIB
 
 

@@ -692,11 +692,13 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_fc1_agg_d100(
 // Time encoding: every argument goes through time_cosf_rev (below), whose reduction is exact enough for any dt the
 // stream produces: arguments beyond 4e6 (old neighbours: dt is seconds) are everyday data at stream scale.
 // ---------------------------------------------------------------------------
-__device__ unsigned long long g_regclk[4 * 1024];   // diagnostic (DBG builds): per wave: shader cycles, wall start, wall end (100 MHz), tiles
+#ifdef ZT_DIAG
+__device__ unsigned long long g_regclk[4 * 1024];   // diagnostic builds (-DZT_DIAG, tools/build_diag.sh): per wave: shader cycles, wall start, wall end (100 MHz), tiles
+#endif
 constexpr int REG_NS = 26;       // MFMA k-steps: F + T <= 104
 constexpr int REG_NB = 7;        // N-tiles of the hidden layer (D = 100 -> 112 columns)
 
-template <int KK, int DBG = 0>     // DBG: diagnostic builds (ZT_AGG_DBG, wrong results): 1 no cosine, 2 bare epilogue, 4 no projected rows
+template <int KK, int DBG = 0>     // DBG != 0: only instantiated in diagnostic builds (-DZT_DIAG + ZT_AGG_DBG; WRONG results: 1 no cosine, 2 bare epilogue, 4 no projected rows)
 __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
     const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
     long long num_edges, int F, long long N, int M, const int *__restrict__ nbr, const int *__restrict__ eix,
@@ -743,7 +745,9 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
 #pragma unroll
     for (int b = 0; b < REG_NB; ++b) bias[b] = (16 * b + r16) < D ? b1[16 * b + r16] : 0.f;
 
+#ifdef ZT_DIAG
     const unsigned long long clk0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull, wall0 = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     const long long tpm = (N + RQ - 1) / RQ;                           // tiles per model
     const long long n_tiles = tpm * M;
     const long long stride = (long long)gridDim.x * AGG_WAVES;
@@ -944,11 +948,13 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
         }
         wave_sync();                                                   // all reads of the scalar buffer are done
     }
+#ifdef ZT_DIAG
     if (DBG && lane == 0 && blockIdx.x * AGG_WAVES + wave < 1024) {
         unsigned long long *o = g_regclk + 4 * (blockIdx.x * AGG_WAVES + wave);
         o[0] = __builtin_amdgcn_s_memtime() - clk0; o[1] = wall0; o[2] = __builtin_amdgcn_s_memrealtime();
         o[3] = __builtin_amdgcn_s_getreg(((5 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1371,12 +1377,14 @@ extern "C" int zt_debug_agg(unsigned long long *host, int reset)
 }
 #endif
 
+#ifdef ZT_DIAG
 extern "C" int zt_debug_regclk(unsigned long long *host)
 {
     ZT_HIP(hipDeviceSynchronize());
     ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_regclk), sizeof(unsigned long long) * 4 * 1024));
     return ZT_OK;
 }
+#endif
 
 extern "C" int64_t zt_embed_workspace_bytes(int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
 {
@@ -1542,6 +1550,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         const int cus = stream_cu_count(s);
         if (wgs > cus) wgs = cus;                                      // persistent: one workgroup (4 waves) per CU
         const size_t reg_lds = 0;
+#ifdef ZT_DIAG
         static const int dbg = getenv("ZT_AGG_DBG") ? atoi(getenv("ZT_AGG_DBG")) : 0;       // diagnostic (wrong results)
 #define ZT_REG_DBG(DB) k_fc1_agg_reg<20, DB><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, \
             num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
@@ -1550,7 +1559,9 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
         else if (k == 20 && dbg == 6) ZT_REG_DBG(6);
         else if (k == 20 && dbg == 7) ZT_REG_DBG(7);
 #undef ZT_REG_DBG
-        else if (k == 20)
+        else
+#endif
+        if (k == 20)
             k_fc1_agg_reg<20><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
                                                                  M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev);
         else

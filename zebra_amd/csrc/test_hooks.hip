@@ -1,6 +1,8 @@
 // Test hooks: direct access to device primitives whose rare paths need their
 // own tests (exact top-k selection under ties).  Not part of the product API.
 #include "numba_sort.hpp"
+#include "tppr_state.hpp"
+#include "test_hooks.h"
 
 using namespace zt;
 
@@ -81,5 +83,13 @@ extern "C" int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_
     }
     k_test_topk<<<cases, 64, 0, (hipStream_t)stream>>>(vals_dev, n, k, cases, mode, sel_out_dev, path_out_dev);
     ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+// move the launch epoch of a T-PPR handle (e.g. next to its wrap-around: all tags are cleared when it reaches 2^17 - 1)
+extern "C" int zt_test_set_epoch(zt_tppr *h, uint32_t epoch)
+{
+    if (!h) return ZT_ERR_ARG;
+    h->epoch = epoch > EPOCH_MAX ? EPOCH_MAX : epoch;
     return ZT_OK;
 }

@@ -1,0 +1,384 @@
+// The dependency prepass of a streaming T-PPR launch (reference utils/util.py:495-574 applies a batch's edges one by
+// one; here the order is made explicit before the update kernel runs): groups the batch's node accesses by node, gives
+// every access the tag of the last earlier writer of its node, picks the hub chains.  Reads node and edge ids only, so it
+// runs ahead of the update on another stream (zt_tppr_plan).
+#include "tppr_state.hpp"
+
+using namespace zt;
+
+namespace {
+
+// ---------------------------------------------------------------- prepass ----
+// One access = (role r, edge i) of the chunk; a = r*B + i.  Roles 0/1 (source,
+// destination) write their node's row, role 2 (negative) only reads it.  An
+// edge's second access to the same node (self-loop, negative == endpoint) is a
+// SHADOW: it is not entered into the node's group.
+// K1: validate ids; count accesses per node; remember each access' slot.
+// K0: a set is planned afresh: the status of the launch it last served is history (the handle's latch keeps it)
+__global__ void k_plan_begin(int *ctl) { if (threadIdx.x == 0) { ctl[2] = 0; ctl[13] = 0; } }
+
+__device__ __forceinline__ void d_count(int a, const int *__restrict__ nodes, const long long *__restrict__ eidx,
+                                        long long role_stride, int B, int n_roles, long long N, int *cnt, int *slot,
+                                        int *ctl, int *latch)
+{
+    if (a >= B * n_roles) return;
+    const int r = a / B, i = a % B;
+    const int x = nodes[(long long)r * role_stride + i];
+    bool ok = x >= 0 && x < N;
+    if (r == 0) {
+        const long long e = eidx[i];
+        ok = ok && e >= 0 && e <= 0x7fffffffll;
+    }
+    if (!ok) {
+        atomicExch(&ctl[2], ZT_ERR_RANGE);
+        latch_failure(latch, ZT_ERR_RANGE);
+        slot[a] = -1;
+        return;
+    }
+    bool shadow = false;
+    if (r >= 1) shadow = nodes[i] == x;                                    // same as the source
+    if (r == 2) shadow = shadow || nodes[role_stride + i] == x;           // same as the destination
+    if (shadow) { slot[a] = -2; return; }
+    slot[a] = atomicAdd(&cnt[x], 1);
+}
+
+__global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
+                        int B, int n_roles, long long N, int *cnt, int *slot, int *ctl, int *latch)
+{
+    d_count(blockIdx.x * blockDim.x + threadIdx.x, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
+}
+
+// K2: the first access of each node reserves a contiguous range of `list`.
+__device__ __forceinline__ void d_reserve(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                          const int *cnt, int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+{
+    if (a >= B * n_roles) return;
+    if (slot[a] == 0) {
+        const int x = nodes[(long long)(a / B) * role_stride + a % B];
+        const int c = cnt[x];
+        off[x] = atomicAdd(&ctl[0], c);
+        if (c >= HOT_MIN) {                        // hub candidate
+            const int hi = atomicAdd(&ctl[3], 1);
+            if (hi < MAX_HOT) { hot_node[hi] = x; hot_cnt[hi] = c; }
+        }
+    }
+}
+
+__global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+{
+    d_reserve(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+}
+
+// K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
+__device__ __forceinline__ void d_hot_select(int t, int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of,
+                                             int *chain_node, int *chain_len, int max_chains)
+{
+    if (t >= MAX_HOT) return;                      // MAX_HOT threads take part
+    int nh = ctl[3];
+    nh = nh < MAX_HOT ? nh : MAX_HOT;
+    if (t < MAX_CHAINS) chain_len[t] = 0;
+    if (ctl[2] == ZT_ERR_RANGE) { if (t == 0) ctl[4] = 0; return; }
+    int rank = 0;
+    if (t < nh) {
+        const int c = hot_cnt[t], x = hot_node[t];
+        for (int q = 0; q < nh; ++q) {
+            const int cq = hot_cnt[q];
+            rank += (cq > c || (cq == c && hot_node[q] < x)) ? 1 : 0;
+        }
+        if (rank < max_chains) { chain_of[x] = rank; chain_node[rank] = x; }
+    }
+    if (t == 0) ctl[4] = nh < max_chains ? nh : max_chains;
+}
+
+__global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of, int *chain_node,
+                             int *chain_len, int max_chains)
+{
+    d_hot_select(threadIdx.x, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+}
+
+// K2c: every edge with a hub endpoint is owned by that hub's chain (the more-touched hub if both are).
+__device__ __forceinline__ void d_own(int i, const int *__restrict__ nodes, long long role_stride, int B, const int *cnt,
+                                      const int *slot, const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+{
+    if (i >= B) return;
+    int owner = -1;
+    if (slot[i] >= 0 && slot[B + i] != -1) {        // valid edge
+        const int u = nodes[i], v = nodes[role_stride + i];
+        const int cu = chain_of[u], cv = chain_of[v];
+        if (cu >= 0 && (cv < 0 || cnt[u] >= cnt[v])) owner = cu;
+        else if (cv >= 0) owner = cv;
+        if (owner >= 0) {
+            const int p = atomicAdd(&chain_len[owner], 1);
+            if (p < CH_MAX) chain_edges[owner * CH_MAX + p] = i;
+            else owner = -1;                        // chain full: the general queue takes it
+        }
+    }
+    owner_of[i] = owner;
+}
+
+__global__ void k_own(const int *__restrict__ nodes, long long role_stride, int B, const int *cnt, const int *slot,
+                      const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+{
+    d_own(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
+}
+
+// K2d: one wavefront per chain sorts its edges ascending (rank by counting).
+__global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *chain_len, int *chain_edges, int *pos_of)
+{
+    __shared__ int e[CH_MAX];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= ctl[4]) return;
+    int len = chain_len[c];
+    len = len < CH_MAX ? len : CH_MAX;
+    for (int p = lane; p < len; p += 64) e[p] = chain_edges[c * CH_MAX + p];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lane; p < len; p += 64) {
+        const int me = e[p];
+        int r = 0;
+        for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
+        chain_edges[c * CH_MAX + r] = me;           // edge indices are distinct
+        pos_of[me] = r;
+    }
+}
+
+// K3: scatter accesses into their node's range, encoded (edge << 2) | role.
+__device__ __forceinline__ void d_fill(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                       const int *off, const int *slot, int *list)
+{
+    if (a >= B * n_roles) return;
+    const int s = slot[a];
+    if (s < 0) return;
+    list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = ((a % B) << 2) | (a / B);   // (edge << 2) | role
+}
+
+__global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
+                       const int *slot, int *list)
+{
+    d_fill(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, off, slot, list);
+}
+
+// K4: per access, from its node's group:
+//   wo    = number of writer accesses by earlier edges  (= ordinal of the last earlier writer)
+//   pflag = the latest earlier edge touching the node, if that access was a reader, else -1
+//   nxt   = how many later edges touch the node (the length of the chain waiting for this access)
+__device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                       const int *cnt, const int *off, const int *slot, const int *list, int *wo,
+                                       int *pflag, int *nxt)
+{
+    if (a >= B * n_roles) return;
+    if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0; return; }
+    const int x = nodes[(long long)(a / B) * role_stride + a % B];
+    const int o = off[x], c = cnt[x];
+    const int me = a % B;
+    int best = -1, best_role = 0, writers = 0, nx = 0;
+    // 16 list entries are fetched before any is used: a hub's group has hundreds of members and the
+    // loop is otherwise one L2 round trip per entry
+    for (int p0 = 0; p0 < c; p0 += 16) {
+        int b[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) b[t] = list[o + ((p0 + t) < c ? (p0 + t) : (c - 1))];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (p0 + t >= c) break;
+            const int e = b[t] >> 2, r = b[t] & 3;
+            if (e < me) {
+                writers += (r < 2) ? 1 : 0;
+                if (e > best) { best = e; best_role = r; }
+            } else if (e > me) {
+                ++nx;
+            }
+        }
+    }
+    wo[a] = writers;
+    nxt[a] = nx;
+    pflag[a] = (best >= 0 && best_role == 2) ? best : -1;
+}
+
+__global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
+                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
+{
+    d_deps(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+}
+
+// K5: restore the per-node counters and the control words for the next call.
+__device__ __forceinline__ void d_cleanup(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                          const int *slot, int *cnt, int *ctl, const int *hot_node, int *chain_of)
+{
+    if (a < MAX_HOT && a < ctl[3]) chain_of[hot_node[a]] = -1;
+    if (a >= B * n_roles) return;
+    if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
+}
+
+__global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
+                          int *cnt, int *ctl, const int *hot_node, int *chain_of)
+{
+    d_cleanup(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
+}
+
+// K6: control words back to zero (after k_cleanup has read ctl[3]); ctl[4] = chains stays for k_stream.
+__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 4 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
+
+// The whole prepass as ONE workgroup, for launches of at most PRE_FUSED_MAX accesses (small batches: there the ten
+// launches above cost more on the host and in launch gaps than the work itself).  Same steps, same arrays, same
+// results; the steps are separated by workgroup barriers instead of kernel boundaries.
+constexpr int PRE_FUSED_MAX = 12288;
+constexpr int PRE_THREADS = 1024;
+__global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
+    const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
+    long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
+    int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
+    int *pos_of, int max_chains)
+{
+    __shared__ int e[CH_MAX];
+    const int tid = threadIdx.x, A = B * n_roles;
+    if (tid == 0) { ctl[2] = 0; ctl[13] = 0; }                                   // k_plan_begin
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_count(a, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_reserve(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_fill(a, nodes, role_stride, B, n_roles, off, slot, list);
+    __syncthreads();
+    for (int a = tid; a < A; a += PRE_THREADS) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+    d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+    __syncthreads();
+    for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
+    __syncthreads();
+    const int n_ch = max_chains > 0 ? ctl[4] : 0;                                // k_chain_sort, chain after chain
+    for (int c = 0; c < n_ch; ++c) {
+        int len = chain_len[c];
+        len = len < CH_MAX ? len : CH_MAX;
+        for (int p = tid; p < len; p += PRE_THREADS) e[p] = chain_edges[c * CH_MAX + p];
+        __syncthreads();
+        for (int p = tid; p < len; p += PRE_THREADS) {
+            const int me = e[p];
+            int r = 0;
+            for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
+            chain_edges[c * CH_MAX + r] = me;
+            pos_of[me] = r;
+        }
+        __syncthreads();
+    }
+    for (int a = tid; a < (A > MAX_HOT ? A : MAX_HOT); a += PRE_THREADS)
+        d_cleanup(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
+    __syncthreads();
+    if (tid < 4 && tid != 2) ctl[tid] = 0;                                       // k_reset_ctl
+}
+
+
+}  // namespace
+
+// CUs a stream may use (CU-masked streams: the size of the mask)
+int zt::tppr_stream_cus(const zt_tppr *h, hipStream_t s)
+{
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) { (void)hipGetLastError(); return h->n_cu; }
+    int c = 0;
+    for (int q = 0; q < 32; ++q) c += __builtin_popcount(mask[q]);
+    return (c > 0 && c < h->n_cu) ? c : h->n_cu;
+}
+
+// hub chains a grid can carry: at most two thirds of its workgroups, so the general queue always keeps waves
+int zt::tppr_chains_for_grid(int grid, int n_models)
+{
+    static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
+    int max_chains = (2 * grid) / (3 * n_models);
+    if (max_chains > chains_env) max_chains = chains_env;
+    if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
+    return max_chains < 0 ? 0 : max_chains;
+}
+
+// grid of k_stream and the number of hub chains for a launch of B edges on a stream of `cus` CUs
+void zt::tppr_launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *grid_out, int *max_chains_out)
+{
+    long long waves = (long long)B * n_models;
+    // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
+    // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
+    // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 8 waves).
+    static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
+    // Every workgroup of the grid must be resident at once (chain workgroups wait on each other's rows):
+    // the CUs of the stream that runs k_stream (a CU-masked stream offers fewer) times the workgroups one
+    // CU holds (asked from the runtime at create time).
+    long long max_waves = (long long)(cus * TPPR_WAVES_PER_WG * wgs_per_cu);
+    const long long resident = (long long)cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1) * TPPR_WAVES_PER_WG;
+    if (max_waves > resident) max_waves = resident;
+    if (max_waves < TPPR_WAVES_PER_WG) max_waves = TPPR_WAVES_PER_WG;
+    if (waves > max_waves) waves = max_waves;
+    const int grid = (int)((waves + TPPR_WAVES_PER_WG - 1) / TPPR_WAVES_PER_WG);
+    *grid_out = grid;
+    // the chain hand-off (two-stage mailbox) is built on the register-resident merge: k <= 30
+    *max_chains_out = h->k <= TPPR_REG_K_MAX ? tppr_chains_for_grid(grid, n_models) : 0;
+}
+
+// The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
+// edge ids, never the T-PPR rows, so it may run while k_stream works on the other set.
+int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *eidx, long long role_stride, int B,
+                        int n_roles, int model, hipStream_t s)
+{
+    zt_tppr::PlanSet &P = h->set[q];
+    if (P.used) ZT_HIP(hipStreamWaitEvent(s, P.consumed, 0));      // k_stream of two calls ago has let go of it
+    use_set(h, q);
+    const int A = B * n_roles;
+    const int tb = 256, gb = (A + tb - 1) / tb;
+    const int n_models = model < 0 ? h->M : 1;
+    int grid, max_chains;
+    tppr_launch_shape(h, h->run_cus > 0 ? h->run_cus : h->n_cu, B, n_models, &grid, &max_chains);
+    static const bool fused_ok = !(getenv("ZT_PREPASS_FUSED") && atoi(getenv("ZT_PREPASS_FUSED")) == 0);
+    if (fused_ok && A <= PRE_FUSED_MAX) {
+        ZT_PROF_BEGIN(s, P_PREPASS);
+        k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
+                                                  h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
+                                                  h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
+                                                  h->pos_of, max_chains);
+        ZT_PROF_END(s, P_PREPASS);
+    } else {
+        ZT_PROF_BEGIN(s, P_PREPASS);
+        k_plan_begin<<<1, 64, 0, s>>>(h->ctl);
+        k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl, h->latch_dev);
+        k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
+        k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
+        k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
+        k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
+                                           max_chains);
+        k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
+                                               h->chain_edges, h->owner_of);
+        if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges, h->pos_of);
+        ZT_PROF_END(s, P_PREPASS);
+        // per-node counters and the control words back to their rest state: the set is ready for k_stream
+        ZT_PROF_BEGIN(s, P_CLEANUP);
+        k_cleanup<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->cnt, h->ctl, h->hot_node, h->chain_of);
+        k_reset_ctl<<<1, 64, 0, s>>>(h->ctl);
+        ZT_PROF_END(s, P_CLEANUP);
+    }
+    ZT_LAUNCH_CHECK();
+    ZT_HIP(hipEventRecord(P.planned, s));
+    P.nodes = nodes; P.B = B; P.n_roles = n_roles; P.model = model; P.grid = grid; P.max_chains = max_chains;
+    return ZT_OK;
+}
+
+
+extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t *eidx_dev, int64_t B, int32_t n_roles,
+                            int32_t model, uint64_t *token_out, void *stream)
+{
+    if (token_out) *token_out = 0;
+    if (!h || B < 0 || (n_roles != 2 && n_roles != 3) || model >= h->M || !token_out) {
+        set_error("zt_tppr_plan: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (int st = latched(h, "zt_tppr_plan")) return st;
+    if (B == 0 || B > MAX_CHUNK) return ZT_OK;      // nothing to prepare / a multi-launch call plans inline
+    if (!nodes_dev || !eidx_dev) { set_error("zt_tppr_plan: NULL buffer"); return ZT_ERR_ARG; }
+    const int q = h->next_set;
+    h->next_set ^= 1;
+    h->set[q].valid = false;
+    int rc = zt::tppr_plan_chunk(h, q, nodes_dev, reinterpret_cast<const long long *>(eidx_dev), B, (int)B, n_roles, model,
+                        (hipStream_t)stream);
+    if (rc != ZT_OK) return rc;
+    h->set[q].valid = true;
+    h->set[q].token = ++h->plan_serial;
+    *token_out = h->set[q].token;
+    return ZT_OK;
+}
+

@@ -463,7 +463,11 @@ static int pruned_launch(const zt_csr *c, const int32_t *q_nodes_dev, const doub
         return ZT_ERR_UNSUPPORTED;
     }
     const int cap_c = (int)cap, cap_f = (int)front;
-    static const int dbg_stop = getenv("ZT_PRUNE_STOP") ? atoi(getenv("ZT_PRUNE_STOP")) : 0;   // diagnostic: 1 walk only, 2 + merge
+#ifdef ZT_DIAG
+    static const int dbg_stop = getenv("ZT_PRUNE_STOP") ? atoi(getenv("ZT_PRUNE_STOP")) : 0;   // diagnostic builds only (WRONG results): 1 walk only, 2 + merge
+#else
+    constexpr int dbg_stop = 0;
+#endif
     for (int m0 = 0; m0 < M;) {
         // as many models per launch as the workgroup's LDS allows (at least one)
         int mm = M - m0 < PR_MAX_MODELS ? M - m0 : PR_MAX_MODELS;
