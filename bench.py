@@ -318,10 +318,25 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     look = 3 * group                            # batches in sight: the rest of this group, the next group, the one after
                                                 # it, and one more (a group is only full while a follower is in sight)
 
+    # the batch loop itself: native (zt_pipeline_run: the region's steps from one host call -- the loop of
+    # evaluation/evaluation.py:19-45 in the library) unless --python-loop, several ranks (the row exchange between steps is
+    # torch.distributed) or no pipeline
+    native = world == 1 and not no_pipeline and not a.python_loop
+    prepared = {}
+
+    def prep(b0, nb):
+        if native:
+            prepared[(b0, nb)] = tgn.prepare_run(batches[b0:b0 + nb])
+
     def run(b0, nb):
         # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)
         ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
         with ctx:
+            if native:
+                if (b0, nb) not in prepared:
+                    prep(b0, nb)
+                tgn.run_device(prepared[(b0, nb)], look=look)
+                return
             for b in range(b0, b0 + nb):
                 ahead = [] if no_pipeline else batches[b + 1: min(b + 1 + look, b0 + nb)]
                 step(*batches[b], ahead=ahead)
@@ -361,6 +376,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
             torch.cuda.synchronize()
         del xa
         spun = True
+    prep(prefill + warmup, steps)               # (the region's batch list in the library's form: made before the clock starts)
     run(prefill, warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
@@ -391,6 +407,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                     kern_a[kn] = dict(launches=n.value, avg_us=1e3 * ms.value / n.value)
         tgn.enable_scoring()
         b1 = prefill + warmup + steps
+        prep(b1 + 5, steps)
         run(b1, 5)
         if not a.no_profile:
             lib.zt_profile_reset()
@@ -556,7 +573,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],
                                                                    wl["beta"], wl["strategy"], F, prefill, warmup),
                    "global_batch": bs, "tppr_launch_group": group, "tppr_cus": tppr_cus,
-                   "clock_spin": spun,
+                   "clock_spin": spun, "step_loop": "native (zt_pipeline_run)" if native else "python",
                    "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
                    "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
         "host_enqueue_ms_per_step": 1e3 * t_host / steps,
@@ -615,6 +632,8 @@ def main():
     ap.add_argument("--group", type=int, default=-1,
                     help="consecutive batches whose streaming T-PPR update runs as ONE launch (zt_pipeline_set_group); "
                          "default: as many as fit a launch (<= 16384 edges), at most 4; 1 for the pruning strategy")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     ap.add_argument("--perm-seed", type=int, default=7,

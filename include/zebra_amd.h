@@ -458,6 +458,11 @@ int zt_pipeline_set_stats(zt_pipeline *p, float *avg_topk_dev);
 int zt_pipeline_outstanding(const zt_pipeline *p);
 int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *ahead, int32_t n_ahead,
                            int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
+/* n consecutive whole-batch steps from one host call (the batch loop of evaluation/evaluation.py:19-45): step b sees
+ * batches b + 1 .. b + look as `ahead`, never beyond the n given; its [3 B_b][D (M + 1)] embeddings go to
+ * out_emb_dev + b * out_stride floats (out_stride 0: one buffer, overwritten every step). */
+int zt_pipeline_run(zt_pipeline *p, const zt_batch *batches, int32_t n, int32_t look, float *out_emb_dev,
+                    int64_t out_stride);
 
 /* ------------------------------------------------------------------------ */
 /* TemporalAttentionLayer.forward -- model/temporal_attention.py:7-68        */

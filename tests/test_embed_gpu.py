@@ -219,6 +219,51 @@ def test_grouped_tppr_launches_match_sequential(group, look, ragged):
                 assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
 
 
+@pytest.mark.parametrize("strategy,group", [("streaming", 1), ("streaming", 3), ("pruning", 1)])
+def test_native_batch_loop_matches_stepwise(strategy, group):
+    """zt_pipeline_run (TGN.run_device: n steps from one host call, the batch loop of evaluation/evaluation.py:19-45) against
+    the same steps made one by one through step_device: every step's embeddings, the scores of the last step, and the
+    state (T-PPR rows, memory tables) afterwards -- bit for bit; a ragged last batch included."""
+    import types
+    from zebra_amd.tppr import get_neighbor_finder
+    D = T = 100
+    N, E, F, bs, k, al, be, seed = 3000, 4070, 1, 400, 20, [0.1, 0.1], [0.5, 0.95], 77
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, 2, seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts)) \
+        if strategy == "pruning" else None
+    res = {}
+    for mode in ("step", "run"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf).eval()
+        tgn.enable_pipeline(tppr_cus=0, max_batch=512, group=group)
+        tgn.enable_scoring()
+        dev = tgn.device
+        t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+        batches = [tuple(x[s0:s0 + bs] for x in t) for s0 in range(0, E, bs)]            # the last one has 70 edges
+        full = [b for b in batches if b[0].numel() == bs]
+        with torch.cuda.stream(tgn.main_stream):
+            if mode == "step":
+                embs = [tgn.step_device(*cur, ahead=batches[q + 1: q + 1 + 3 * group]).clone() for q, cur in enumerate(batches)]
+                out = torch.stack(embs[:len(full)])
+                last = embs[-1]
+            else:
+                out = torch.empty((len(full), 3 * bs, 300), dtype=torch.float32, device=dev)
+                tgn.run_device(tgn.prepare_run(full), out=out)
+                last = tgn.step_device(*batches[-1])
+            prob = tgn.last_prob().clone()
+        torch.cuda.synchronize()
+        st = [tgn.embedding_module.tppr_finder.export_state(m) for m in range(2)] if strategy == "streaming" else []
+        res[mode] = (out, last, prob, tgn.memory.memory.clone(), tgn.memory.messages.clone(), tgn.memory.last_update.clone(), st)
+        tgn.enable_pipeline(False)
+    a, b = res["step"], res["run"]
+    for q in range(6):
+        assert torch.equal(a[q], b[q]), q
+    for x, y in zip(a[6], b[6]):
+        for kk in x:
+            assert np.array_equal(x[kk], y[kk]), kk
+
+
 def test_pipeline_batch_size_change_keeps_packed_weights():
     """A pipelined stream whose LAST batch is shorter by enough to move round_up(4 * 2B, 256) -- bs = 64 then 20 --
     (round-2 advisor finding: the GRU's packed weights used to sit behind the row list of the workspace, whose

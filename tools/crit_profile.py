@@ -6,8 +6,10 @@ from zebra_amd import _capi
 _capi.LIB_PATH = '/root/repo/tools/out/libzebra_crit.so'
 from zebra_amd import tppr, synth
 lib = _capi.lib()
-wl = synth.WORKLOADS["c5"]; B = 4096; NB = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], NB * B, seed=2020)
+WL = sys.argv[2] if len(sys.argv) > 2 else "c5"        # crit_profile.py [batches] [workload] [batches per launch]
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+wl = synth.WORKLOADS[WL]; B = wl["bs"] * G; NB = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+src, dst, ts, eidx = synth.power_law_stream(wl["n_nodes"], NB * B, bipartite=wl["bipartite"], seed=2020, perm_seed=7)
 neg = synth.negatives(dst, len(src), seed=2021)
 f = tppr.tppr_finder(wl["n_nodes"] + 1, 20, 2, [0.1, 0.1], [0.5, 0.95])
 d = torch.device('cuda')

@@ -538,6 +538,24 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     return ZT_OK;
 }
 
+// n consecutive whole-batch steps from ONE host call: the per-batch loop of evaluation/evaluation.py:19-45 (and of a bulk
+// replay) without a trip through the caller's language per batch.  Step b sees the batches b + 1 .. b + look as `ahead`
+// (never beyond the n given: nothing of a later batch is enqueued).  out_emb_dev + b * out_stride receives step b's
+// [3 B_b][D (M + 1)] embeddings (out_stride = 0: every step overwrites the same buffer -- a caller that only wants the
+// scores of zt_pipeline_set_scoring or the final state).
+extern "C" int zt_pipeline_run(zt_pipeline *p, const zt_batch *batches, int32_t n, int32_t look, float *out_emb_dev,
+                               int64_t out_stride)
+{
+    if (!p || !batches || n < 0 || look < 0 || !out_emb_dev || out_stride < 0) { set_error("zt_pipeline_run: bad argument"); return ZT_ERR_ARG; }
+    for (int32_t b = 0; b < n; ++b) {
+        const int32_t na = (b + 1 + look <= n) ? look : (n - b - 1);
+        const int rc = zt_pipeline_step_ahead(p, &batches[b], na > 0 ? &batches[b + 1] : nullptr, na, 0, 3 * batches[b].B, 0,
+                                              2 * batches[b].B, out_emb_dev + (size_t)b * (size_t)out_stride);
+        if (rc != ZT_OK) return rc;
+    }
+    return ZT_OK;
+}
+
 extern "C" int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, const zt_batch *plan,
                                 int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev)
 {

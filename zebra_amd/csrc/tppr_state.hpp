@@ -20,9 +20,17 @@ constexpr int MAX_CHUNK = 16384;       // edges per launch (ordinals must fit OR
 constexpr unsigned EPOCH_MAX = (1u << (32 - ORD_BITS)) - 1;
 static_assert(MAX_CHUNK == zt::TPPR_MAX_LAUNCH, "common.hpp: TPPR_MAX_LAUNCH");
 // hub chains: the nodes touched most often in a launch get a workgroup of their own
-constexpr int HOT_MIN = 24;            // accesses in one launch that make a node a chain candidate
+// (overridable for experiments: tools/exp/chains_exp.sh -- 32 / 48 chains and a threshold of 12 were measured in round 4:
+//  no gain on C3, a loss on C5, where chain workgroups then crowd out the general queue)
+#ifndef ZT_HOT_MIN
+#define ZT_HOT_MIN 24
+#endif
+#ifndef ZT_MAX_CHAINS
+#define ZT_MAX_CHAINS 16
+#endif
+constexpr int HOT_MIN = ZT_HOT_MIN;       // accesses in one launch that make a node a chain candidate
 constexpr int MAX_HOT = 128;           // candidates kept
-constexpr int MAX_CHAINS = 16;         // chains per model
+constexpr int MAX_CHAINS = ZT_MAX_CHAINS; // chains per model
 constexpr int CTL_LOG = 6;             // timeout reports kept per launch
 constexpr int CTL_WORDS = 16 + 8 * CTL_LOG;
 constexpr int CH_MAX = 2048;           // edges per chain (the rest go through the general queue)

@@ -337,6 +337,50 @@ class TGN(torch.nn.Module):
                                            C.c_int64(r1), C.c_int64(p0), C.c_int64(p1), ptr(out)), "zt_pipeline_step")
         return out
 
+    def prepare_run(self, batches):
+        """The ctypes view of a list of batches (five device tensors each) for ``run_device``: made once, outside a timed
+        region.  The tensors must stay alive while a run may still read them."""
+        arr = (_capi.Batch * max(1, len(batches)))()
+        for q, b in enumerate(batches):
+            arr[q].src, arr[q].dst, arr[q].neg, arr[q].ts, arr[q].eidx = [x.data_ptr() for x in b]
+            arr[q].B = b[0].numel()
+        return arr, len(batches), [tuple(b) for b in batches]
+
+    @torch.no_grad()
+    def run_device(self, prepared, out=None, look=None):
+        """n consecutive eval-mode steps over whole batches as ONE native call (zt_pipeline_run): the batch loop of
+        evaluation/evaluation.py:19-45 without a Python iteration per batch.  ``prepared`` = ``prepare_run(batches)``.
+        out: None (one [3 B, H] buffer overwritten by every step -- for callers after the scores or the final state), or a
+        [n, 3 B, H] float32 tensor that receives every step's embeddings.  Call from ``self.main_stream``; the streaming
+        T-PPR state ends exactly behind the last batch given."""
+        if getattr(self, "_pipe", None) is None:
+            raise RuntimeError("run_device needs enable_pipeline()")
+        if not self.test_mode:
+            self.update_memory_in_test(self.memory)
+            self.test_mode = True
+        arr, n, keep = prepared
+        if n == 0:
+            return out
+        self._pipe_refresh()
+        if getattr(self, "_score_on", False):
+            self._pipe_scoring_sync()
+        self._pipe_want_stats(False)
+        H = self.embedding_dimension * (self.embedding_module.n_tppr + 1)
+        Bmax = max(int(arr[q].B) for q in range(n))
+        if out is None:
+            buf = getattr(self, "_run_scratch", None)
+            if buf is None or buf.numel() < 3 * Bmax * H:
+                buf = self._run_scratch = torch.empty(3 * Bmax * H, dtype=torch.float32, device=self.device)
+            stride = 0
+        else:
+            if out.shape != (n, 3 * Bmax, H) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float32 [n, 3 B, H] tensor")
+            buf, stride = out, 3 * Bmax * H
+        self._run_keep = keep
+        check(lib().zt_pipeline_run(self._pipe, arr, C.c_int32(n), C.c_int32(3 * self._pipe_group if look is None else look),
+                                    ptr(buf), C.c_int64(stride)), "zt_pipeline_run")
+        return out
+
     @torch.no_grad()
     def step_device(self, src_d, dst_d, neg_d, ts_d, eidx_d, check_status=False, prefetch=None, plan=None,
                     stats=False, rows=None, positions=None, ahead=None):
