@@ -23,7 +23,7 @@ struct HopRec {
     int wo_next, pf_next;   // ... and at its next edge (-1: there is none)
 };
 
-__device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
+__device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
                                  long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint, int chain_idx,
                                  const HopRec &rec)
 {
@@ -508,7 +508,7 @@ __device__ inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds 
 // order, hop after hop), the partner's and the negative sample's rows come from memory like everybody's.  The chain
 // reads the partner's OLD row as well: its "reads done" flag (cdone) gates the store of the partner's new row.
 // Taking this work out of the chain workgroup leaves the wave that holds the chain alone on its SIMD.
-__device__ inline void process_chain_partner(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo)
+__device__ __attribute__((always_inline)) inline void process_chain_partner(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo)
 {
     const int k = h.k, B = A.B, n_roles = A.n_roles;
     const int m = A.m_lo + mo;

@@ -145,7 +145,9 @@ __device__ __forceinline__ u64 *hub_version(const zt_tppr &h, int m, int c, int 
     return h.hubver + (((size_t)m * MAX_CHAINS + c) * (CH_MAX + 1) + t) * h.rg;
 }
 
-__device__ inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
+// (always_inline: with a third call site in k_stream the inliner once left this a real call -- rows in scratch memory, the
+//  kernel 17x slower: round 4)
+__device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
                                     long long hub, int prev_edge, int next_edge, int tpos, ChainHint *hint = nullptr,
                                     int chain_idx = -1)
 {
