@@ -155,9 +155,21 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
             if (f < GRU_MT * 16 * Xp) A[(size_t)g * lda + c] = v[u];
         }
     }
-    for (int f = tid; f < GRU_MT * 16 * Hp; f += nthr) {
-        const int g = f / Hp, c = f - g * Hp;
-        A[(size_t)g * lda + Xp + c] = (g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+    {   // the memory columns: all of a thread's elements in flight before its first LDS store (one round trip, not four)
+        constexpr int HU = 4;
+        for (int f0 = tid; f0 < GRU_MT * 16 * Hp; f0 += nthr * HU) {
+            float v[HU];
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const int f = f0 + u * nthr, g = f / Hp, c = f - g * Hp;
+                v[u] = (f < GRU_MT * 16 * Hp && g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < HU; ++u) {
+                const int f = f0 + u * nthr, g = f / Hp, c = f - g * Hp;
+                if (f < GRU_MT * 16 * Hp) A[(size_t)g * lda + Xp + c] = v[u];
+            }
+        }
     }
     __syncthreads();
 
