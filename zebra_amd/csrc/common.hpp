@@ -185,7 +185,7 @@ __device__ __forceinline__ float time_cosf(float x)
     r = fmaf(kf, 4.37113883e-08f, r);                   // the third term is < 5e-9 for |k| < 2.6e6
     // |r| <= pi/4 exactly reduced; the quadrant goes back in as quarter revolutions and v_cos_f32
     // (argument in revolutions) finishes: 9 instructions, max |err| 3e-7 over |x| < 4e6 (measured
-    // against float64 cos on 4M arguments, tools/costest.hip.txt)
+    // against float64 cos on 4M arguments: a round-2 microbenchmark)
     const int q = (int)kf & 3;
     return __builtin_amdgcn_cosf(fmaf(r, 0.159154943f, 0.25f * (float)q));
 }
