@@ -380,7 +380,9 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     run(prefill, warmup)
     if not a.no_profile:
         lib.zt_profile_reset()
-        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else 4)
+        # (two event records per timed launch are host calls too: every 4th launch of the main stream's kernels in the headline
+        #  run, every 8th in the legs, whose small-batch steps are bound by host enqueue)
+        lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else (4 if headline else 8))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -38,7 +38,7 @@ int store_messages_ex(const float *memory_dev, const float *last_update_dev, con
                       const int32_t *dst_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
                       int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
                       int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
-                      bool *zeroed_out = nullptr);
+                      bool *zeroed_out = nullptr, bool set_flags = true);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
 // the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)

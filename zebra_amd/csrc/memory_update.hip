@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_build_messages(
     const float *__restrict__ time_w, long long num_nodes, long long num_edges, int D, int F, int T,
     const int *__restrict__ src, const int *__restrict__ dst, const double *__restrict__ ts,
     const long long *__restrict__ eidx, long long B, float *messages, float *msg_ts, unsigned char *flags,
-    int *scratch, int *uniq_ids, int *n_uniq, const int *status, long long pos_lo, long long pos_hi)
+    int *scratch, int *uniq_ids, int *n_uniq, const int *status, long long pos_lo, long long pos_hi, int set_flags)
 {
     const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_build_messages(
         for (int c = lane; c < T; c += WAVE) row[2 * D + F + c] = time_cosf(delta * time_w[c]);
         if (lane == 0) {
             msg_ts[v] = tf;
-            flags[v] = 1;
+            if (set_flags) flags[v] = 1;           // (0: the caller consumes the list of winners itself, see store_messages_ex)
             if (uniq_ids) uniq_ids[atomicAdd(n_uniq, 1)] = v;
             else if (n_uniq) atomicAdd(n_uniq, 1);
         }
@@ -411,7 +411,7 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
                           const int32_t *dst_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B, int64_t pos_lo,
                           int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
                           int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
-                          bool *zeroed_out)
+                          bool *zeroed_out, bool set_flags)
 {
     if (zeroed_out) *zeroed_out = false;
     if (B < 0 || D <= 0 || F < 0 || T < 0 || !status_dev) { set_error("zt_store_messages: bad argument"); return ZT_ERR_ARG; }
@@ -422,14 +422,14 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
         return ZT_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (n_uniq_dev) ZT_HIP(hipMemsetAsync(n_uniq_dev, 0, sizeof(int), s));
+    if (n_uniq_dev && n_uniq_dev != zero_word_dev) ZT_HIP(hipMemsetAsync(n_uniq_dev, 0, sizeof(int), s));   // (else k_last_pos zeroes it)
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
     ZT_PROF_BEGIN(s, P_STORE_MSG);
     k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
                                                                scratch_dev, status_dev, zero_word_dev);
     k_build_messages<<<(unsigned)((2 * B + 3) / 4), 256, 0, s>>>(
         memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
-        B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi);
+        B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi, set_flags ? 1 : 0);
     ZT_PROF_END(s, P_STORE_MSG);
     ZT_LAUNCH_CHECK();
     if (zeroed_out) *zeroed_out = zero_word_dev != nullptr;      // k_last_pos ran: the word is zero for whatever follows on this stream

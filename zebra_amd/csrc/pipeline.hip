@@ -483,17 +483,21 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // caller's row exchange) and nothing the aggregation writes; the GRU below waits for them.
     ZT_HIP(hipEventRecord(p->step_begin, p->main_s));
     ZT_HIP(hipStreamWaitEvent(p->msg_s, p->step_begin, 0));
+    // Every endpoint of the batch gets a message here and is updated by the GRU below: in this protocol (eval steps, entered
+    // with no flag pending -- step_device flushes first) "flagged among the batch's endpoints after the store" IS the list of
+    // winners the message kernel already makes.  So the kernel hands its list to the GRU directly (the GRU workspace's row
+    // list and counter; k_last_pos zeroes the counter) and sets no flag: Memory.clear_messages for the same ids would clear
+    // it again -- and the compaction kernel (k_select_flagged) leaves the step.
     bool cnt_zeroed = false;
+    const int msg_dim = 2 * d.D + d.F + d.T;
+    char *gws = reinterpret_cast<char *>(d.gru_ws);
+    int32_t *gru_cnt = reinterpret_cast<int32_t *>(gws);
+    int32_t *gru_rows = reinterpret_cast<int32_t *>(gws + zt_gru_rows_offset(d.D, msg_dim));
     rc = zt::store_messages_ex(d.memory, d.last_update, d.efeat, d.ew.time_w, d.num_nodes, d.num_edges, d.D, d.F, d.T,
                                cur->src, cur->dst, cur->ts, cur->eidx, B, pos_lo, pos_hi, d.messages, d.msg_ts, d.flags,
-                               d.scratch, nullptr, nullptr, d.status, reinterpret_cast<int32_t *>(d.gru_ws), p->msg_s, &cnt_zeroed);
+                               d.scratch, gru_rows, gru_cnt, d.status, gru_cnt, p->msg_s, &cnt_zeroed, false);
     if (rc != ZT_OK) return rc;
-    // ... and the compaction of the flagged endpoints (the GRU's row list) right behind them, on the same stream: one
-    // launch less between the aggregation and the GRU on the main stream
-    const int msg_dim = 2 * d.D + d.F + d.T;
-    rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                           nullptr, &d.gw, d.gru_ws, 1, nullptr, nullptr, p->main_s, cnt_zeroed, p->msg_s, false);
-    if (rc != ZT_OK) return rc;
+    if (!cnt_zeroed) ZT_HIP(hipMemsetAsync(gru_cnt, 0, sizeof(int), p->msg_s));       // (B == 0 cannot get here; belt and braces)
     ZT_HIP(hipEventRecord(p->msgs_done, p->msg_s));
     if (n_rows > 0) {
         rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
