@@ -219,6 +219,69 @@ def test_grouped_tppr_launches_match_sequential(group, look, ragged):
                 assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
 
 
+@pytest.mark.parametrize("F,n", [(172, 400), (172, 37), (1, 512), (1, 2000), (4, 1)])
+def test_gru_kernels_agree(F, n):
+    """k_gru_split (a workgroup per 16 rows x N-tile, new rows committed by the tile's last workgroup: used up to 512 rows)
+    against k_gru (ZT_GRU_SPLIT_MAX_ROWS=0) and torch's GRUCell on the same flagged rows: memory, last_update, the projected
+    table; flags cleared; ragged last tile; rows the update does not name stay untouched."""
+    import os
+    import subprocess
+    import sys
+    D = T = 100
+    N, E1 = 5000, 100
+    w = I.model_weights(D, F, T, 2, 31)
+    _, efeat = I.random_tables(N, E1, D, F, 31)
+    g = torch.Generator().manual_seed(F + n)
+    msg = torch.randn((N, 2 * D + F + T), generator=g)
+    mem0 = torch.randn((N, D), generator=g) * 0.3
+    ts = torch.rand(N, generator=g) * 1e6
+    ids = (torch.randperm(N - 1, generator=g)[:n] + 1).to(torch.int32)
+    outs = {}
+    for mode in ("split", "tile"):
+        os.environ["ZT_GRU_SPLIT_MAX_ROWS"] = "100000" if mode == "split" else "0"
+        # the switch is read once per process: run each mode in a child
+        code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import inputs as I
+from helpers import build_tgn
+D = T = 100; F = %d; N = %d
+w = I.model_weights(D, F, T, 2, 31)
+_, efeat = I.random_tables(N, 100, D, F, 31)
+tgn = build_tgn(N, 100, D, F, T, 20, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
+d = np.load(sys.argv[1])
+m = tgn.memory
+m.messages.copy_(torch.from_numpy(d["msg"]).cuda()); m.memory.copy_(torch.from_numpy(d["mem"]).cuda()); m.timestamps.copy_(torch.from_numpy(d["ts"]).cuda())
+ids = torch.from_numpy(d["ids"]).cuda()
+m._flag_buf[ids.long()] = 1
+tgn.memory_updater.update_device(m, ids, ids.numel())
+torch.cuda.synchronize()
+np.savez(sys.argv[2], mem=m.memory.cpu().numpy(), lu=m.last_update.cpu().numpy(), flags=m._flag_buf.cpu().numpy())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
+       os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), F, N)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            np.savez(os.path.join(td, "in.npz"), msg=msg.numpy(), mem=mem0.numpy(), ts=ts.numpy(), ids=ids.numpy())
+            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
+                               env=dict(os.environ), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[mode] = dict(np.load(os.path.join(td, "out.npz")))
+    del os.environ["ZT_GRU_SPLIT_MAX_ROWS"]
+    cell = torch.nn.GRUCell(2 * D + F + T, D)
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(w["w_ih"])); cell.weight_hh.copy_(torch.from_numpy(w["w_hh"]))
+        cell.bias_ih.copy_(torch.from_numpy(w["b_ih"])); cell.bias_hh.copy_(torch.from_numpy(w["b_hh"]))
+        want = mem0.clone()
+        want[ids.long()] = cell(msg[ids.long()], mem0[ids.long()])
+    for mode in ("split", "tile"):
+        o = outs[mode]
+        assert np.abs(o["mem"] - want.numpy()).max() <= 1e-5, mode
+        lu = np.zeros(N, np.float32); lu[ids.numpy()] = ts.numpy()[ids.numpy()]
+        assert np.array_equal(o["lu"], lu), mode
+        assert not o["flags"].any(), mode
+    assert np.abs(outs["split"]["mem"] - outs["tile"]["mem"]).max() <= 2e-6
+
+
 @pytest.mark.parametrize("strategy,group", [("streaming", 1), ("streaming", 3), ("pruning", 1)])
 def test_native_batch_loop_matches_stepwise(strategy, group):
     """zt_pipeline_run (TGN.run_device: n steps from one host call, the batch loop of evaluation/evaluation.py:19-45) against

@@ -291,9 +291,190 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_gru_split (round 4): the same update for SMALL row counts.  Phase stamps of k_gru at C2's batch (400 rows, 25
+// workgroups on 224 CUs; tools/exp/gru_phases.py): 66 000 cycles per workgroup, 49 000 of them in the two gate products
+// -- a tile's 3 108 MFMAs all run on ONE compute unit (25 000 cycles of matrix pipe on its four SIMDs) while nine tenths
+// of the chip idle.  Here a workgroup owns (16 rows, ONE N-tile of the hidden layer): seven times the workgroups, and
+// its four waves split K, each with ALL its weight fragments (three gates x <= 10 chunks) requested before anything is
+// looked at, beside the staging of the tile's [message | memory] rows (every element in flight before the first LDS
+// store).  The waves' partial gate sums meet in LDS, wave 0 applies the gates.
+// The N-tiles of a row are now computed by DIFFERENT workgroups, each of which reads the row's old memory columns as K
+// input: nobody may write memory until all have read.  So the new values go to a staging buffer (workspace), and the
+// LAST workgroup of a tile to arrive (a counter per tile, reset by that workgroup) commits the 16 rows to the memory
+// table and projects them (P[v] = W_m h'[v] needs a row's all N-tiles anyway).
+// ---------------------------------------------------------------------------------------------------------
+#ifdef ZT_GRU_STAMP
+// diagnostic build only (tools/exp/gru_phases.py): shader-clock readings at the phase boundaries of k_gru_split
+__device__ unsigned long long g_gru[2048 * 10];
+#define GSTAMP(i) do { if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 2048) g_gru[blockIdx.x * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+constexpr int GS_WAVES = 4;
+constexpr int GS_MAXCH = 10;         // chunks of 16 k-columns per wave: (Xp + Hp) / 16 <= 40 (msg <= 512)
+constexpr int GS_STAGE = 37;         // staged elements per thread: 16 (msg + D) <= 37 * 256
+constexpr int GS_TILE_COUNTERS = 512;
+constexpr int GS_MAX_ROWS = GS_TILE_COUNTERS * 16;
+
+__global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, float *last_update, const float *__restrict__ messages,
+                                                             const float *__restrict__ msg_ts, const int *__restrict__ rows,
+                                                             const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp, int lda,
+                                                             const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
+                                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+                                                             const float *__restrict__ Wm_p, float *__restrict__ P, int *tile_cnt,
+                                                             float *hnew)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *A = reinterpret_cast<float *>(smem);                          // [16][lda]: [message (Xp) | memory (Hp)], zero padded
+    float *red = A + 16 * lda;                                           // [4 waves][4 sums][64 lanes][4]
+    int *rid = reinterpret_cast<int *>(red + GS_WAVES * 4 * 64 * 4);     // [16] node ids; [16] = "this workgroup is the tile's last"
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+    GSTAMP(0);
+    const int total = *n_rows;
+    const int r0 = blockIdx.x * 16, nt = blockIdx.y, NT = Hp / 16;
+    if (r0 >= total) return;
+    const int nr = (total - r0) < 16 ? (total - r0) : 16;
+    GSTAMP(1);
+    const int KCx = Xp / 16, KC = KCx + Hp / 16;
+    const int col = 16 * nt + r16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---- this wave's weight fragments: chunks wave, wave + 4, ... of [message | memory] for the three gates ----
+    f32x4 wr[GS_MAXCH], wz[GS_MAXCH], wn[GS_MAXCH];
+#pragma unroll
+    for (int q = 0; q < GS_MAXCH; ++q) {
+        const int c = wave + GS_WAVES * q;
+        const bool on = c < KC, hid = c >= KCx;
+        const float *W = hid ? Whh_p : Wih_p;
+        const int Kp = hid ? Hp : Xp, cc = hid ? c - KCx : c;
+        const size_t o = (size_t)col * Kp + 16 * (on ? cc : 0) + 4 * g4;
+        wr[q] = on ? *reinterpret_cast<const f32x4 *>(W + o) : zero4;
+        wz[q] = on ? *reinterpret_cast<const f32x4 *>(W + (size_t)Hp * Kp + o) : zero4;
+        wn[q] = on ? *reinterpret_cast<const f32x4 *>(W + (size_t)2 * Hp * Kp + o) : zero4;
+    }
+    const bool cin = col < D;
+    const float bir = cin ? b_ih[col] : 0.f, biz = cin ? b_ih[D + col] : 0.f, bin = cin ? b_ih[2 * D + col] : 0.f;
+    const float bhr = cin ? b_hh[col] : 0.f, bhz = cin ? b_hh[D + col] : 0.f, bhn = cin ? b_hh[2 * D + col] : 0.f;
+    if (tid < 16) rid[tid] = tid < nr ? rows[r0 + tid] : 0;
+    for (int f = tid; f < 16 * lda; f += 256) A[f] = 0.f;                // padding columns, rows beyond nr
+    __syncthreads();
+    GSTAMP(2);
+    // ---- stage the tile: every load in flight before the first store ----
+    const int W1 = msg_dim + D;
+    {
+        float v[GS_STAGE];
+#pragma unroll
+        for (int q = 0; q < GS_STAGE; ++q) {
+            const int f = tid + q * 256, g = f / W1, c = f - g * W1;
+            v[q] = g >= nr ? 0.f : (c < msg_dim ? messages[(size_t)rid[g] * msg_dim + c] : memory[(size_t)rid[g] * D + (c - msg_dim)]);
+        }
+#pragma unroll
+        for (int q = 0; q < GS_STAGE; ++q) {
+            const int f = tid + q * 256, g = f / W1, c = f - g * W1;
+            if (g < nr) A[g * lda + (c < msg_dim ? c : Xp + (c - msg_dim))] = v[q];
+        }
+    }
+    __syncthreads();
+    GSTAMP(3);
+    // ---- partial gate sums over this wave's chunks ([message | memory]: chunk c starts at column 16 c of the tile) ----
+    f32x4 ar = zero4, az = zero4, ani = zero4, anh = zero4;
+#pragma unroll
+    for (int q = 0; q < GS_MAXCH; ++q) {
+        const int c = wave + GS_WAVES * q;
+        if (c >= KC) break;
+        const bool hid = c >= KCx;
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(A + r16 * lda + 16 * c + 4 * g4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ar = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wr[q][j], ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wz[q][j], az, 0, 0, 0);
+            if (hid) anh = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wn[q][j], anh, 0, 0, 0);
+            else     ani = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wn[q][j], ani, 0, 0, 0);
+        }
+    }
+    GSTAMP(4);
+    f32x4 *rw = reinterpret_cast<f32x4 *>(red) + (size_t)wave * 4 * 64;
+    rw[0 * 64 + lane] = ar; rw[1 * 64 + lane] = az; rw[2 * 64 + lane] = ani; rw[3 * 64 + lane] = anh;
+    __syncthreads();
+    GSTAMP(5);
+    if (wave == 0) {
+        // gates (torch.nn.GRUCell): r, z = sigmoid(gi + gh); n = tanh(gi_n + r gh_n); h' = (1 - z) n + z h; the four waves'
+        // partial sums are added in wave order
+        const f32x4 *rr = reinterpret_cast<const f32x4 *>(red);
+        f32x4 sr = rr[0 * 64 + lane], sz = rr[1 * 64 + lane], sni = rr[2 * 64 + lane], snh = rr[3 * 64 + lane];
+#pragma unroll
+        for (int wv = 1; wv < GS_WAVES; ++wv) {
+            sr += rr[(wv * 4 + 0) * 64 + lane]; sz += rr[(wv * 4 + 1) * 64 + lane];
+            sni += rr[(wv * 4 + 2) * 64 + lane]; snh += rr[(wv * 4 + 3) * 64 + lane];
+        }
+        if (cin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = 4 * g4 + j;
+                if (g >= nr) continue;
+                const float r = 1.f / (1.f + expf(-(sr[j] + bir + bhr)));
+                const float z = 1.f / (1.f + expf(-(sz[j] + biz + bhz)));
+                const float n = tanhf(sni[j] + bin + r * (snh[j] + bhn));
+                const float hold = A[g * lda + Xp + col];
+                st_agent(reinterpret_cast<int *>(hnew + (size_t)(r0 + g) * Hp + col), __float_as_int((1.f - z) * n + z * hold));
+            }
+        }
+        if (nt == 0 && lane < nr) { const int v = rid[lane]; last_update[v] = msg_ts[v]; }      // memory_updater.py:40
+        // ---- arrive: the tile's last workgroup commits ----
+        __threadfence();
+        int done = 0;
+        if (lane == 0) done = atomicAdd(&tile_cnt[blockIdx.x], 1);
+        done = __builtin_amdgcn_readfirstlane(done);
+        if (lane == 0) { rid[16] = done == NT - 1 ? 1 : 0; if (done == NT - 1) atomicExch(&tile_cnt[blockIdx.x], 0); }
+    }
+    __syncthreads();
+    GSTAMP(6);
+    if (rid[16] == 0) return;
+    // ---- every N-tile of these 16 rows has been computed from the OLD rows: new rows -> memory table, -> projected table ----
+    __threadfence();
+    {
+        constexpr int CU = 7;                                            // 16 x Hp <= 7 * 256
+        float v[CU];
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const int f = tid + q * 256, g = f / Hp, c = f - g * Hp;
+            v[q] = (g < nr && c < D) ? __int_as_float(ld_agent(reinterpret_cast<const int *>(hnew + (size_t)(r0 + g) * Hp + c))) : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < CU; ++q) {
+            const int f = tid + q * 256, g = f / Hp, c = f - g * Hp;
+            if (g < 16 && c < Hp) A[g * lda + Xp + c] = v[q];
+            if (g < nr && c < D) memory[(size_t)rid[g] * D + c] = v[q];
+        }
+    }
+    GSTAMP(7);
+    if (P == nullptr) return;
+    __syncthreads();
+    for (int b = wave; b < NT; b += GS_WAVES) {
+        const int KCh = Hp / 16;                                         // <= 8
+        f32x4 wv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            wv[c] = c < KCh ? *reinterpret_cast<const f32x4 *>(Wm_p + (size_t)(16 * b + r16) * Hp + 16 * c + 4 * g4) : zero4;
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c >= KCh) break;
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(A + r16 * lda + Xp + 16 * c + 4 * g4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[c][j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = 4 * g4 + j;
+            if (g < nr) P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
+        }
+    }
+}
+
 struct GruPlan {
     int Xp, Hp, lda;
-    size_t lds, off_rows, off_cnt, off_wih, off_whh, total;
+    size_t lds, off_rows, off_cnt, off_wih, off_whh, off_tiles, off_hnew, total;
 };
 
 void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
@@ -309,7 +490,9 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.off_cnt = take(256);
     p.off_wih = take((size_t)3 * p.Hp * p.Xp * 4);
     p.off_whh = take((size_t)3 * p.Hp * p.Hp * 4);
+    p.off_tiles = take((size_t)GS_TILE_COUNTERS * 4);                    // k_gru_split: arrival counters per tile (zeroed with the weights)
     p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
+    p.off_hnew = take(max_rows > 0 && max_rows <= GS_MAX_ROWS ? (size_t)((max_rows + 15) / 16 * 16) * p.Hp * 4 : 0);   // k_gru_split: new rows until the commit
     p.total = o;
 }
 
@@ -501,6 +684,25 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     if (!weights_ready) {                       // gate-packed, padded copies: once per weight change
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
+        ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GS_TILE_COUNTERS * 4, s));
+    }
+    // few rows: a workgroup per (tile, N-tile) -- the whole chip works on what k_gru gives to a tenth of it; many rows: k_gru
+    // (several workgroups per CU, a row tile's weights fetched once).  ZT_GRU_SPLIT_MAX_ROWS moves the switch (tuning knob).
+    static const long long split_max = getenv("ZT_GRU_SPLIT_MAX_ROWS") ? atoll(getenv("ZT_GRU_SPLIT_MAX_ROWS")) : 512;
+    if (max_rows <= split_max && max_rows <= GS_MAX_ROWS && (p.Xp + p.Hp) / 16 <= GS_WAVES * GS_MAXCH &&
+        16 * (msg_dim + D) <= GS_STAGE * 256 && 16 * p.Hp <= 7 * 256) {
+        const size_t lds2 = ((size_t)16 * p.lda + (size_t)GS_WAVES * 4 * 64 * 4) * 4 + 32 * 4;
+        static size_t attr2 = 0;
+        if (lds2 > 48 * 1024 && lds2 > attr2) {
+            ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            attr2 = lds2;
+        }
+        k_gru_split<<<dim3((unsigned)((max_rows + 15) / 16), (unsigned)(p.Hp / 16)), 64 * GS_WAVES, lds2, s>>>(
+            memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih,
+            wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew));
+        ZT_PROF_END(s, P_GRU);
+        ZT_LAUNCH_CHECK();
+        return ZT_OK;
     }
     static size_t attr_lds = 0;
     if (p.lds > 48 * 1024 && p.lds > attr_lds) {
@@ -515,6 +717,15 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }
+
+#ifdef ZT_GRU_STAMP
+extern "C" int zt_debug_gru(unsigned long long *host)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gru), sizeof(unsigned long long) * 2048 * 10));
+    return ZT_OK;
+}
+#endif
 
 extern "C" int zt_pack_rows(const zt_row_tables *tables, const int32_t *ids_dev, const int32_t *n_valid_dev, int64_t cap,
                             float *out_dev, void *stream)
