@@ -42,6 +42,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
 #endif
     int wl_fail = 0;
     CRIT(4);
+    STAMP3(0);
     // a reader of the hub's row in memory that precedes this edge must have read it before this hop may store there
     // ---- the partner's row from memory (poll where a writer of this launch precedes us) ----
     Row rp;
@@ -117,6 +118,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     // s_waitcnt vmcnt(0) here: it would also wait for the write-through stores of this wave's previous hop.)
     st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
     CRIT(5);
+    STAMP3(1);
 #ifdef ZT_CRIT
     crit_t[9] = !pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : (!pre_b.ok ? 9 : 0));     // why the partner's side is not prepared
     crit_t[13] = (long long)ld_agent(h.ctl + 1) * 100000 + i;    // head of the general queue (task index) when this hop was ready, and its edge
@@ -145,6 +147,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge, true)) wl_fail |= 16;
     __builtin_amdgcn_s_setprio(3);
     CRIT(0);
+    STAMP3(2);
     Row rh;
     unsigned hub_unc = 0u;
     int hub_munc = 0, hub_nalt = 0, hub_sorted = 0;
@@ -299,6 +302,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
             if (lane == 0) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0 && fin) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             CRIT(3);
+            STAMP3(8);
             __builtin_amdgcn_s_setprio(0);                       // the rest of this hop is off the chain
             // ---- what the tail needs ----
             if (table && lane < lenp) L.htab[pre_b.h2] = -1;     // the table is clean again
@@ -453,6 +457,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
         CRIT(2);
         publish_seq(true, final_out);                            // the successor can start
         CRIT(3);
+        STAMP3(8);
         __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
     }
     }   // (!lean_done)
@@ -489,6 +494,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     if (next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
     if (lane == 0)                                               // both stages of the incoming slot have been read
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    STAMP3(3);
 #ifdef ZT_CRIT
     if (lean_done) { CRIT(6); crit_t[7] = 1; }
     if (lane == 0 && mo == 0) atomicAdd((unsigned long long *)&g_crit[8199 * 16 + (lean_done ? 0 : (pre_b.ok ? 6 : (!pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : 9))))], 1ull);
@@ -531,6 +537,7 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
     const long long pnode = hub_is_u ? v : u;          // == hub for a self-loop
     const int wo_p = hub_is_u ? wo_v : wo_u;
     Row rh, rp, rg;
+    STAMP3(4);
     // ---- rows: the partner's and the negative sample's from memory, the hub's old one from its version slot ----
     const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u, gtag = wo_g ? (tag_base | (unsigned)wo_g) : 0u;
     const bool g_own = n_roles == 3 && g != u && g != v;
@@ -541,6 +548,7 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
     if (g_own) sg = load_row(h, m, g, lane, gtag, rg);
     if (pnode != hub && ptag && sp != ptag) (void)load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2);
     if (g_own && gtag && sg != gtag) (void)load_row_wait(h, m, g, lane, gtag, rg, h.ctl + 2);
+    STAMP3(5);
     {
         unsigned polls = 0;
         long long t0 = 0;
@@ -558,6 +566,7 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
     // ---- all reads done: later writers of these rows may go ahead ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st_agent(done + i, epoch);
+    STAMP3(6);
     if (pnode != hub) {
         // (edge_idx, hub, ts) is the key entering the partner's dictionary
         const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)hub;
@@ -566,6 +575,7 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
         const double new_norm = rp.norm * beta + beta;
         (void)wait_flag(cdone + i, epoch, h.ctl + 2, -i - 2);      // the chain has read the partner's old row
         store_row_scatter(h, m, pnode, lane, n, cc, new_norm, tag_base | (unsigned)(wo_p + 1));
+        STAMP3(7);
     } else {
         rp = rh;
     }

@@ -39,8 +39,13 @@ __device__ long long g_stamps[8192 * 4];
 __device__ long long g_stamps2[8192 * 8];
 #define STAMP2(slot) do { if (lane_id() == 0 && g_stamp_i >= 0 && g_stamp_i < 8192) g_stamps2[g_stamp_i * 8 + (slot)] = (long long)wall_clock64(); } while (0)   // diagnostic build only: per task t_deq, t_rows, t_x1, t_end (100 MHz ticks)
 #define STAMP(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps[i * 4 + (slot)] = (long long)wall_clock64(); } while (0)
+// chain-owned edges: slots 0-3 the hub hop (entered, partner's row in hand, turn arrived, end), 4-7 the partner half
+// (entered, partner's and negative's rows in hand, hub's version in hand, partner's row stored), 8 the hop's publication
+__device__ long long g_stamps3[8192 * 12];
+#define STAMP3(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps3[i * 12 + (slot)] = (long long)wall_clock64(); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP3(slot) do { } while (0)
 #define STAMP2(slot) do { } while (0)
 #endif
 

@@ -447,6 +447,12 @@ extern "C" int zt_debug_paths(int *host)
     ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_paths), sizeof(int) * 8));
     return ZT_OK;
 }
+extern "C" int zt_debug_stamps3(long long *host, int n)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps3), sizeof(long long) * n * 12));
+    return ZT_OK;
+}
 extern "C" int zt_debug_stamps2(long long *host, int n)
 {
     ZT_HIP(hipDeviceSynchronize());
