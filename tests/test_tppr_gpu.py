@@ -607,3 +607,70 @@ def test_randomised_prune_soak(zt, oracle):
     for seed in range(5000, 5200):
         err = soak_prune.one(seed, zt, oracle, torch)
         assert err is None, err
+
+
+@pytest.mark.parametrize("name,batch", [("bip_k20", 0), ("bip_k20", 4), ("hub_ties", 0), ("gen_k40", 1)])
+def test_dependency_plan_matches_restatement(zt, name, batch):
+    """The prepass of a launch (csrc/tppr_prepass.hip; the order utils/util.py:495-574 applies a batch's edges in, made
+    explicit) against a numpy restatement, through the test hook zt_test_tppr_plan_dump: writer ordinals, chain positions
+    (= the hub's ordinal; an edge between two hubs in both chains), owners, and which accesses read a row by version."""
+    import ctypes as C
+    import torch
+    from zebra_amd import _capi
+    kind, N, E, seed, bs, k, al, be, _ = I.STREAM_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream(kind, N, E, seed)
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    s0, s1 = batch * bs, min(E, (batch + 1) * bs)
+    B = s1 - s0
+    nodes = np.concatenate([src[s0:s1], dst[s0:s1], neg[s0:s1]]).astype(np.int32)
+    nd = torch.from_numpy(nodes).cuda()
+    ed = torch.from_numpy(eidx[s0:s1].astype(np.int64)).cuda()
+    tok = f.plan_device(nd, ed, 3, -1)
+    assert tok != 0
+    wo = np.zeros(3 * B, np.int32); pf = np.zeros_like(wo); hv = np.zeros_like(wo); own = np.zeros(B, np.int32)
+    cn = np.zeros(16, np.int32); cl = np.zeros(16, np.int32); ce = np.zeros((16, 2048), np.int32); nc = np.zeros(1, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    _capi.check(_capi.hooks_lib().zt_test_tppr_plan_dump(f._live.h, P(wo), P(pf), P(hv), P(own), P(cn), P(cl), P(ce), P(nc)))
+    n_ch = int(nc[0])
+    u, v, g = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
+    shadow = lambda r, i: (r >= 1 and nodes[r * B + i] == u[i]) or (r == 2 and g[i] == v[i])
+    cnt, wr, last = {}, {}, {}
+    wo_ref = np.zeros(3 * B, np.int32); pf_ref = np.full(3 * B, -1, np.int32)
+    for i in range(B):
+        for r in range(3):
+            x = int(nodes[r * B + i])
+            if shadow(r, i):
+                continue
+            cnt[x] = cnt.get(x, 0) + 1
+            wo_ref[r * B + i] = wr.get(x, 0)
+            if x in last and last[x][1] == 2:
+                pf_ref[r * B + i] = last[x][0]
+        for r in range(3):                                      # (an edge's accesses see the edges before it only)
+            if not shadow(r, i):
+                x = int(nodes[r * B + i])
+                if r < 2:
+                    wr[x] = wr.get(x, 0) + 1
+        for r in (2, 1, 0):                                     # the node's latest access: a writer role wins over the reader's
+            if not shadow(r, i):
+                last[int(nodes[r * B + i])] = (i, r)
+    assert np.array_equal(wo, wo_ref) and np.array_equal(pf, pf_ref)
+    hot = sorted([x for x in cnt if cnt[x] >= 24], key=lambda x: (-cnt[x], x))
+    assert n_ch <= len(hot) and list(cn[:n_ch]) == hot[:n_ch] and (n_ch > 0 or name != "bip_k20")
+    chain_of = {int(cn[c]): c for c in range(n_ch)}
+    for c in range(n_ch):
+        edges = [i for i in range(B) if u[i] == cn[c] or v[i] == cn[c]]
+        assert cl[c] == len(edges) and list(ce[c, :cl[c]]) == edges, "chain %d" % c
+    hv_ref = np.full(3 * B, -1, np.int32); own_ref = np.full(B, -1, np.int32)
+    for i in range(B):
+        for r in range(3):
+            x = int(nodes[r * B + i])
+            if not shadow(r, i) and x in chain_of and cl[chain_of[x]] > 0:
+                hv_ref[r * B + i] = chain_of[x]
+        a, b = int(u[i]), int(v[i])
+        ia, ib = a in chain_of, (b in chain_of and b != a)
+        if ia and (not ib or cnt[a] >= cnt[b]):
+            own_ref[i] = chain_of[a]
+        elif ib:
+            own_ref[i] = chain_of[b]
+    assert np.array_equal(hv, hv_ref) and np.array_equal(own, own_ref)
+    f.stream_device(nd, torch.from_numpy(ts[s0:s1].astype(np.float64)).cuda(), ed, 3, True, -1, plan_token=tok)

@@ -23,6 +23,10 @@ int zt_test_topk(const double *vals_dev, int32_t n, int32_t k, int32_t cases,
 /* Test hook: set the T-PPR handle's launch epoch (the row tags' high bits), to
  * exercise the wrap-around (all tags are cleared when it reaches 2^18 - 1). */
 int zt_test_set_epoch(zt_tppr *h, uint32_t epoch);
+/* Test hook: the dependency plan zt_tppr_plan made last, copied to host arrays -- wo / pflag / hv [n_roles * B] (B = the
+ * planned launch's edges), owner_of [B], chain_node / chain_len [16], chain_edges [16][2048], *n_chains. */
+int zt_test_tppr_plan_dump(zt_tppr *h, int32_t *wo, int32_t *pflag, int32_t *hv, int32_t *owner_of, int32_t *chain_node,
+                           int32_t *chain_len, int32_t *chain_edges, int32_t *n_chains);
 
 #ifdef __cplusplus
 }

@@ -93,3 +93,24 @@ extern "C" int zt_test_set_epoch(zt_tppr *h, uint32_t epoch)
     h->epoch = epoch > EPOCH_MAX ? EPOCH_MAX : epoch;
     return ZT_OK;
 }
+
+// the dependency plan zt_tppr_plan made last (tppr_prepass.hip), copied to host arrays: wo / pflag / hv [3 * B] (B = the
+// planned launch's edges), owner_of [B], chain_node / chain_len [16], chain_edges [16][2048]; *n_chains = the chains picked
+extern "C" int zt_test_tppr_plan_dump(zt_tppr *h, int32_t *wo, int32_t *pflag, int32_t *hv, int32_t *owner_of,
+                                      int32_t *chain_node, int32_t *chain_len, int32_t *chain_edges, int32_t *n_chains)
+{
+    if (!h) return ZT_ERR_ARG;
+    const zt_tppr::PlanSet &P = h->set[h->next_set ^ 1];
+    if (!P.valid) return ZT_ERR_ARG;
+    ZT_HIP(hipDeviceSynchronize());
+    const size_t a = (size_t)P.B * P.n_roles * sizeof(int);
+    ZT_HIP(hipMemcpy(wo, P.wo, a, hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(pflag, P.pflag, a, hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(hv, P.hv, a, hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(owner_of, P.owner_of, (size_t)P.B * sizeof(int), hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(chain_node, P.chain_node, MAX_CHAINS * sizeof(int), hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(chain_len, P.chain_len, MAX_CHAINS * sizeof(int), hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(chain_edges, P.chain_edges, (size_t)MAX_CHAINS * CH_MAX * sizeof(int), hipMemcpyDeviceToHost));
+    ZT_HIP(hipMemcpy(n_chains, P.ctl + 4, sizeof(int), hipMemcpyDeviceToHost));
+    return ZT_OK;
+}

@@ -17,10 +17,9 @@ namespace {
 // flags) at the start of every hop's preparation.
 struct HopRec {
     int partner;       // the other endpoint (-1: self-loop)
-    int wo_h, wo_p;    // ordinal of the last earlier writer of the hub / of the partner (the tags to expect)
-    int pf_h;          // a reader of the hub's row that must be done before this hop may store it (-1: none)
-    int wo_prev;       // the same ordinal at the chain's previous edge
-    int wo_next, pf_next;   // ... and at its next edge (-1: there is none)
+    int wo_p;          // ordinal of the last earlier writer of the partner (the tag to expect; the hub's own is the position)
+    int pchain;        // the partner is a hub itself and this edge a position of ITS chain too: that chain's index -- its
+                       // row is version wo_p there and that chain applies its update --, else -1
 };
 
 __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
@@ -32,10 +31,8 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     const int m = A.m_lo + mo;
     if (rec.partner < 0) return false;
     const long long pnode = rec.partner;
-    const int wo_h = rec.wo_h, wo_p = rec.wo_p;
-    if (rec.wo_prev + 1 != wo_h) return false;                                // somebody else wrote the hub in between
+    const int wo_h = tpos, wo_p = rec.wo_p;                                  // (chain position = the hub's writer ordinal)
     const double alpha = h.alpha[m], beta = h.beta[m];
-    unsigned *done = h.done + (long long)m * MAX_CHUNK;
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS, vtag = tag_base | 1u;
 #ifdef ZT_CRIT
     long long crit_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -43,21 +40,15 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     int wl_fail = 0;
     CRIT(4);
     STAMP3(0);
-    // a reader of the hub's row in memory that precedes this edge must have read it before this hop may store there
-    // ---- the partner's row from memory (poll where a writer of this launch precedes us) ----
+    // ---- the partner's row: from `rows` (poll where a writer of this launch precedes us), or -- the partner is a hub and
+    // ---- its chain holds this edge too -- the version of its row at that chain's position ----
     Row rp;
-    const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u;
+    const RowSrc psrc = row_src(h, m, pnode, wo_p, rec.pchain, tag_base, vtag);
     RawRow praw;
-    load_row_issue(h.rows + ((long long)m * h.N + pnode) * h.rg, k, lane, praw);     // on its way while the rest is looked up
+    load_row_issue(psrc.base, k, lane, praw);                               // on its way while the rest is looked up
     const double tnow = A.tsv[i];
     const long long e = A.eidx[i];
-    const int pf_h = rec.pf_h;
-    if (pf_h >= 0 && !wait_flag(done + pf_h, epoch, h.ctl + 2, pf_h)) wl_fail |= 1;
-    bool hub_to_memory = true, next_by_mail = false;                        // see process_edge
-    if (next_edge >= 0) {
-        next_by_mail = rec.wo_next == wo_h + 1;
-        hub_to_memory = !(next_by_mail && rec.pf_next < 0);
-    }
+    const bool hub_to_memory = next_edge < 0;                               // see process_edge: the chain's last hop only
     MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
     // (the two float64 divisions of the scale factors: while the partner's row is on its way)
     PreScale pre_scale;
@@ -90,8 +81,8 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
         }
     };
     if (psteps >= 0) set_scale();
-    if (row_from_raw(praw, k, lane, ptag, rp) != ptag)
-        if (!load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2)) wl_fail |= 2;
+    if (row_from_raw(praw, k, lane, psrc.expect, rp) != psrc.expect && psrc.polled)
+        if (!load_row_wait_at(psrc.base, k, lane, psrc.expect, rp, h.ctl + 2, (int)pnode, psrc.aux(m), psrc.version)) wl_fail |= 2;
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
     int pre_hash = 0;                           // 1 / 3: partner entered into this wave's hash table (slot function 1 / 2),
     int h2slot = 0;                             // 2: its keys collide under both
@@ -490,8 +481,9 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     }
     c.slot = trueslot;
     if (hub_to_memory) store_row_scatter(h, m, hub, lane, n_new, c, new_norm, tag_base | (unsigned)(wo_h + 1));
-    // the new row in dictionary order is the NEXT position's version: its partner task reads it there
-    if (next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
+    // the new row in dictionary order is the NEXT position's version: that edge's partner task, the hub's readers and
+    // the chains of other hubs read it there
+    store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
     if (lane == 0)                                               // both stages of the incoming slot have been read
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     STAMP3(3);
@@ -523,12 +515,12 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
     const unsigned *cdone = h.cdone + (long long)m * MAX_CHUNK;
     const unsigned epoch = A.epoch, tag_base = epoch << ORD_BITS, vtag = tag_base | 1u;
     const long long role_stride = A.role_stride;
-    const int c = h.owner_of[i], t = h.pos_of[i];
+    const int c = h.owner_of[i];
     const long long hub = h.chain_node[c];
-    int my_wo = 0, my_pf = -1;
-    if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; }
-    if (my_pf >= 0) (void)wait_flag(done + my_pf, epoch, h.ctl + 2, my_pf);      // a reader before me has not read yet
+    int my_wo = 0, my_pf = -1, my_hv = -1;
+    if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_hv = h.hv[lane * B + i]; }
     const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
+    const int hv_u = __shfl(my_hv, 0), hv_v = __shfl(my_hv, 1), hv_g = __shfl(my_hv, 2);
     const long long u = A.nodes[i], v = A.nodes[role_stride + i];
     const long long g = n_roles == 3 ? A.nodes[2 * role_stride + i] : u;
     const double tnow = A.tsv[i];
@@ -536,38 +528,39 @@ __device__ __attribute__((always_inline)) inline void process_chain_partner(cons
     const bool hub_is_u = u == hub;
     const long long pnode = hub_is_u ? v : u;          // == hub for a self-loop
     const int wo_p = hub_is_u ? wo_v : wo_u;
+    const int t = hub_is_u ? wo_u : wo_v;              // the edge's position in the owner's chain = the hub's writer ordinal
+    // the partner is a hub whose chain holds this edge too: that chain applies the partner's update, its old row is a version
+    const int pchain = pnode != hub ? (hub_is_u ? hv_v : hv_u) : -1;
+    // A reader of the partner's row that precedes this edge has not read yet (this task stores that row).  The negative
+    // sample's row likewise: a writer waits for the LAST reader before it only, so every reader waits for the reader
+    // before it.  (Not for rows held by version: those are never overwritten.)
+    {
+        const int pf_p = __shfl(my_pf, hub_is_u ? 1 : 0), pf_g = __shfl(my_pf, 2);
+        if (pnode != hub && pchain < 0 && pf_p >= 0) (void)wait_flag(done + pf_p, epoch, h.ctl + 2, pf_p);
+        if (n_roles == 3 && hv_g < 0 && pf_g >= 0) (void)wait_flag(done + pf_g, epoch, h.ctl + 2, pf_g);
+    }
     Row rh, rp, rg;
     STAMP3(4);
-    // ---- rows: the partner's and the negative sample's from memory, the hub's old one from its version slot ----
-    const unsigned ptag = wo_p ? (tag_base | (unsigned)wo_p) : 0u, gtag = wo_g ? (tag_base | (unsigned)wo_g) : 0u;
+    // ---- rows: the partner's and the negative sample's from `rows` (or, hubs, from their chains' versions), the hub's
+    // ---- old one from its version slot ----
+    const RowSrc psrc = row_src(h, m, pnode, wo_p, pchain, tag_base, vtag), gsrc = row_src(h, m, g, wo_g, hv_g, tag_base, vtag);
     const bool g_own = n_roles == 3 && g != u && g != v;
     unsigned sp = 0, sg = 0;
     const u64 *ver = hub_version(h, m, c, t);
     unsigned sh = load_row_at(ver, k, lane, vtag, rh);
-    if (pnode != hub) sp = load_row(h, m, pnode, lane, ptag, rp);
-    if (g_own) sg = load_row(h, m, g, lane, gtag, rg);
-    if (pnode != hub && ptag && sp != ptag) (void)load_row_wait(h, m, pnode, lane, ptag, rp, h.ctl + 2);
-    if (g_own && gtag && sg != gtag) (void)load_row_wait(h, m, g, lane, gtag, rg, h.ctl + 2);
+    if (pnode != hub) sp = load_row_at(psrc.base, k, lane, psrc.expect, rp);
+    if (g_own) sg = load_row_at(gsrc.base, k, lane, gsrc.expect, rg);
+    if (pnode != hub && sp != psrc.expect) (void)load_row_wait_at(psrc.base, k, lane, psrc.expect, rp, h.ctl + 2, (int)pnode, psrc.aux(m), psrc.version);
+    if (g_own && sg != gsrc.expect) (void)load_row_wait_at(gsrc.base, k, lane, gsrc.expect, rg, h.ctl + 2, (int)g, gsrc.aux(m), gsrc.version);
     STAMP3(5);
-    {
-        unsigned polls = 0;
-        long long t0 = 0;
-        while (sh != vtag) {                           // the chain has not reached this position yet
-            __builtin_amdgcn_s_sleep(32);
-            sh = load_row_at(ver, k, lane, vtag, rh);
-            if ((++polls & 255u) == 0) {
-                const long long now = (long long)wall_clock64();
-                if (t0 == 0) t0 = now;
-                else if (now - t0 > WAIT_TICKS) { note_timeout(h.ctl + 2, 4, i, (int)vtag, (int)sh, t); break; }
-                if (launch_failed(h.ctl + 2)) break;
-            }
-        }
-    }
+    if (sh != vtag) (void)load_row_wait_at(ver, k, lane, vtag, rh, h.ctl + 2, (int)hub, m | (t << 4), true);      // the chain has not reached this position yet
     // ---- all reads done: later writers of these rows may go ahead ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st_agent(done + i, epoch);
     STAMP3(6);
-    if (pnode != hub) {
+    if (pnode != hub && pchain >= 0) {
+        // (the partner's chain applies its update; its old row is only emitted here)
+    } else if (pnode != hub) {
         // (edge_idx, hub, ts) is the key entering the partner's dictionary
         const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)hub;
         Cand cc;

@@ -145,6 +145,25 @@ __device__ __forceinline__ u64 *hub_version(const zt_tppr &h, int m, int c, int 
     return h.hubver + (((size_t)m * MAX_CHAINS + c) * (CH_MAX + 1) + t) * h.rg;
 }
 
+// Where an access finds its row: in `rows` under the tag of the node's last earlier writer of the launch, or -- a hub's row
+// for everybody but the hub's own chain -- in the chain's versions, slot = that writer ordinal, under the launch's version tag.
+struct RowSrc {
+    const u64 *base;
+    unsigned expect;
+    bool version;
+    bool polled;       // the row must carry `expect` (a row nobody of this launch has written is taken as it is)
+    int slot;          // (for a time-out report) the version slot
+    __device__ __forceinline__ int aux(int m) const { return version ? (m | (slot << 4)) : m; }
+};
+__device__ __forceinline__ RowSrc row_src(const zt_tppr &h, int m, long long x, int wo, int hv, unsigned tag_base, unsigned vtag)
+{
+    RowSrc s;
+    s.slot = wo;
+    if (hv >= 0) { s.base = hub_version(h, m, hv, wo); s.expect = vtag; s.version = true; s.polled = true; }
+    else { s.base = h.rows + ((long long)m * h.N + x) * h.rg; s.expect = wo ? (tag_base | (unsigned)wo) : 0u; s.version = false; s.polled = wo != 0; }
+    return s;
+}
+
 // (always_inline: with a third call site in k_stream the inliner once left this a real call -- rows in scratch memory, the
 //  kernel 17x slower: round 4)
 __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr &h, const StreamArgs &A, WaveLds &L, int lane, int i, int mo, Mail *mail,
@@ -167,12 +186,18 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
     unsigned wl_seen = 0;
 
     // ---- dependencies of this edge's three accesses ----
-    int my_wo = 0, my_pf = -1, my_nx = 0;
-    if (lane < n_roles) { my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i]; }
-    if (my_pf >= 0 && !wait_flag(done + my_pf, epoch, h.ctl + 2, my_pf)) wl_fail |= 1;   // a reader before me has not read yet
+    int my_wo = 0, my_pf = -1, my_nx = 0, my_hv = -1;
+    if (lane < n_roles) {
+        my_wo = h.wo[lane * B + i]; my_pf = h.pflag[lane * B + i]; my_nx = h.nxt[lane * B + i];
+        if (A.use_chains) my_hv = h.hv[lane * B + i];
+    }
+    // a reader before me has not read yet.  (Not a chain wave's concern: it stores the hub's row to `rows` once, after the
+    // chain's last hop -- nobody else reads that row there in this launch -- and the partner's row not at all.)
+    if (mail == nullptr && my_pf >= 0 && !wait_flag(done + my_pf, epoch, h.ctl + 2, my_pf)) wl_fail |= 1;
     wl_fail = __ballot(wl_fail != 0) != 0ull ? 1 : 0;
     WL(0, 2);
     const int wo_u = __shfl(my_wo, 0), wo_v = __shfl(my_wo, 1), wo_g = __shfl(my_wo, 2);
+    const int hv_u = __shfl(my_hv, 0), hv_v = __shfl(my_hv, 1), hv_g = __shfl(my_hv, 2);
     // the endpoint with the longer chain still waiting behind it is merged and published first
     const bool v_first = __shfl(my_nx, 1) > __shfl(my_nx, 0);
 
@@ -191,43 +216,36 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
         hub_by_mail = prev_out == mine;
     }
 
-    // Must the hub's new row also go to memory?  Not when the chain's next edge takes it from the
-    // mailbox and nobody reads it in between (no reader precedes that edge's access): the next edge's
-    // own row supersedes it.  This is a correctness rule, not only a saving: the mailbox hand-off is
-    // NOT ordered against this wave's row stores, so a successor could otherwise get its (newer) row
-    // into memory before ours and ours would then overwrite it.  Whenever the row IS stored, its next
-    // accessor waits for it in memory (directly, or through a reader's reads-done flag).
-    bool hub_to_memory = true;
-    // next_by_mail: the chain's next edge takes this hop's new row (nobody else writes the hub in between): that row is
-    // then also the next position's VERSION (hub_version), which its partner task reads; otherwise the next hop stores
-    // its version itself, from the row it finds in memory
-    bool next_by_mail = false;
-    if (mail != nullptr && next_edge >= 0) {
-        const int nrole = A.nodes[next_edge] == hub ? 0 : 1;
-        const int my_out = ((u == hub) ? wo_u : wo_v) + 1;
-        next_by_mail = h.wo[nrole * B + next_edge] == my_out;
-        hub_to_memory = !(next_by_mail && h.pflag[nrole * B + next_edge] < 0);
-    }
+    // Must the hub's new row also go to `rows`?  Only from the chain's LAST hop: every hop's new row goes to the next
+    // position's version slot, where everybody else reads it.  This is a correctness rule, not only a saving: the mailbox
+    // hand-off is NOT ordered against this wave's row stores, so a successor could otherwise get its (newer) row into
+    // `rows` before ours and ours would then overwrite it.
+    const bool hub_to_memory = mail == nullptr || next_edge < 0;
 
     // ---- rows: one memory round trip; poll where a writer of this launch precedes us ----
     Row ru, rv, rg;
     const bool u_mail = hub_by_mail && u == hub, v_mail = hub_by_mail && v == hub && v != u;
     unsigned su = 0, sv = 0, sg = 0;
-    if (!u_mail) su = load_row(h, m, u, lane, wo_u ? (tag_base | (unsigned)wo_u) : 0u, ru);
-    if (v != u && !v_mail) sv = load_row(h, m, v, lane, wo_v ? (tag_base | (unsigned)wo_v) : 0u, rv);
+    // (a chain wave reads its own hub's row from `rows` -- the chain's first hop -- and another hub's by version; a general
+    //  task has no in-chain hub as an endpoint, its negative sample may be one)
+    const RowSrc src_u = row_src(h, m, u, wo_u, (mail != nullptr && u != hub) ? hv_u : -1, tag_base, vtag);
+    const RowSrc src_v = row_src(h, m, v, wo_v, (mail != nullptr && v != hub) ? hv_v : -1, tag_base, vtag);
+    const RowSrc src_g = row_src(h, m, g, wo_g, hv_g, tag_base, vtag);
+    if (!u_mail) su = load_row_at(src_u.base, k, lane, src_u.expect, ru);
+    if (v != u && !v_mail) sv = load_row_at(src_v.base, k, lane, src_v.expect, rv);
     // (a chain wave applies the HUB's update only: the partner's update and the emission of this edge's rows are a
     //  general task of their own, process_chain_partner -- the negative sample's row is not needed here)
     const bool g_own = mail == nullptr && n_roles == 3 && g != u && g != v;
-    if (g_own) sg = load_row(h, m, g, lane, wo_g ? (tag_base | (unsigned)wo_g) : 0u, rg);
+    if (g_own) sg = load_row_at(src_g.base, k, lane, src_g.expect, rg);
     WL(0, 3);
-    if (!u_mail && wo_u && su != (tag_base | (unsigned)wo_u))
-        if (!load_row_wait(h, m, u, lane, tag_base | (unsigned)wo_u, ru, h.ctl + 2, &wl_seen)) wl_fail |= 2;
+    if (!u_mail && src_u.polled && su != src_u.expect)
+        if (!load_row_wait_at(src_u.base, k, lane, src_u.expect, ru, h.ctl + 2, (int)u, src_u.aux(m), src_u.version, &wl_seen)) wl_fail |= 2;
     WL(0, 4);
-    if (v != u && !v_mail && wo_v && sv != (tag_base | (unsigned)wo_v))
-        if (!load_row_wait(h, m, v, lane, tag_base | (unsigned)wo_v, rv, h.ctl + 2, &wl_seen)) wl_fail |= 4;
+    if (v != u && !v_mail && src_v.polled && sv != src_v.expect)
+        if (!load_row_wait_at(src_v.base, k, lane, src_v.expect, rv, h.ctl + 2, (int)v, src_v.aux(m), src_v.version, &wl_seen)) wl_fail |= 4;
     WL(0, 5);
-    if (g_own && wo_g && sg != (tag_base | (unsigned)wo_g))
-        if (!load_row_wait(h, m, g, lane, tag_base | (unsigned)wo_g, rg, h.ctl + 2, &wl_seen)) wl_fail |= 8;
+    if (g_own && src_g.polled && sg != src_g.expect)
+        if (!load_row_wait_at(src_g.base, k, lane, src_g.expect, rg, h.ctl + 2, (int)g, src_g.aux(m), src_g.version, &wl_seen)) wl_fail |= 8;
     int pre_hash = 0;                           // 1: partner entered into this wave's hash table, 2: with a clash
     const bool sw = v_first && u != v;          // v's new row is computed and published first
     MailSlot *in_slot = hub_by_mail ? &mail->slot[(tpos - 1) % MAIL_R] : nullptr;
@@ -417,17 +435,14 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
                 __builtin_amdgcn_s_setprio(0);
             }
             if (hub_to_memory || xa != hub) store_row_scatter(h, m, xa, lane, n, c, new_norm, tag_base | (unsigned)(oa + 1));
-            if (mail != nullptr && xa == hub && next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n, c, new_norm, vtag);
+            if (mail != nullptr && xa == hub) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n, c, new_norm, vtag);
         };
         if (!split && mail != nullptr) {
             // a chain wave whose hub row did not come through the mailbox in set order (first hop, self-loop, the partner is
-            // the busier node): the hub's update in one piece; the old row is this position's version if nobody stored it
+            // the busier node): the hub's update in one piece (version 0, the row the chain's first hop finds in `rows`, was
+            // stored when the workgroup started: k_stream)
             if (x1 == hub) update(r1, r2, x1, x2, o1, pre_hash, mo == 0 ? i : -1);
             else update(r2, r1, x2, x1, o2, 0, -1);
-            if (!hub_by_mail) {
-                const Row &ro = hub_is_u ? ru : rv;
-                store_row_at(hub_version(h, m, chain_idx, tpos), k, lane, ro.len, ro.key, ro.ts, ro.w, ro.norm, vtag);
-            }
             STAMP(2);
             WL(0, 8);
         } else if (!split) {
@@ -579,7 +594,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
             c.slot = trueslot;
             if (hub_to_memory) store_row_scatter(h, m, x1, lane, n_new, c, new_norm, tag_base | (unsigned)(o1 + 1));
             // the new row in dictionary order is the NEXT position's version: its partner task reads it there
-            if (next_by_mail) store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
+            store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
             release_in();
         }
     }

@@ -97,50 +97,58 @@ __global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, 
     d_hot_select(threadIdx.x, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
 }
 
-// K2c: every edge with a hub endpoint is owned by that hub's chain (the more-touched hub if both are).
+// K2c: every edge with a hub endpoint enters that hub's chain at position = the hub's writer ordinal there (all earlier
+// writers of a hub are its chain's edges, so the ordinal IS the position: no sort).  An edge between two hubs enters both
+// chains -- each chain applies its own hub's update and takes the other hub's row from the other chain's versions; the
+// chain of the more-touched hub is the edge's OWNER: its partner task in the general queue emits the edge's rows.
+// A chain holds CH_MAX edges; a hub's later edges go through the general queue and the row in `rows`.
 __device__ __forceinline__ void d_own(int i, const int *__restrict__ nodes, long long role_stride, int B, const int *cnt,
-                                      const int *slot, const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+                                      const int *slot, const int *wo, const int *chain_of, int *chain_len, int *chain_edges,
+                                      int *owner_of)
 {
     if (i >= B) return;
     int owner = -1;
     if (slot[i] >= 0 && slot[B + i] != -1) {        // valid edge
         const int u = nodes[i], v = nodes[role_stride + i];
-        const int cu = chain_of[u], cv = chain_of[v];
-        if (cu >= 0 && (cv < 0 || cnt[u] >= cnt[v])) owner = cu;
-        else if (cv >= 0) owner = cv;
-        if (owner >= 0) {
-            const int p = atomicAdd(&chain_len[owner], 1);
-            if (p < CH_MAX) chain_edges[owner * CH_MAX + p] = i;
-            else owner = -1;                        // chain full: the general queue takes it
-        }
+        const int cu = chain_of[u], cv = v != u ? chain_of[v] : -1;
+        const int pu = wo[i], pv = wo[B + i];
+        const bool in_u = cu >= 0 && pu < CH_MAX, in_v = cv >= 0 && pv < CH_MAX;
+        if (in_u) { chain_edges[cu * CH_MAX + pu] = i; atomicMax(&chain_len[cu], pu + 1); }
+        if (in_v) { chain_edges[cv * CH_MAX + pv] = i; atomicMax(&chain_len[cv], pv + 1); }
+        if (in_u && (!in_v || cnt[u] >= cnt[v])) owner = cu;
+        else if (in_v) owner = cv;
     }
     owner_of[i] = owner;
 }
 
 __global__ void k_own(const int *__restrict__ nodes, long long role_stride, int B, const int *cnt, const int *slot,
-                      const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
+                      const int *wo, const int *chain_of, int *chain_len, int *chain_edges, int *owner_of)
 {
-    d_own(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
+    d_own(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
 }
 
-// K2d: one wavefront per chain sorts its edges ascending (rank by counting).
-__global__ __launch_bounds__(64) void k_chain_sort(const int *ctl, const int *chain_len, int *chain_edges, int *pos_of)
+// K2d: per access, the chain that holds the node's row by version (zt_tppr::hv): a writer access that is a chain position,
+// a reader access (negative sample) up to the chain's last version.  (After K2c: chain_len is final.)
+__device__ __forceinline__ void d_hubacc(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
+                                         const int *slot, const int *wo, const int *chain_of, const int *chain_len, int *hv)
 {
-    __shared__ int e[CH_MAX];
-    const int c = blockIdx.x, lane = threadIdx.x;
-    if (c >= ctl[4]) return;
-    int len = chain_len[c];
-    len = len < CH_MAX ? len : CH_MAX;
-    for (int p = lane; p < len; p += 64) e[p] = chain_edges[c * CH_MAX + p];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int p = lane; p < len; p += 64) {
-        const int me = e[p];
-        int r = 0;
-        for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
-        chain_edges[c * CH_MAX + r] = me;           // edge indices are distinct
-        pos_of[me] = r;
+    if (a >= B * n_roles) return;
+    int c = -1;
+    if (slot[a] >= 0) {
+        const int r = a / B;
+        const int cc = chain_of[nodes[(long long)r * role_stride + a % B]];
+        if (cc >= 0) {
+            const int len = chain_len[cc], w = wo[a];
+            if (len > 0 && (r < 2 ? w < CH_MAX : w <= len)) c = cc;
+        }
     }
+    hv[a] = c;
+}
+
+__global__ void k_hubacc(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
+                         const int *wo, const int *chain_of, const int *chain_len, int *hv)
+{
+    d_hubacc(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, slot, wo, chain_of, chain_len, hv);
 }
 
 // K3: scatter accesses into their node's range, encoded (edge << 2) | role.
@@ -229,9 +237,8 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
     long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
     int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
-    int *pos_of, int max_chains)
+    int *hv, int max_chains)
 {
-    __shared__ int e[CH_MAX];
     const int tid = threadIdx.x, A = B * n_roles;
     if (tid == 0) { ctl[2] = 0; ctl[13] = 0; }                                   // k_plan_begin
     __syncthreads();
@@ -244,23 +251,10 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     for (int a = tid; a < A; a += PRE_THREADS) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
     d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
     __syncthreads();
-    for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, chain_of, chain_len, chain_edges, owner_of);
+    for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
     __syncthreads();
-    const int n_ch = max_chains > 0 ? ctl[4] : 0;                                // k_chain_sort, chain after chain
-    for (int c = 0; c < n_ch; ++c) {
-        int len = chain_len[c];
-        len = len < CH_MAX ? len : CH_MAX;
-        for (int p = tid; p < len; p += PRE_THREADS) e[p] = chain_edges[c * CH_MAX + p];
-        __syncthreads();
-        for (int p = tid; p < len; p += PRE_THREADS) {
-            const int me = e[p];
-            int r = 0;
-            for (int q = 0; q < len; ++q) r += e[q] < me ? 1 : 0;
-            chain_edges[c * CH_MAX + r] = me;
-            pos_of[me] = r;
-        }
-        __syncthreads();
-    }
+    for (int a = tid; a < A; a += PRE_THREADS) d_hubacc(a, nodes, role_stride, B, n_roles, slot, wo, chain_of, chain_len, hv);
+    __syncthreads();
     for (int a = tid; a < (A > MAX_HOT ? A : MAX_HOT); a += PRE_THREADS)
         d_cleanup(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
     __syncthreads();
@@ -331,7 +325,7 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
         k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
                                                   h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
                                                   h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
-                                                  h->pos_of, max_chains);
+                                                  h->hv, max_chains);
         ZT_PROF_END(s, P_PREPASS);
     } else {
         ZT_PROF_BEGIN(s, P_PREPASS);
@@ -342,9 +336,9 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
         k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
         k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
                                            max_chains);
-        k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->chain_of, h->chain_len,
+        k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->wo, h->chain_of, h->chain_len,
                                                h->chain_edges, h->owner_of);
-        if (max_chains > 0) k_chain_sort<<<max_chains, 64, 0, s>>>(h->ctl, h->chain_len, h->chain_edges, h->pos_of);
+        k_hubacc<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->wo, h->chain_of, h->chain_len, h->hv);
         ZT_PROF_END(s, P_PREPASS);
         // per-node counters and the control words back to their rest state: the set is ready for k_stream
         ZT_PROF_BEGIN(s, P_CLEANUP);

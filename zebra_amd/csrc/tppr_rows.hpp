@@ -866,32 +866,43 @@ __device__ __forceinline__ bool wait_flag(const unsigned *flag, unsigned epoch, 
 // Load a row that an earlier edge of this launch rewrites: poll until every
 // granule carries `expect`.  The mismatching tag tells how many chain hops are
 // still ahead, which sets the back-off.
-__device__ inline bool load_row_wait(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r,
-                                     int *status, unsigned *last_seen = nullptr)
+// poll a row until its granules carry the expected tag.  `version`: the row is a slot of a chain's hub-row versions (all
+// of a launch's versions carry one tag, so there is no "hops still to go" to size the naps by: short, even naps)
+__device__ inline bool load_row_wait_at(const u64 *base, int k, int lane, unsigned expect, Row &r, int *status, int x, int m,
+                                        bool version, unsigned *last_seen = nullptr)
 {
     unsigned polls = 0;
     long long t0 = 0;
     for (;;) {
-        const unsigned seen = load_row(h, m, x, lane, expect, r);
+        const unsigned seen = load_row_at(base, k, lane, expect, r);
         if (last_seen) *last_seen = seen;
         if (seen == expect) return true;
-        // hops still to go on this node's chain (tags of older launches count as ordinal 0)
-        const unsigned cur = (seen >> ORD_BITS) == (expect >> ORD_BITS) ? (seen & ((1u << ORD_BITS) - 1)) : 0u;
-        const unsigned want = expect & ((1u << ORD_BITS) - 1);
-        int ahead = (int)want - (int)cur - 1;               // 0: my predecessor is being written right now
-        if (ahead > 0) {
-            int naps = ahead > 64 ? 64 : ahead;             // ~1.5 us per hop ahead, capped
-            for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(56);
+        if (version) {
+            __builtin_amdgcn_s_sleep(6);
         } else {
-            __builtin_amdgcn_s_sleep(2);
+            // hops still to go on this node's chain (tags of older launches count as ordinal 0)
+            const unsigned cur = (seen >> ORD_BITS) == (expect >> ORD_BITS) ? (seen & ((1u << ORD_BITS) - 1)) : 0u;
+            const unsigned want = expect & ((1u << ORD_BITS) - 1);
+            int ahead = (int)want - (int)cur - 1;               // 0: my predecessor is being written right now
+            if (ahead > 0) {
+                int naps = ahead > 64 ? 64 : ahead;             // ~1.5 us per hop ahead, capped
+                for (int q = 0; q < naps; ++q) __builtin_amdgcn_s_sleep(56);
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+            }
         }
         if ((++polls & 255u) == 0) {
             const long long now = (long long)wall_clock64();
             if (t0 == 0) t0 = now;
-            else if (now - t0 > WAIT_TICKS) { note_timeout(status, 2, (int)x, (int)expect, (int)seen, m); return false; }
+            else if (now - t0 > WAIT_TICKS) { note_timeout(status, version ? 4 : 2, x, (int)expect, (int)seen, m); return false; }
             if (launch_failed(status)) return false;
         }
     }
+}
+__device__ inline bool load_row_wait(const zt_tppr &h, int m, long long x, int lane, unsigned expect, Row &r,
+                                     int *status, unsigned *last_seen = nullptr)
+{
+    return load_row_wait_at(h.rows + ((long long)m * h.N + x) * h.rg, h.k, lane, expect, r, status, (int)x, m, false, last_seen);
 }
 
 

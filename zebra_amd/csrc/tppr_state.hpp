@@ -31,7 +31,11 @@ static_assert(MAX_CHUNK == zt::TPPR_MAX_LAUNCH, "common.hpp: TPPR_MAX_LAUNCH");
 constexpr int HOT_MIN = ZT_HOT_MIN;       // accesses in one launch that make a node a chain candidate
 constexpr int MAX_HOT = 128;           // candidates kept
 constexpr int MAX_CHAINS = ZT_MAX_CHAINS; // chains per model
+#ifdef ZT_WAITLOG
+constexpr int CTL_LOG = 60;            // (diagnostic build: tools/build_waitlog.sh)
+#else
 constexpr int CTL_LOG = 6;             // timeout reports kept per launch
+#endif
 constexpr int CTL_WORDS = 16 + 8 * CTL_LOG;
 constexpr int CH_MAX = 2048;           // edges per chain (the rest go through the general queue)
 }  // namespace
@@ -54,16 +58,20 @@ struct zt_tppr {
     unsigned *done;  // [M][MAX_CHUNK] reads-done flag per (model, edge) = epoch
     unsigned *cdone; // [M][MAX_CHUNK] the same for the CHAIN's reads of a chain-owned edge (hub + partner row)
     u64 *hubver;     // [M][MAX_CHAINS][CH_MAX + 1][rg]: version t of a chain's hub row = the row before chain position t
-                     // (dictionary order, tagged with the launch epoch), or nullptr (k > REG_K_MAX: no chains)
+                     // (dictionary order, tagged with the launch epoch), or nullptr (k > REG_K_MAX: no chains).  Within a
+                     // launch a hub's row lives HERE: everybody but its own chain reads it by version, and only the
+                     // chain's last hop stores it back to `rows`
     // hub chains of the launch
     int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
     int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts
     int *hot_cnt;
     int *chain_node;   // [MAX_CHAINS]
     int *chain_len;    // [MAX_CHAINS]
-    int *chain_edges;  // [MAX_CHAINS][CH_MAX] edges owned by the chain, ascending
-    int *owner_of;     // [MAX_CHUNK] chain owning the edge, or -1
-    int *pos_of;       // [MAX_CHUNK] its position in that chain's edge list
+    int *chain_edges;  // [MAX_CHAINS][CH_MAX] the hub's edges in order: position = the hub's writer ordinal (wo) at that edge.
+                       // An edge between two hubs is in BOTH chains: each applies its own hub's update
+    int *owner_of;     // [MAX_CHUNK] the chain whose partner task (general queue) emits the edge's rows, or -1
+    int *hv;           // [3 * MAX_CHUNK] per access: the chain that holds the accessed node's row by version (the row to
+                       // read is version wo of that chain), or -1: the row is read from / written to `rows`
     // control words (device): [0] cursor, [1] queue head, [2] status, [3] hot candidates, [4] chains,
     // [13] timeout reports, [16..] the reports (see note_timeout)
     int *ctl;
@@ -80,7 +88,7 @@ struct zt_tppr {
     // the next call can run on another stream while k_stream still reads the previous call's set.
     struct PlanSet {
         int *cnt, *off, *slot, *list, *wo, *pflag, *nxt, *chain_of, *hot_node, *hot_cnt, *chain_node, *chain_len,
-            *chain_edges, *owner_of, *pos_of, *ctl;
+            *chain_edges, *owner_of, *hv, *ctl;
         hipEvent_t planned, consumed;      // prepass finished / k_stream finished with the set
         bool used;                         // `consumed` has been recorded at least once
         // what the set was planned for (valid == a zt_tppr_plan result not consumed yet)
@@ -105,7 +113,7 @@ inline void use_set(zt_tppr *h, int q)
     const zt_tppr::PlanSet &P = h->set[q];
     h->cnt = P.cnt; h->off = P.off; h->slot = P.slot; h->list = P.list; h->wo = P.wo; h->pflag = P.pflag; h->nxt = P.nxt;
     h->chain_of = P.chain_of; h->hot_node = P.hot_node; h->hot_cnt = P.hot_cnt; h->chain_node = P.chain_node;
-    h->chain_len = P.chain_len; h->chain_edges = P.chain_edges; h->owner_of = P.owner_of; h->pos_of = P.pos_of; h->ctl = P.ctl;
+    h->chain_len = P.chain_len; h->chain_edges = P.chain_edges; h->owner_of = P.owner_of; h->hv = P.hv; h->ctl = P.ctl;
 }
 
 // a failure latched by an earlier launch makes every later call fail until zt_tppr_status has reported it

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
 {
     __shared__ WaveLds lds[WAVES_PER_WG];
     __shared__ Mail mail;
-    __shared__ int ch_edge[CH_MAX], ch_partner[CH_MAX], ch_woh[CH_MAX], ch_wop[CH_MAX], ch_pfh[CH_MAX];   // chain workgroups: HopRec
+    __shared__ int ch_edge[CH_MAX], ch_partner[CH_MAX], ch_wop[CH_MAX], ch_pch[CH_MAX];   // chain workgroups: HopRec
     WaveLds &L = lds[threadIdx.x / WAVE];
     const int lane = lane_id();
     if (ld_agent(h.ctl + 2) == ZT_ERR_RANGE) {         // rejected by k_count: the state is not touched,
@@ -96,9 +96,17 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
             const int role_h = u == hub ? 0 : 1;
             ch_edge[q] = e;
             ch_partner[q] = u == v ? -1 : (int)(u == hub ? v : u);
-            ch_woh[q] = h.wo[role_h * A.B + e];
             ch_wop[q] = h.wo[(1 - role_h) * A.B + e];
-            ch_pfh[q] = h.pflag[role_h * A.B + e];
+            ch_pch[q] = u == v ? -1 : h.hv[(1 - role_h) * A.B + e];
+        }
+        // version 0 of the hub's row = the row as the launch finds it in `rows` (nobody stores there before the chain's last
+        // hop): copied by the last wave right away, so that nothing that reads it -- the hub's readers ahead of its first
+        // edge, that edge's partner task, another hub's chain whose first edge is this hub's first too -- waits for a hop
+        if (len > 0 && (int)(threadIdx.x / WAVE) == WAVES_PER_WG - 1) {
+            const int m0 = A.m_lo + mo;
+            Row r0;
+            (void)load_row(h, m0, hub, lane, 0u, r0);
+            store_row_at(hub_version(h, m0, c, 0), h.k, lane, r0.len, r0.key, r0.ts, r0.w, r0.norm, (A.epoch << ORD_BITS) | 1u);
         }
         __syncthreads();
         // chain_waves (ZT_CHAIN_WAVES, default all eight) waves take hops: what a hop needs besides the hub's update -- the
@@ -119,10 +127,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, Strea
 #define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
             const int pe = t > 0 ? ZT_U(ch_edge[t - 1]) : -1, ne = t + 1 < len ? ZT_U(ch_edge[t + 1]) : -1, ce = ZT_U(ch_edge[t]);
             HopRec rec;
-            rec.partner = ZT_U(ch_partner[t]); rec.wo_h = ZT_U(ch_woh[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pf_h = ZT_U(ch_pfh[t]);
-            rec.wo_prev = t > 0 ? ZT_U(ch_woh[t - 1]) : -1;
-            rec.wo_next = t + 1 < len ? ZT_U(ch_woh[t + 1]) : -1;
-            rec.pf_next = t + 1 < len ? ZT_U(ch_pfh[t + 1]) : -1;
+            rec.partner = ZT_U(ch_partner[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pchain = ZT_U(ch_pch[t]);
 #undef ZT_U
             if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec))
                 process_edge(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c);
@@ -209,7 +214,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         ZT_HIP(hipMalloc(&P.chain_len, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMalloc(&P.chain_edges, sizeof(int) * MAX_CHAINS * CH_MAX));
         ZT_HIP(hipMalloc(&P.owner_of, sizeof(int) * MAX_CHUNK));
-        ZT_HIP(hipMalloc(&P.pos_of, sizeof(int) * MAX_CHUNK));
+        ZT_HIP(hipMalloc(&P.hv, sizeof(int) * 3 * MAX_CHUNK));
         ZT_HIP(hipMemset(P.chain_of, 0xff, (size_t)num_nodes * sizeof(int)));
         ZT_HIP(hipMemset(P.chain_len, 0, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMemset(P.cnt, 0, (size_t)num_nodes * sizeof(int)));
@@ -257,7 +262,7 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
         (void)hipFree(P.cnt); (void)hipFree(P.off); (void)hipFree(P.ctl); (void)hipFree(P.slot); (void)hipFree(P.list);
         (void)hipFree(P.wo); (void)hipFree(P.pflag); (void)hipFree(P.nxt); (void)hipFree(P.chain_of);
         (void)hipFree(P.hot_node); (void)hipFree(P.hot_cnt); (void)hipFree(P.chain_node); (void)hipFree(P.chain_len);
-        (void)hipFree(P.chain_edges); (void)hipFree(P.owner_of); (void)hipFree(P.pos_of);
+        (void)hipFree(P.chain_edges); (void)hipFree(P.owner_of); (void)hipFree(P.hv);
         (void)hipEventDestroy(P.planned); (void)hipEventDestroy(P.consumed);
     }
     delete h;
@@ -491,15 +496,20 @@ extern "C" int zt_tppr_status(zt_tppr *h, void *stream)
             set_error("node or edge id out of range");
         } else {
             // kind 1: reads-done flag, 2: row tag (node, expect, seen, model), 3: mailbox (edge, expect, seen, prev edge)
+#ifdef ZT_WAITLOG
+            char msg[8192];
+#else
             char msg[480];
+#endif
             int o = snprintf(msg, sizeof(msg), "dependency wait timed out; %d waits gave up:", c[13]);
             for (int q = 0; q < CTL_LOG && q < c[13] && o < (int)sizeof(msg) - 80; ++q) {
                 const int *r = c + 16 + 8 * q;
                 o += snprintf(msg + o, sizeof(msg) - o, " [kind %d: %d expect 0x%x seen 0x%x aux %d wg %d wave %d t %d]", r[0],
                               r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
             }
-            set_error("%s", msg);
+            set_error("%.470s", msg);
 #ifdef ZT_WAITLOG
+            fprintf(stderr, "[waitlog] %s\n", msg);
             {
                 const int B = h->dbg_B, R = h->dbg_roles;
                 std::vector<int> wl(2 * MAX_CHUNK * 8), nodes((size_t)R * B), wo(3 * MAX_CHUNK), own(MAX_CHUNK), cn(MAX_CHAINS),
