@@ -122,7 +122,7 @@ def test_wikipedia_configs_vs_oracle(oracle, name, steps):
     wl = synth.WORKLOADS[name]
     fill = (wl["n_edges"] // 10) // wl["bs"]
     worst, cus, grp = _run(oracle, name, 0, fill, 32, steps)
-    assert cus == 32 and grp == (4 if steps >= 40 else 2)
+    assert cus == 64 and grp == (4 if steps >= 40 else 2)
 
 
 @pytest.mark.parametrize("steps", [200, 20])
@@ -134,7 +134,7 @@ def test_reddit_config_vs_oracle(oracle, steps):
     wl = synth.WORKLOADS["c3"]
     fill = (wl["n_edges"] // 10) // wl["bs"]
     worst, cus, grp = _run(oracle, "c3", 0, fill, 30, steps)
-    assert cus == 32 and grp == (4 if steps >= 40 else 2)
+    assert cus == 64 and grp == (4 if steps >= 40 else 2)
 
 
 def test_superuser_config_vs_oracle(oracle):

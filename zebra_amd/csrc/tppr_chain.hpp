@@ -39,7 +39,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
 #endif
     int wl_fail = 0;
     CRIT(4);
-    STAMP3(0);
+    HSTAMP(0);
     // ---- the partner's row: from `rows` (poll where a writer of this launch precedes us), or -- the partner is a hub and
     // ---- its chain holds this edge too -- the version of its row at that chain's position ----
     Row rp;
@@ -109,7 +109,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     // s_waitcnt vmcnt(0) here: it would also wait for the write-through stores of this wave's previous hop.)
     st_agent(h.cdone + (long long)m * MAX_CHUNK + i, epoch);
     CRIT(5);
-    STAMP3(1);
+    HSTAMP(1);
 #ifdef ZT_CRIT
     crit_t[9] = !pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : (!pre_b.ok ? 9 : 0));     // why the partner's side is not prepared
     crit_t[13] = (long long)ld_agent(h.ctl + 1) * 100000 + i;    // head of the general queue (task index) when this hop was ready, and its edge
@@ -138,7 +138,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge, true)) wl_fail |= 16;
     __builtin_amdgcn_s_setprio(3);
     CRIT(0);
-    STAMP3(2);
+    HSTAMP(2);
     Row rh;
     unsigned hub_unc = 0u;
     int hub_munc = 0, hub_nalt = 0, hub_sorted = 0;
@@ -293,7 +293,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
             if (lane == 0) __hip_atomic_store(&out_slot->seq_set, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (lane == 0 && fin) __hip_atomic_store(&out_slot->seq_ord, tpos + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             CRIT(3);
-            STAMP3(8);
+            HSTAMP(4);
             __builtin_amdgcn_s_setprio(0);                       // the rest of this hop is off the chain
             // ---- what the tail needs ----
             if (table && lane < lenp) L.htab[pre_b.h2] = -1;     // the table is clean again
@@ -448,7 +448,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
         CRIT(2);
         publish_seq(true, final_out);                            // the successor can start
         CRIT(3);
-        STAMP3(8);
+        HSTAMP(4);
         __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
     }
     }   // (!lean_done)
@@ -486,7 +486,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     store_row_scatter_at(hub_version(h, m, chain_idx, tpos + 1), k, lane, n_new, c, new_norm, vtag);
     if (lane == 0)                                               // both stages of the incoming slot have been read
         __hip_atomic_store(&in_slot->seq_free, tpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    STAMP3(3);
+    HSTAMP(3);
 #ifdef ZT_CRIT
     if (lean_done) { CRIT(6); crit_t[7] = 1; }
     if (lane == 0 && mo == 0) atomicAdd((unsigned long long *)&g_crit[8199 * 16 + (lean_done ? 0 : (pre_b.ok ? 6 : (!pre_scale.valid ? 7 : (pre_hash == 2 ? 8 : 9))))], 1ull);

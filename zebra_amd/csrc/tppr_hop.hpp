@@ -181,6 +181,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
     long long crit_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
+    HSTAMP(0);
     WL(0, 1); WL(1, blockIdx.x * WAVES_PER_WG + threadIdx.x / WAVE); WL(5, mail ? prev_edge : -2); WL(2, wall_clock64() >> 7);
     int wl_fail = 0;
     unsigned wl_seen = 0;
@@ -374,6 +375,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
     if (v == u) rv = ru;
 
     STAMP(1);
+    HSTAMP(1); HSTAMP(2);
     WL(0, 7); WL(3, wall_clock64() >> 7); WL(6, wl_fail | (hub_by_mail ? 256 : 0)); if (wl_fail & 14) WL(7, wl_seen);
     // ---- all reads done: later writers of these rows may go ahead ----
     // The row loads above must have RETURNED before a later writer may see the flag (the row of a negative
@@ -432,6 +434,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
                 publish_set(c.slot, n, new_norm);
                 if (c.slot >= 0) out_slot->pos[c.slot] = c.slot;
                 publish_seq(true, true);
+                HSTAMP(4);
                 __builtin_amdgcn_s_setprio(0);
             }
             if (hub_to_memory || xa != hub) store_row_scatter(h, m, xa, lane, n, c, new_norm, tag_base | (unsigned)(oa + 1));
@@ -561,6 +564,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
                 CRIT(2);
                 publish_seq(true, final_out);                            // the successor can start
                 CRIT(3);
+                HSTAMP(4);
                 __builtin_amdgcn_s_setprio(0);                           // the rest of this hop is off the chain
             }
 #ifdef ZT_STAMP
@@ -608,6 +612,7 @@ __device__ __attribute__((always_inline)) inline void process_edge(const zt_tppr
         for (int q = 0; q < 16; ++q) g_crit[i * 16 + q] = crit_t[q];
 #endif
     STAMP(3);
+    HSTAMP(3);
     WL(4, wall_clock64() >> 7); WL(0, 9);
     (void)wl_fail;
 }

@@ -39,13 +39,17 @@ __device__ long long g_stamps[8192 * 4];
 __device__ long long g_stamps2[8192 * 8];
 #define STAMP2(slot) do { if (lane_id() == 0 && g_stamp_i >= 0 && g_stamp_i < 8192) g_stamps2[g_stamp_i * 8 + (slot)] = (long long)wall_clock64(); } while (0)   // diagnostic build only: per task t_deq, t_rows, t_x1, t_end (100 MHz ticks)
 #define STAMP(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps[i * 4 + (slot)] = (long long)wall_clock64(); } while (0)
-// chain-owned edges: slots 0-3 the hub hop (entered, partner's row in hand, turn arrived, end), 4-7 the partner half
-// (entered, partner's and negative's rows in hand, hub's version in hand, partner's row stored), 8 the hop's publication
-__device__ long long g_stamps3[8192 * 12];
-#define STAMP3(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps3[i * 12 + (slot)] = (long long)wall_clock64(); } while (0)
+// hub hops, per (chain, position) of model 0: 0 entered, 1 partner's row in hand and prepared, 2 turn arrived, 3 end,
+// 4 publication; partner halves, per edge: 4 entered, 5 partner's and negative's rows in hand, 6 hub's version in hand,
+// 7 partner's row stored
+__device__ long long g_hopst[16 * 2048 * 8];
+__device__ long long g_stamps3[8192 * 8];
+#define HSTAMP(slot) do { if (lane == 0 && mo == 0 && chain_idx >= 0 && chain_idx < 16 && tpos < 2048) g_hopst[(chain_idx * 2048 + tpos) * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+#define STAMP3(slot) do { if (lane == 0 && mo == 0 && i < 8192) g_stamps3[i * 8 + (slot)] = (long long)wall_clock64(); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
 #define STAMP3(slot) do { } while (0)
+#define HSTAMP(slot) do { } while (0)
 #define STAMP2(slot) do { } while (0)
 #endif
 

@@ -51,7 +51,10 @@ static_assert(WAVES_PER_WG == zt::TPPR_WAVES_PER_WG && REG_K_MAX == zt::TPPR_REG
 
 namespace {
 
-__global__ __launch_bounds__(WAVE * WAVES_PER_WG) void k_stream(zt_tppr h, StreamArgs A)
+#ifndef ZT_STREAM_BOUNDS
+#define ZT_STREAM_BOUNDS (WAVE * WAVES_PER_WG)      // (tools/exp/bounds_exp.sh: 768 = three waves per SIMD, 168 VGPRs)
+#endif
+__global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamArgs A)
 {
     __shared__ WaveLds lds[WAVES_PER_WG];
     __shared__ Mail mail;
@@ -455,7 +458,13 @@ extern "C" int zt_debug_paths(int *host)
 extern "C" int zt_debug_stamps3(long long *host, int n)
 {
     ZT_HIP(hipDeviceSynchronize());
-    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps3), sizeof(long long) * n * 12));
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps3), sizeof(long long) * n * 8));
+    return ZT_OK;
+}
+extern "C" int zt_debug_hopst(long long *host)
+{
+    ZT_HIP(hipDeviceSynchronize());
+    ZT_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hopst), sizeof(long long) * 16 * 2048 * 8));
     return ZT_OK;
 }
 extern "C" int zt_debug_stamps2(long long *host, int n)

@@ -93,10 +93,12 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     and the last batches of a region are queried one by one, which a 20-step run pays for with large groups);
     1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD leaves the
     main stream a straggler XCD) -- three for the T-PPR stream at C5's batch (its non-hub tasks need the waves),
-    one for small batches; no masks for the pruning strategy, whose query kernel wants the whole chip."""
+    two for small batches (16 hub chains x 2 models + a general queue need 48 workgroups: on one XCD only 10 chains
+    fit, measured 0.181 -> 0.153 ms/step on C3); no masks for the pruning strategy, whose query kernel wants the
+    whole chip."""
     streaming = wl["strategy"] == "streaming"
     if group < 1:
         group = max(1, min(4, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
     if tppr_cus < 0:
-        tppr_cus = (96 if wl["bs"] >= 2048 else 32) if streaming else 0
+        tppr_cus = (96 if wl["bs"] >= 2048 else 64) if streaming else 0
     return tppr_cus, group
