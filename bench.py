@@ -402,7 +402,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         kern_a = {}
         if not a.no_profile:
             for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg", "embed_out",
-                       "store_messages", "gru_update"):
+                       "store_messages", "gru_update", "gru_commit"):
                 n, ms = C.c_int64(), C.c_double()
                 lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
                 if n.value:
@@ -451,7 +451,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         kern = kern_a
     elif not a.no_profile:
         for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg",
-                   "embed_out", "store_messages", "gru_update"):
+                   "embed_out", "store_messages", "gru_update", "gru_commit"):
             n, ms = C.c_int64(), C.c_double()
             lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
             if n.value:

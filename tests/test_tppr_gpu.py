@@ -674,3 +674,71 @@ def test_dependency_plan_matches_restatement(zt, name, batch):
             own_ref[i] = chain_of[b]
     assert np.array_equal(hv, hv_ref) and np.array_equal(own, own_ref)
     f.stream_device(nd, torch.from_numpy(ts[s0:s1].astype(np.float64)).cuda(), ed, 3, True, -1, plan_token=tok)
+
+
+@pytest.mark.parametrize("shape", ["many_big_groups", "one_huge_group", "big_list_overflow", "small_fused"])
+def test_dependency_plan_of_large_launches(zt, shape):
+    """Writer ordinals and reader flags of launches that take every branch of the prepass' dependency step
+    (csrc/tppr_prepass.hip: d_deps per access, d_deps_group = a cooperative sort per group of >= 48 accesses, the
+    per-access loop again for groups beyond 4096 members or when more than 512 groups qualify; the single-workgroup form
+    up to 4096 accesses, ten launches beyond), against the order utils/util.py:495-574 applies a batch's edges in."""
+    import ctypes as C
+    import torch
+    from zebra_amd import _capi
+    rng = np.random.RandomState(17)
+    if shape == "many_big_groups":
+        B, N = 8192, 3000
+        p = np.arange(1, N, dtype=np.float64) ** -1.0
+        draw = lambda n: 1 + rng.choice(N - 1, n, p=p / p.sum())
+        u, v, g = draw(B), draw(B), draw(B)
+    elif shape == "one_huge_group":
+        B, N = 16384, 5000
+        u = np.where(rng.random_sample(B) < 0.55, 7, 1 + rng.randint(0, N - 1, B))
+        v, g = 1 + rng.randint(0, N - 1, B), 1 + rng.randint(0, N - 1, B)
+    elif shape == "big_list_overflow":
+        B, N = 16384, 601
+        u, v, g = (1 + rng.randint(0, N - 1, B) for _ in range(3))
+    else:
+        B, N = 1200, 300
+        p = np.arange(1, N, dtype=np.float64) ** -1.2
+        draw = lambda n: 1 + rng.choice(N - 1, n, p=p / p.sum())
+        u, v, g = draw(B), draw(B), draw(B)
+    nodes = np.concatenate([u, v, g]).astype(np.int32)
+    f = zt.tppr_finder(N, 20, 2, [0.1, 0.1], [0.5, 0.95])
+    nd = torch.from_numpy(nodes).cuda()
+    ed = torch.arange(1, B + 1, dtype=torch.int64, device="cuda")
+    tok = f.plan_device(nd, ed, 3, -1)
+    assert tok != 0
+    wo = np.zeros(3 * B, np.int32); pf = np.zeros_like(wo); hv = np.zeros_like(wo); own = np.zeros(B, np.int32)
+    cn = np.zeros(16, np.int32); cl = np.zeros(16, np.int32); ce = np.zeros((16, 2048), np.int32); nc = np.zeros(1, np.int32)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    _capi.check(_capi.hooks_lib().zt_test_tppr_plan_dump(f._live.h, P(wo), P(pf), P(hv), P(own), P(cn), P(cl), P(ce), P(nc)))
+    wr, last, cnt = {}, {}, {}
+    wo_ref = np.zeros(3 * B, np.int32); pf_ref = np.full(3 * B, -1, np.int32)
+    for i in range(B):
+        acc = []
+        for r in range(3):
+            x = int(nodes[r * B + i])
+            if (r >= 1 and x == int(u[i])) or (r == 2 and x == int(v[i])):
+                continue
+            acc.append((r, x))
+            cnt[x] = cnt.get(x, 0) + 1
+            wo_ref[r * B + i] = wr.get(x, 0)
+            if x in last and last[x][1] == 2:
+                pf_ref[r * B + i] = last[x][0]
+        for r, x in acc:
+            if r < 2:
+                wr[x] = wr.get(x, 0) + 1
+        for r, x in reversed(acc):
+            last[x] = (i, r)
+    big = [c for c in cnt.values() if c >= 48]
+    if shape == "many_big_groups":
+        assert 20 < len(big) <= 512 and max(big) <= 4096
+    elif shape == "one_huge_group":
+        assert max(big) > 4096
+    elif shape == "big_list_overflow":
+        assert len(big) > 512
+    assert np.array_equal(wo, wo_ref), "writer ordinals"
+    assert np.array_equal(pf, pf_ref), "reader flags"
+    ts = torch.arange(1, B + 1, dtype=torch.float64, device="cuda")
+    f.stream_device(nd, ts, ed, 3, True, -1, plan_token=tok)

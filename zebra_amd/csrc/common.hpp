@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 // an event pair is recorded on the launch stream around the kernel; elapsed
 // times are summed per kernel name when the profile is read.
 enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_AGG, P_EMBED_OUT, P_STORE_MSG, P_GRU,
-              P_SCORE, P_COUNT };
+              P_SCORE, P_GRU_COMMIT, P_COUNT };
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, int id);
 void prof_end(hipStream_t s, int id);
@@ -31,7 +31,12 @@ int gru_update_ex(float *memory_dev, float *last_update_dev, const float *messag
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                   const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
                   const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, void *select_stream = nullptr,
-                  bool select_done = false);
+                  bool select_done = false, bool staged = false);
+// staged = true: the kernel only READS the tables (new rows and projections go to the workspace); gru_commit_ex, later and
+// possibly on another stream, writes them to memory / proj_table / last_update.  Same workspace and id count for both.
+bool gru_can_stage(int64_t max_rows);
+int gru_commit_ex(float *memory_dev, float *last_update_dev, const float *msg_ts_dev, int32_t D, int32_t msg_dim,
+                  int64_t max_rows, void *workspace_dev, float *proj_table, void *stream);
 // zt_store_messages_range that also zeroes one int (the GRU update's row counter: first word of its workspace)
 int store_messages_ex(const float *memory_dev, const float *last_update_dev, const float *efeat_dev, const float *time_w_dev,
                       int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,

@@ -123,8 +123,12 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                                              const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
                                              int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
-                                             const float *__restrict__ Wm_p, float *__restrict__ P)
+                                             const float *__restrict__ Wm_p, float *__restrict__ P,
+                                             float *__restrict__ stage_h, float *__restrict__ stage_p)
 {
+    // stage_h != nullptr (the pipeline's staged form, gru_update_ex): the new rows and their projections go to
+    // stage_h / stage_p [position in the row list][Hp] instead of the tables, last_update is left alone: k_gru_commit
+    // writes all three later.  The kernel then only READS the tables and may run beside the aggregation that reads them too.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,14 +259,16 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                 const float n = tanhf(ani[a][b][j] + bin + r * (anh[a][b][j] + bhn));
                 const float hold = A[(size_t)g * lda + Xp + col];
                 const float hnew = (1.f - z) * n + z * hold;
-                memory[(size_t)rid[g] * D + col] = hnew;
+                if (stage_h != nullptr) stage_h[(size_t)(r0 + g) * Hp + col] = hnew;
+                else memory[(size_t)rid[g] * D + col] = hnew;
                 if (P != nullptr) A[(size_t)g * lda + Xp + col] = hnew;    // (this thread alone reads and writes the element)
             }
     }
-    for (int g = tid; g < nr; g += nthr) {
-        const int v = rows[r0 + g];
-        last_update[v] = msg_ts[v];                   // memory_updater.py:40
-    }
+    if (stage_h == nullptr)
+        for (int g = tid; g < nr; g += nthr) {
+            const int v = rows[r0 + g];
+            last_update[v] = msg_ts[v];               // memory_updater.py:40
+        }
     // ---- the projected table follows the rows just rewritten: P[v] = W_m memory'[v] (aggregate.hip, k_project_rows),
     // ---- here from the new rows while they are still in LDS: one kernel and one pass over the rows less per step
     if (P != nullptr) {
@@ -285,7 +291,10 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int g = g4 * 4 + j;
-                if (g < nr) P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
+                if (g < nr) {
+                    if (stage_p != nullptr) stage_p[(size_t)(r0 + g) * Hp + wave * 16 + r16] = acc[j];
+                    else P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
+                }
             }
         }
     }
@@ -316,6 +325,7 @@ constexpr int GS_MAXCH = 10;         // chunks of 16 k-columns per wave: (Xp + H
 constexpr int GS_STAGE = 37;         // staged elements per thread: 16 (msg + D) <= 37 * 256
 constexpr int GS_TILE_COUNTERS = 512;
 constexpr int GS_MAX_ROWS = GS_TILE_COUNTERS * 16;
+constexpr long long GRU_STAGE_MAX_ROWS = 65536;     // staged updates (and their workspace areas) up to this many ids
 
 __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, float *last_update, const float *__restrict__ messages,
                                                              const float *__restrict__ msg_ts, const int *__restrict__ rows,
@@ -323,8 +333,10 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
                                                              const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                              const float *__restrict__ Wm_p, float *__restrict__ P, int *tile_cnt,
-                                                             float *hnew)
+                                                             float *hnew, float *__restrict__ stage_p, int staged)
 {
+    // staged (see k_gru): the new rows stay in `hnew` ([position][Hp]), their projections go to stage_p, last_update is
+    // left alone; the tile's last workgroup still computes the projections (they need a row's all N-tiles).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);                          // [16][lda]: [message (Xp) | memory (Hp)], zero padded
     float *red = A + 16 * lda;                                           // [4 waves][4 sums][64 lanes][4]
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
                 st_agent(reinterpret_cast<int *>(hnew + (size_t)(r0 + g) * Hp + col), __float_as_int((1.f - z) * n + z * hold));
             }
         }
-        if (nt == 0 && lane < nr) { const int v = rid[lane]; last_update[v] = msg_ts[v]; }      // memory_updater.py:40
+        if (!staged && nt == 0 && lane < nr) { const int v = rid[lane]; last_update[v] = msg_ts[v]; }      // memory_updater.py:40
         // ---- arrive: the tile's last workgroup commits ----
         __threadfence();
         int done = 0;
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
         for (int q = 0; q < CU; ++q) {
             const int f = tid + q * 256, g = f / Hp, c = f - g * Hp;
             if (g < 16 && c < Hp) A[g * lda + Xp + c] = v[q];
-            if (g < nr && c < D) memory[(size_t)rid[g] * D + c] = v[q];
+            if (!staged && g < nr && c < D) memory[(size_t)rid[g] * D + c] = v[q];
         }
     }
     GSTAMP(7);
@@ -467,14 +479,37 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int g = 4 * g4 + j;
-            if (g < nr) P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
+            if (g < nr) {
+                if (staged) stage_p[(size_t)(r0 + g) * Hp + 16 * b + r16] = acc[j];
+                else P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
+            }
         }
+    }
+}
+
+// The second half of a staged update: row i of the list -> memory[rows[i]] = stage_h[i], P[rows[i]] = stage_p[i],
+// last_update[rows[i]] = msg_ts[rows[i]] (memory_updater.py:40).  One wavefront per row.
+__global__ __launch_bounds__(256) void k_gru_commit(float *__restrict__ memory, float *__restrict__ last_update,
+                                                    const float *__restrict__ msg_ts, const int *__restrict__ rows,
+                                                    const int *__restrict__ n_rows, int D, int Hp,
+                                                    const float *__restrict__ stage_h, const float *__restrict__ stage_p,
+                                                    float *__restrict__ P)
+{
+    const int lane = threadIdx.x & 63, total = *n_rows;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += gridDim.x * 4) {
+        const int v = rows[i];
+        for (int c = lane; c < Hp; c += 64) {
+            const float h = stage_h[(size_t)i * Hp + c];
+            if (c < D) memory[(size_t)v * D + c] = h;
+            if (P != nullptr) P[(size_t)v * Hp + c] = stage_p[(size_t)i * Hp + c];
+        }
+        if (lane == 0) last_update[v] = msg_ts[v];
     }
 }
 
 struct GruPlan {
     int Xp, Hp, lda;
-    size_t lds, off_rows, off_cnt, off_wih, off_whh, off_tiles, off_hnew, total;
+    size_t lds, off_rows, off_cnt, off_wih, off_whh, off_tiles, off_hnew, off_pnew, total;
 };
 
 void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
@@ -492,7 +527,10 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.off_whh = take((size_t)3 * p.Hp * p.Hp * 4);
     p.off_tiles = take((size_t)GS_TILE_COUNTERS * 4);                    // k_gru_split: arrival counters per tile (zeroed with the weights)
     p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
-    p.off_hnew = take(max_rows > 0 && max_rows <= GS_MAX_ROWS ? (size_t)((max_rows + 15) / 16 * 16) * p.Hp * 4 : 0);   // k_gru_split: new rows until the commit
+    // new rows until the commit (k_gru_split always; k_gru in the staged form) and, staged, their projections
+    const size_t stage = max_rows > 0 && max_rows <= GRU_STAGE_MAX_ROWS ? (size_t)((max_rows + 15) / 16 * 16) * p.Hp * 4 : 0;
+    p.off_hnew = take(stage);
+    p.off_pnew = take(stage);
     p.total = o;
 }
 
@@ -649,7 +687,8 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
 int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                       uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                       const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, void *select_stream, bool select_done)
+                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, void *select_stream, bool select_done,
+                      bool staged)
 {
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
@@ -662,6 +701,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     GruPlan p;
     gru_plan(max_rows, D, msg_dim, p);
     if (p.lds > 150 * 1024) { set_error("zt_gru_update: message width %d too large", msg_dim); return ZT_ERR_UNSUPPORTED; }
+    if (staged && max_rows > GRU_STAGE_MAX_ROWS) { set_error("zt_gru_update: staged form for at most %lld ids", GRU_STAGE_MAX_ROWS); return ZT_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     char *ws = reinterpret_cast<char *>(workspace_dev);
     int *cnt = reinterpret_cast<int *>(ws + p.off_cnt);
@@ -699,7 +739,8 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         }
         k_gru_split<<<dim3((unsigned)((max_rows + 15) / 16), (unsigned)(p.Hp / 16)), 64 * GS_WAVES, lds2, s>>>(
             memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih,
-            wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew));
+            wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew),
+            reinterpret_cast<float *>(ws + p.off_pnew), staged ? 1 : 0);
         ZT_PROF_END(s, P_GRU);
         ZT_LAUNCH_CHECK();
         return ZT_OK;
@@ -712,8 +753,36 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     }
     const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
     k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
-                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table);
+                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table,
+                                   staged ? reinterpret_cast<float *>(ws + p.off_hnew) : nullptr,
+                                   staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr);
     ZT_PROF_END(s, P_GRU);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+bool zt::gru_can_stage(int64_t max_rows) { return max_rows > 0 && max_rows <= GRU_STAGE_MAX_ROWS; }
+
+// The commit of a staged gru_update_ex (same workspace, same max_rows): rows, projections and last_update into the tables.
+int zt::gru_commit_ex(float *memory_dev, float *last_update_dev, const float *msg_ts_dev, int32_t D, int32_t msg_dim,
+                      int64_t max_rows, void *workspace_dev, float *proj_table, void *stream)
+{
+    if (!memory_dev || !last_update_dev || !msg_ts_dev || !workspace_dev || D <= 0 || msg_dim <= 0 || !gru_can_stage(max_rows)) {
+        set_error("zt_gru_commit: bad argument");
+        return ZT_ERR_ARG;
+    }
+    GruPlan p;
+    gru_plan(max_rows, D, msg_dim, p);
+    char *ws = reinterpret_cast<char *>(workspace_dev);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((max_rows + 3) / 4);
+    ZT_PROF_BEGIN(s, P_GRU_COMMIT);
+    k_gru_commit<<<grid < 2048u ? grid : 2048u, 256, 0, s>>>(memory_dev, last_update_dev, msg_ts_dev,
+                                                             reinterpret_cast<const int *>(ws + p.off_rows),
+                                                             reinterpret_cast<const int *>(ws + p.off_cnt), D, p.Hp,
+                                                             reinterpret_cast<const float *>(ws + p.off_hnew),
+                                                             reinterpret_cast<const float *>(ws + p.off_pnew), proj_table);
+    ZT_PROF_END(s, P_GRU_COMMIT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

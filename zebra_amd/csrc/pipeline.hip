@@ -31,7 +31,11 @@ struct zt_pipeline {
     zt_pipeline_desc d;
     hipStream_t side, main_s, plan_s;
     hipStream_t msg_s;         // the message build of the current batch, beside its aggregation (reads the memory tables only)
-    hipEvent_t step_begin, msgs_done;
+    hipStream_t gru_s;         // the GRU's gate products of the current batch (staged: they only read the tables), on the main
+                               // stream's compute units: its workgroups move in as the aggregation's retire and run beside the
+                               // output layer (and the scorer); the commit follows on the main stream
+    hipEvent_t step_begin, msgs_done, gru_done;
+    bool stage_gru;            // ZT_GRU_STAGED=1 turns the staged form on (default: the GRU runs in line on the main stream)
     int group;                 // batches per T-PPR launch (streaming)
     struct Slot {
         int32_t *nodes;        // [3 * cap]   src of every member | dst ... | neg ...   (role stride = Btot)
@@ -266,21 +270,29 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         if (rc == ZT_OK) rc = zt_stream_create_masked(&b, tppr_cus, prop.multiProcessorCount);
         // the message kernels are small (a few dozen registers, no LDS): they share the T-PPR stream's compute units, where
         // they fit beside k_stream's workgroups -- the aggregation kernel fills the register files of its own
-        void *c = nullptr;
+        void *c = nullptr, *g = nullptr;
         if (rc == ZT_OK) rc = zt_stream_create_masked(&c, 0, tppr_cus);
+        if (rc == ZT_OK) rc = zt_stream_create_masked(&g, tppr_cus, prop.multiProcessorCount);
         if (rc != ZT_OK) {                     // (round-3 advisor: the streams already created leaked here)
             if (a) (void)zt_stream_destroy(a);
             if (b) (void)zt_stream_destroy(b);
             if (c) (void)zt_stream_destroy(c);
+            if (g) (void)zt_stream_destroy(g);
             delete p;
             return rc;
         }
-        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c;
+        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c; p->gru_s = (hipStream_t)g;
     } else {
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->msg_s, hipStreamNonBlocking));
+        ZT_HIP(hipStreamCreateWithFlags(&p->gru_s, hipStreamNonBlocking));
     }
+    // (measured, round 4: C5 0.3516 against 0.3526 ms/step, 0.391 against 0.409 with the scorer at the tail -- but C2 0.093 ->
+    //  0.141, C3 0.154 -> 0.224, C4 0.156 -> 0.181: two more stream-to-stream hand-offs on a step that is a chain of short
+    //  kernels, and the output layer shares its compute units.  Off unless ZT_GRU_STAGED=1.)
+    p->stage_gru = getenv("ZT_GRU_STAGED") && atoi(getenv("ZT_GRU_STAGED")) != 0;
+    ZT_HIP(hipEventCreateWithFlags(&p->gru_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->msgs_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->scored[0], hipEventDisableTiming | zt::sync_event_flags()));
@@ -317,7 +329,8 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
     (void)hipStreamDestroy(p->side); (void)hipStreamDestroy(p->main_s); (void)hipStreamDestroy(p->plan_s);
-    (void)hipStreamDestroy(p->msg_s);
+    (void)hipStreamDestroy(p->msg_s); (void)hipStreamDestroy(p->gru_s);
+    (void)hipEventDestroy(p->gru_done);
     (void)hipEventDestroy(p->scored[0]); (void)hipEventDestroy(p->scored[1]);
     (void)hipEventDestroy(p->entry); (void)hipEventDestroy(p->step_begin); (void)hipEventDestroy(p->msgs_done);
     delete p;
@@ -499,6 +512,23 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     if (rc != ZT_OK) return rc;
     if (!cnt_zeroed) ZT_HIP(hipMemsetAsync(gru_cnt, 0, sizeof(int), p->msg_s));       // (B == 0 cannot get here; belt and braces)
     ZT_HIP(hipEventRecord(p->msgs_done, p->msg_s));
+    // ---- P3 (the gate products): staged -- the kernel only reads the tables, its results wait in the GRU workspace --, on a
+    // stream of its own over the main stream's compute units, behind the message build.  The aggregation kernels there are
+    // persistent with a whole register file each, so the GRU's workgroups move in as those retire and run beside the output
+    // layer and the scorer; the commit (rows, projections, last_update into the tables) follows on the main stream.  Needs the
+    // padded W_m of an earlier step (embed_ready) when there is a projected table; otherwise the update runs in line below.
+    const bool staged = p->stage_gru && zt::gru_can_stage(2 * B) && (d.proj_table == nullptr || p->embed_ready);
+    const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
+                                                                     : nullptr;
+    if (staged) {
+        ZT_HIP(hipStreamWaitEvent(p->gru_s, p->msgs_done, 0));
+        rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
+                               nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->gru_s, true, nullptr,
+                               true, true);
+        if (rc != ZT_OK) return rc;
+        p->gru_ready = true;
+        ZT_HIP(hipEventRecord(p->gru_done, p->gru_s));
+    }
     if (n_rows > 0) {
         rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                       od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
@@ -515,11 +545,20 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
             p->score_B = B;
         }
     }
-    // ---- P3: GRU update over the messages built beside the aggregation, projected rows ----
+    // ---- P3: the staged update's commit, or the whole GRU update over the messages built beside the aggregation; the
+    // refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace ----
+    if (staged) {
+        ZT_HIP(hipStreamWaitEvent(p->main_s, p->gru_done, 0));
+        rc = zt::gru_commit_ex(d.memory, d.last_update, d.msg_ts, d.D, msg_dim, 2 * B, d.gru_ws, wm_p ? d.proj_table : nullptr, p->main_s);
+        if (rc != ZT_OK) return rc;
+        s->key[j] = nullptr;
+        if (++s->n_done >= s->n) {
+            ZT_HIP(hipEventRecord(s->consumed, p->main_s));
+            s->n = 0;
+        }
+        return ZT_OK;
+    }
     ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
-    // the refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace
-    const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
-                                                                     : nullptr;
     rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
                            nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, nullptr,
                            true);

@@ -27,7 +27,8 @@ std::vector<hipEvent_t> g_prof_pool;
 double g_prof_ms[P_COUNT];
 long long g_prof_n[P_COUNT];
 const char *const g_prof_names[P_COUNT] = {"tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk",
-                                           "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update", "score"};
+                                           "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update", "score",
+                                           "gru_commit"};
 hipEvent_t prof_event()
 {
     hipEvent_t e;
@@ -37,7 +38,7 @@ hipEvent_t prof_event()
 }
 int g_prof_every = 1;                 // time every n-th launch of each kernel (zt_profile_enable(n))
 long long g_prof_seen[P_COUNT];
-long long g_prof_open[P_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};   // index of the open record per kernel
+long long g_prof_open[P_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // index of the open record per kernel
 }  // namespace
 void prof_begin(hipStream_t s, int id)
 {

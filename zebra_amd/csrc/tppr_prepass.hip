@@ -50,13 +50,18 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
 
 // K2: the first access of each node reserves a contiguous range of `list`.
 __device__ __forceinline__ void d_reserve(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
-                                          const int *cnt, int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+                                          const int *cnt, int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt,
+                                          int big_min)
 {
     if (a >= B * n_roles) return;
     if (slot[a] == 0) {
         const int x = nodes[(long long)(a / B) * role_stride + a % B];
         const int c = cnt[x];
         off[x] = atomicAdd(&ctl[0], c);
+        if (c >= big_min && c <= DEPS_SORT_MAX) {  // a big group: its dependencies come from a sort (d_deps_group)
+            const int bi = atomicAdd(&ctl[5], 1);
+            if (bi < MAX_BIG) hot_node[MAX_HOT + bi] = x;
+        }
         if (c >= HOT_MIN) {                        // hub candidate
             const int hi = atomicAdd(&ctl[3], 1);
             if (hi < MAX_HOT) { hot_node[hi] = x; hot_cnt[hi] = c; }
@@ -65,9 +70,9 @@ __device__ __forceinline__ void d_reserve(int a, const int *__restrict__ nodes, 
 }
 
 __global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
-                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt)
+                          int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt, int big_min)
 {
-    d_reserve(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+    d_reserve(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt, big_min);
 }
 
 // K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
@@ -173,12 +178,13 @@ __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int
 //   nxt   = how many later edges touch the node (the length of the chain waiting for this access)
 __device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                        const int *cnt, const int *off, const int *slot, const int *list, int *wo,
-                                       int *pflag, int *nxt)
+                                       int *pflag, int *nxt, int n_big, int big_min)
 {
     if (a >= B * n_roles) return;
     if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0; return; }
     const int x = nodes[(long long)(a / B) * role_stride + a % B];
     const int o = off[x], c = cnt[x];
+    if (c >= big_min && c <= DEPS_SORT_MAX && n_big <= MAX_BIG) return;    // d_deps_group's (every big group is on the list)
     const int me = a % B;
     int best = -1, best_role = 0, writers = 0, nx = 0;
     // 16 list entries are fetched before any is used: a hub's group has hundreds of members and the
@@ -205,9 +211,73 @@ __device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, lon
 }
 
 __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
-                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt)
+                       const int *off, const int *slot, const int *list, int *wo, int *pflag, int *nxt, const int *ctl,
+                       int big_min)
 {
-    d_deps(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+    d_deps(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt, ctl[5], big_min);
+}
+
+// K4b: the same three numbers for ALL members of one big group at once.  d_deps walks the whole group per access -- a hub
+// with c accesses costs c^2 list reads, and the thread that owns one of them c / 16 dependent round trips: 70 us for
+// the 400 members of C5's hub in a two-batch launch, 410 us in the single-workgroup form.  A group's members are
+// (edge << 2 | role) words with distinct edges (an edge's second access to a node is a shadow and not in the group), so
+// after a sort by value the member at position p has exactly p earlier edges: wo = writers among [0, p) (a prefix
+// count), the latest earlier access is the member at p - 1, nxt = c - 1 - p.  One workgroup sorts the group in LDS
+// (bitonic, padded to a power of two) and scans the writer flags.  `s` holds DEPS_SORT_MAX ints, `t` two per thread.
+__device__ __forceinline__ void d_deps_group(int tid, int nthr, int x, int B, const int *cnt, const int *off, const int *list,
+                                             int *wo, int *pflag, int *nxt, int *s, int *t)
+{
+    const int c = cnt[x], o = off[x];
+    int P = 64;
+    while (P < c) P <<= 1;
+    for (int i = tid; i < P; i += nthr) s[i] = i < c ? list[o + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += nthr) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int a = s[i], b = s[l];
+                    if ((a > b) == ((i & k2) == 0)) { s[i] = b; s[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // writers among [0, p): every thread counts a contiguous chunk, the chunk sums are scanned (Hillis-Steele between the
+    // two halves of t: 2 * nthr ints)
+    const int chunk = (P + nthr - 1) / nthr, b0 = tid * chunk;
+    int loc = 0;
+    for (int q = 0; q < chunk; ++q) loc += (b0 + q < c && (s[b0 + q] & 3) < 2) ? 1 : 0;
+    int *src = t, *dst = t + nthr;
+    src[tid] = loc;
+    __syncthreads();
+    for (int d = 1; d < nthr; d <<= 1) {
+        dst[tid] = src[tid] + (tid >= d ? src[tid - d] : 0);
+        __syncthreads();
+        int *sw = src; src = dst; dst = sw;
+    }
+    int run = src[tid] - loc;
+    for (int q = 0; q < chunk; ++q) {
+        const int p = b0 + q;
+        if (p >= c) break;
+        const int v = s[p], e = v >> 2, r = v & 3, a = r * B + e;
+        wo[a] = run;
+        run += r < 2 ? 1 : 0;
+        nxt[a] = c - 1 - p;
+        pflag[a] = (p > 0 && (s[p - 1] & 3) == 2) ? (s[p - 1] >> 2) : -1;
+    }
+    __syncthreads();                                   // (the arrays are reused for the next group)
+}
+
+constexpr int DEPS_BIG_THREADS = 256;
+__global__ __launch_bounds__(DEPS_BIG_THREADS) void k_deps_big(int B, const int *cnt, const int *off, const int *list, int *wo,
+                                                               int *pflag, int *nxt, const int *ctl, const int *big_node)
+{
+    __shared__ int s[DEPS_SORT_MAX], t[2 * DEPS_BIG_THREADS];
+    const int n_big = ctl[5];
+    if (n_big > MAX_BIG) return;                       // the list overflowed: d_deps has taken every access
+    for (int g = blockIdx.x; g < n_big; g += gridDim.x)
+        d_deps_group(threadIdx.x, DEPS_BIG_THREADS, big_node[g], B, cnt, off, list, wo, pflag, nxt, s, t);
 }
 
 // K5: restore the per-node counters and the control words for the next call.
@@ -225,30 +295,38 @@ __global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, 
     d_cleanup(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
 }
 
-// K6: control words back to zero (after k_cleanup has read ctl[3]); ctl[4] = chains stays for k_stream.
-__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 4 && threadIdx.x != 2) ctl[threadIdx.x] = 0; }
+// K6: control words back to zero (after k_cleanup has read ctl[3]); ctl[4] = chains stays for k_stream.  ([5]: big groups)
+__global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 6 && threadIdx.x != 2 && threadIdx.x != 4) ctl[threadIdx.x] = 0; }
 
 // The whole prepass as ONE workgroup, for launches of at most PRE_FUSED_MAX accesses (small batches: there the ten
 // launches above cost more on the host and in launch gaps than the work itself).  Same steps, same arrays, same
 // results; the steps are separated by workgroup barriers instead of kernel boundaries.
-constexpr int PRE_FUSED_MAX = 12288;
+constexpr int PRE_FUSED_MAX = 4096;      // (round 4: was 12288 -- a C5 batch's 12 288 accesses took 412 us in one workgroup,
+                                        //  110 us as ten launches; ZT_PREPASS_FUSED_MAX overrides)
 constexpr int PRE_THREADS = 1024;
 __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
     long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
     int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
-    int *hv, int max_chains)
+    int *hv, int max_chains, int big_min)
 {
+    __shared__ int sort_s[DEPS_SORT_MAX], sort_t[2 * PRE_THREADS];
     const int tid = threadIdx.x, A = B * n_roles;
     if (tid == 0) { ctl[2] = 0; ctl[13] = 0; }                                   // k_plan_begin
     __syncthreads();
     for (int a = tid; a < A; a += PRE_THREADS) d_count(a, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
     __syncthreads();
-    for (int a = tid; a < A; a += PRE_THREADS) d_reserve(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt);
+    for (int a = tid; a < A; a += PRE_THREADS) d_reserve(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt, big_min);
     __syncthreads();
     for (int a = tid; a < A; a += PRE_THREADS) d_fill(a, nodes, role_stride, B, n_roles, off, slot, list);
     __syncthreads();
-    for (int a = tid; a < A; a += PRE_THREADS) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt);
+    {
+        const int n_big = __hip_atomic_load(&ctl[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = tid; a < A; a += PRE_THREADS) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt, n_big, big_min);
+        if (n_big <= MAX_BIG)
+            for (int g = 0; g < n_big; ++g)
+                d_deps_group(tid, PRE_THREADS, hot_node[MAX_HOT + g], B, cnt, off, list, wo, pflag, nxt, sort_s, sort_t);
+    }
     d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
     __syncthreads();
     for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
@@ -258,7 +336,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     for (int a = tid; a < (A > MAX_HOT ? A : MAX_HOT); a += PRE_THREADS)
         d_cleanup(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
     __syncthreads();
-    if (tid < 4 && tid != 2) ctl[tid] = 0;                                       // k_reset_ctl
+    if (tid < 6 && tid != 2 && tid != 4) ctl[tid] = 0;                           // k_reset_ctl
 }
 
 
@@ -320,20 +398,25 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
     int grid, max_chains;
     tppr_launch_shape(h, h->run_cus > 0 ? h->run_cus : h->n_cu, B, n_models, &grid, &max_chains);
     static const bool fused_ok = !(getenv("ZT_PREPASS_FUSED") && atoi(getenv("ZT_PREPASS_FUSED")) == 0);
-    if (fused_ok && A <= PRE_FUSED_MAX) {
+    // (ZT_DEPS_SORT_MIN: the group size from which the dependencies come from the cooperative sort; 0 = never -- A/B knob)
+    static const int big_min_env = getenv("ZT_DEPS_SORT_MIN") ? atoi(getenv("ZT_DEPS_SORT_MIN")) : BIG_MIN;
+    const int big_min = big_min_env > 0 ? big_min_env : 0x7fffffff;
+    static const int fused_max = getenv("ZT_PREPASS_FUSED_MAX") ? atoi(getenv("ZT_PREPASS_FUSED_MAX")) : PRE_FUSED_MAX;
+    if (fused_ok && A <= fused_max && A <= 12288) {
         ZT_PROF_BEGIN(s, P_PREPASS);
         k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
                                                   h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
                                                   h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
-                                                  h->hv, max_chains);
+                                                  h->hv, max_chains, big_min);
         ZT_PROF_END(s, P_PREPASS);
     } else {
         ZT_PROF_BEGIN(s, P_PREPASS);
         k_plan_begin<<<1, 64, 0, s>>>(h->ctl);
         k_count<<<gb, tb, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->ctl, h->latch_dev);
-        k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt);
+        k_reserve<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->ctl, h->hot_node, h->hot_cnt, big_min);
         k_fill<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->off, h->slot, h->list);
-        k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt);
+        k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt, h->ctl, big_min);
+        k_deps_big<<<64, DEPS_BIG_THREADS, 0, s>>>(B, h->cnt, h->off, h->list, h->wo, h->pflag, h->nxt, h->ctl, h->hot_node + MAX_HOT);
         k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
                                            max_chains);
         k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->wo, h->chain_of, h->chain_len,

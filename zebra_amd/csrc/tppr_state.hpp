@@ -30,6 +30,9 @@ static_assert(MAX_CHUNK == zt::TPPR_MAX_LAUNCH, "common.hpp: TPPR_MAX_LAUNCH");
 #endif
 constexpr int HOT_MIN = ZT_HOT_MIN;       // accesses in one launch that make a node a chain candidate
 constexpr int MAX_HOT = 128;           // candidates kept
+constexpr int BIG_MIN = 48;            // a node group of this many accesses gets its dependencies from a cooperative sort
+constexpr int MAX_BIG = 512;           // (tppr_prepass.hip: d_deps_group); the list of such nodes sits behind hot_node[MAX_HOT]
+constexpr int DEPS_SORT_MAX = 4096;    // members of a group the sort takes (larger groups: the per-access loop)
 constexpr int MAX_CHAINS = ZT_MAX_CHAINS; // chains per model
 #ifdef ZT_WAITLOG
 constexpr int CTL_LOG = 60;            // (diagnostic build: tools/build_waitlog.sh)
@@ -63,7 +66,7 @@ struct zt_tppr {
                      // chain's last hop stores it back to `rows`
     // hub chains of the launch
     int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
-    int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts
+    int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts; [MAX_HOT .. MAX_HOT + MAX_BIG): nodes of big groups
     int *hot_cnt;
     int *chain_node;   // [MAX_CHAINS]
     int *chain_len;    // [MAX_CHAINS]
@@ -72,7 +75,7 @@ struct zt_tppr {
     int *owner_of;     // [MAX_CHUNK] the chain whose partner task (general queue) emits the edge's rows, or -1
     int *hv;           // [3 * MAX_CHUNK] per access: the chain that holds the accessed node's row by version (the row to
                        // read is version wo of that chain), or -1: the row is read from / written to `rows`
-    // control words (device): [0] cursor, [1] queue head, [2] status, [3] hot candidates, [4] chains,
+    // control words (device): [0] cursor, [1] queue head, [2] status, [3] hot candidates, [4] chains, [5] big groups,
     // [13] timeout reports, [16..] the reports (see note_timeout)
     int *ctl;
     unsigned epoch;

@@ -211,7 +211,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         ZT_HIP(hipMalloc(&P.pflag, sizeof(int) * 3 * MAX_CHUNK));
         ZT_HIP(hipMalloc(&P.nxt, sizeof(int) * 3 * MAX_CHUNK));
         ZT_HIP(hipMalloc(&P.chain_of, (size_t)num_nodes * sizeof(int)));
-        ZT_HIP(hipMalloc(&P.hot_node, sizeof(int) * MAX_HOT));
+        ZT_HIP(hipMalloc(&P.hot_node, sizeof(int) * (MAX_HOT + MAX_BIG)));
         ZT_HIP(hipMalloc(&P.hot_cnt, sizeof(int) * MAX_HOT));
         ZT_HIP(hipMalloc(&P.chain_node, sizeof(int) * MAX_CHAINS));
         ZT_HIP(hipMalloc(&P.chain_len, sizeof(int) * MAX_CHAINS));
