@@ -315,7 +315,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     # views of every batch, made once: slicing tensors is host work that is not part of the path
     batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
                 ts_d[b * bs:(b + 1) * bs], eidx_d[b * bs:(b + 1) * bs]) for b in range(n_steps_total)]
-    look = 3 * group                            # batches in sight: the rest of this group, the next group, the one after
+    look = synth.pipeline_look(group)           # batches in sight: the rest of this group, the next group, the one after
                                                 # it, and one more (a group is only full while a follower is in sight)
 
     # the batch loop itself: native (zt_pipeline_run: the region's steps from one host call -- the loop of

@@ -80,7 +80,7 @@ def _run(oracle, name, first_batch, fill, nb, steps_for_group, group=-1, tppr_cu
     dev = tgn.device
     t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
     batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(first_batch, n_b)]
-    look = 3 * grp                                             # bench.py's view ahead
+    look = synth.pipeline_look(grp)                            # bench.py's view ahead
     embs = []
     with torch.cuda.stream(tgn.main_stream):
         for q, cur in enumerate(batches):
@@ -149,9 +149,9 @@ def test_superuser_config_vs_oracle(oracle):
 
 @pytest.mark.parametrize("group,perm", [(2, 7), (4, 7), (2, None), (4, None)])
 def test_bench_path_vs_oracle_c5_launch_shapes(oracle, group, perm):
-    """C5's launch configuration as bench.py runs it -- T-PPR on 96 CUs (three XCDs), launches over 2 (the driver's
-    20-step run) and 4 batches (200 steps) -- on 100 K nodes, where the hub's chain is a tenth of the batch (the
-    round-3 test ran 64 CUs / group 2 only): 4 unchecked + 12 checked batches; ids shuffled as in the bench and
+    """C5's launch configuration as bench.py runs it -- T-PPR on 96 CUs (three XCDs; the prepass sizes the number of hub
+    chains by the general queue's load), launches over 2 (the driver's 20-step run) and 4 batches (200 steps) -- on 100 K
+    nodes, where the hub's chain is a tenth of the batch: 4 unchecked + 12 checked batches; ids shuffled as in the bench and
     id == popularity rank (the hot rows contiguous)."""
     from zebra_amd import synth
     wl = dict(synth.WORKLOADS["c5"], n_nodes=100_000, n_edges=16 * 4096)

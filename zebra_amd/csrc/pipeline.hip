@@ -176,10 +176,15 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     };
     add(first);
     if (want > MAX_GROUP) want = MAX_GROUP;
-    // Leave a follower in sight: the aggregation of a group's FIRST batch waits for the whole launch, so where the
-    // view ahead ends (the end of a stream, or of a timed region) the last batches are queried one by one and the
-    // aggregation of each runs beside the update of the next.
-    if (n_more < want) want = n_more >= 1 ? n_more : 1;
+    // Leave followers in sight: the aggregation of a group's FIRST batch waits for the whole launch, and after the LAST
+    // launch of a stream (or of a timed region) the main stream still has every batch of that launch to aggregate.  So
+    // where the view ahead ends the groups taper -- with n_more followers in sight a group takes at most n_more - 1 of
+    // them along: the last THREE batches of a region are queried one by one (round 4; two before: the driver's 20-step
+    // run ended with a two-batch launch and two aggregations behind it) and the aggregation of each runs beside the update
+    // of the next.  A full group needs want + 1 followers in sight (synth.pipeline_look).
+    static const bool taper3 = !(getenv("ZT_GROUP_TAPER") && atoi(getenv("ZT_GROUP_TAPER")) == 0);     // (A/B knob: 0 = round 3's rule)
+    if (taper3) { if (n_more <= want) want = n_more >= 2 ? n_more - 1 : 1; }
+    else if (n_more < want) want = n_more >= 1 ? n_more : 1;
     for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
         const zt_batch *b = more + q;
         // members are equally long, except that the last one may be shorter; everything fits one launch and the slot

@@ -75,13 +75,34 @@ __global__ void k_reserve(const int *__restrict__ nodes, long long role_stride, 
     d_reserve(blockIdx.x * blockDim.x + threadIdx.x, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt, big_min);
 }
 
+// How many hub chains a launch should run (round 4).  A chain workgroup is taken from the general queue, and the general
+// queue has to get through the launch's `tasks` (edge, model) tasks -- ~16 us of a wave's time each -- in the time the longest
+// chain needs (~1.5 us per hop, `top` hops): it wants tasks * 16 / (8 waves * 1.5 * top) = 4 tasks / (3 top) workgroups.
+// What is left of the grid goes to chains (at least MIN_CHAINS of them).  C5 on 64 workgroups: 32 768 tasks against a hub of
+// ~830 accesses per four-batch launch -> 53 general workgroups, 5 chains per model (measured: 5 .. 8 chains 0.353 ms/step,
+// 12 0.382, 16 0.440; on 96 workgroups 16 chains fit: 0.352); C3: 4 800 tasks, ~480 -> 14 general workgroups, 16 chains.
+constexpr int MIN_CHAINS = 4;
+__device__ __forceinline__ int d_chain_budget(int top, int grid, int tasks, int n_models, int max_chains)
+{
+    if (top <= 0 || grid <= 0) return max_chains;
+    const int general = (4 * tasks + 3 * top - 1) / (3 * top);
+    int n = (grid - general) / (n_models > 0 ? n_models : 1);
+    if (n < MIN_CHAINS) n = MIN_CHAINS;
+    return n < max_chains ? n : max_chains;
+}
+
 // K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
 __device__ __forceinline__ void d_hot_select(int t, int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of,
-                                             int *chain_node, int *chain_len, int max_chains)
+                                             int *chain_node, int *chain_len, int max_chains, int grid, int tasks, int n_models)
 {
     if (t >= MAX_HOT) return;                      // MAX_HOT threads take part
     int nh = ctl[3];
     nh = nh < MAX_HOT ? nh : MAX_HOT;
+    {   // the chain budget of this launch (every thread works it out alike: at most MAX_HOT reads)
+        int top = 0;
+        for (int q = 0; q < nh; ++q) top = hot_cnt[q] > top ? hot_cnt[q] : top;
+        max_chains = d_chain_budget(top, grid, tasks, n_models, max_chains);
+    }
     if (t < MAX_CHAINS) chain_len[t] = 0;
     if (ctl[2] == ZT_ERR_RANGE) { if (t == 0) ctl[4] = 0; return; }
     int rank = 0;
@@ -96,10 +117,12 @@ __device__ __forceinline__ void d_hot_select(int t, int *ctl, const int *hot_nod
     if (t == 0) ctl[4] = nh < max_chains ? nh : max_chains;
 }
 
+
+
 __global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of, int *chain_node,
-                             int *chain_len, int max_chains)
+                             int *chain_len, int max_chains, int grid, int tasks, int n_models)
 {
-    d_hot_select(threadIdx.x, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+    d_hot_select(threadIdx.x, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains, grid, tasks, n_models);
 }
 
 // K2c: every edge with a hub endpoint enters that hub's chain at position = the hub's writer ordinal there (all earlier
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
     long long N, int *cnt, int *slot, int *off, int *list, int *wo, int *pflag, int *nxt, int *ctl, int *latch,
     int *hot_node, int *hot_cnt, int *chain_of, int *chain_node, int *chain_len, int *chain_edges, int *owner_of,
-    int *hv, int max_chains, int big_min)
+    int *hv, int max_chains, int big_min, int grid, int n_models)
 {
     __shared__ int sort_s[DEPS_SORT_MAX], sort_t[2 * PRE_THREADS];
     const int tid = threadIdx.x, A = B * n_roles;
@@ -327,7 +350,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
             for (int g = 0; g < n_big; ++g)
                 d_deps_group(tid, PRE_THREADS, hot_node[MAX_HOT + g], B, cnt, off, list, wo, pflag, nxt, sort_s, sort_t);
     }
-    d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains);
+    d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains, grid, B * n_models, n_models);
     __syncthreads();
     for (int i = tid; i < B; i += PRE_THREADS) d_own(i, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
     __syncthreads();
@@ -401,13 +424,16 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
     // (ZT_DEPS_SORT_MIN: the group size from which the dependencies come from the cooperative sort; 0 = never -- A/B knob)
     static const int big_min_env = getenv("ZT_DEPS_SORT_MIN") ? atoi(getenv("ZT_DEPS_SORT_MIN")) : BIG_MIN;
     const int big_min = big_min_env > 0 ? big_min_env : 0x7fffffff;
+    // (ZT_CHAIN_BUDGET=0: as many chains as the grid allows, whatever the general queue's load -- A/B knob)
+    static const bool budget_on = !(getenv("ZT_CHAIN_BUDGET") && atoi(getenv("ZT_CHAIN_BUDGET")) == 0);
+    const int budget_grid = budget_on ? grid : 0;
     static const int fused_max = getenv("ZT_PREPASS_FUSED_MAX") ? atoi(getenv("ZT_PREPASS_FUSED_MAX")) : PRE_FUSED_MAX;
     if (fused_ok && A <= fused_max && A <= 12288) {
         ZT_PROF_BEGIN(s, P_PREPASS);
         k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
                                                   h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,
                                                   h->chain_of, h->chain_node, h->chain_len, h->chain_edges, h->owner_of,
-                                                  h->hv, max_chains, big_min);
+                                                  h->hv, max_chains, big_min, budget_grid, n_models);
         ZT_PROF_END(s, P_PREPASS);
     } else {
         ZT_PROF_BEGIN(s, P_PREPASS);
@@ -418,7 +444,7 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
         k_deps<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->cnt, h->off, h->slot, h->list, h->wo, h->pflag, h->nxt, h->ctl, big_min);
         k_deps_big<<<64, DEPS_BIG_THREADS, 0, s>>>(B, h->cnt, h->off, h->list, h->wo, h->pflag, h->nxt, h->ctl, h->hot_node + MAX_HOT);
         k_hot_select<<<1, MAX_HOT, 0, s>>>(h->ctl, h->hot_node, h->hot_cnt, h->chain_of, h->chain_node, h->chain_len,
-                                           max_chains);
+                                           max_chains, budget_grid, B * n_models, n_models);
         k_own<<<(B + tb - 1) / tb, tb, 0, s>>>(nodes, role_stride, B, h->cnt, h->slot, h->wo, h->chain_of, h->chain_len,
                                                h->chain_edges, h->owner_of);
         k_hubacc<<<gb, tb, 0, s>>>(nodes, role_stride, B, n_roles, h->slot, h->wo, h->chain_of, h->chain_len, h->hv);

@@ -92,13 +92,22 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     group: as many batches per T-PPR launch as fit (<= 16384 edges, <= 4), fewer for a short region (the first
     and the last batches of a region are queried one by one, which a 20-step run pays for with large groups);
     1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD leaves the
-    main stream a straggler XCD) -- three for the T-PPR stream at C5's batch (its non-hub tasks need the waves),
-    two for small batches (16 hub chains x 2 models + a general queue need 48 workgroups: on one XCD only 10 chains
-    fit, measured 0.181 -> 0.153 ms/step on C3); no masks for the pruning strategy, whose query kernel wants the
-    whole chip."""
+    main stream a straggler XCD) -- three for the T-PPR stream at C5's batch (its general queue needs ~53 workgroups
+    beside the hub chains: tppr_prepass.hip, d_chain_budget), two for small batches (16 hub chains x 2 models + a
+    general queue need 48 workgroups: on one XCD only 10 chains fit, measured 0.181 -> 0.153 ms/step on C3); no masks
+    for the pruning strategy, whose query kernel wants the whole chip.  (C5 on two XCDs with 5-8 chains was measured
+    in round 4 -- aggregation 216 -> 180 us on 192 CUs, k_stream 1 246 -> 1 267 us per four batches: 0.360 against 0.353
+    ms/step at 200 steps, the same at 20 -- and not adopted.)"""
     streaming = wl["strategy"] == "streaming"
     if group < 1:
         group = max(1, min(4, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
     if tppr_cus < 0:
         tppr_cus = (96 if wl["bs"] >= 2048 else 64) if streaming else 0
     return tppr_cus, group
+
+
+def pipeline_look(group):
+    """Batches a step should see ahead of the current one so that T-PPR launch groups stay full: the rest of this group, the
+    next group, the one after it, and one more (a group takes at most n - 1 of the n followers in sight along:
+    pipeline.hip, make_group)."""
+    return 3 * group + 1

@@ -377,7 +377,7 @@ class TGN(torch.nn.Module):
                 raise ValueError("out must be a contiguous float32 [n, 3 B, H] tensor")
             buf, stride = out, 3 * Bmax * H
         self._run_keep = keep
-        check(lib().zt_pipeline_run(self._pipe, arr, C.c_int32(n), C.c_int32(3 * self._pipe_group if look is None else look),
+        check(lib().zt_pipeline_run(self._pipe, arr, C.c_int32(n), C.c_int32(3 * self._pipe_group + 1 if look is None else look),
                                     ptr(buf), C.c_int64(stride)), "zt_pipeline_run")
         return out
 
