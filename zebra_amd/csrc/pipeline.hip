@@ -56,6 +56,7 @@ struct zt_pipeline {
         uint64_t token;        // zt_tppr_plan token, 0 = none
         int64_t q_lo, q_hi;    // pruning strategy: the rows of the (single) member the query was launched for
         bool launched, used;
+        bool waited;           // the main stream has been told to wait for `ready_ev` of this launch (a later member need not again)
     } slot[3];
     int next_slot;
     int64_t cap;               // edges a slot can hold
@@ -64,6 +65,7 @@ struct zt_pipeline {
     float *sh_od, *sh_ow;
     bool embed_ready, gru_ready;
     hipEvent_t entry;          // main stream at the moment a group is staged: the batches' tensors are written by then
+    bool entry_recorded;       // ... recorded in the step call under way (only the calls that stage a group need it)
     float *avg_topk;           // zt_pipeline_set_stats: mean row sum of model 0's weights over [src | dst] (or NULL)
     // zt_pipeline_set_scoring: the link scorer behind the aggregation of every whole-batch step (or off)
     // On the main stream: on a stream of its own (measured: C5 0.421 instead of 0.41 ms/step, C4 0.256 instead of 0.208) it
@@ -199,7 +201,10 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     // (`entry` was recorded when the step call began -- BEFORE the main stream was told to wait for the current group's
     //  T-PPR update: recorded here, behind that wait, it held the staging and the plan of the NEXT groups back until the
     //  current update was done; a quarter of a millisecond at the start of a timed region)
-    if (st != p->main_s) ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
+    if (st != p->main_s) {
+        if (!p->entry_recorded) { ZT_HIP(hipEventRecord(p->entry, p->main_s)); p->entry_recorded = true; }
+        ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
+    }
     k_stage_group<<<(unsigned)((g.Btot + 255) / 256), 256, 0, st>>>(g, s.nodes, s.nodes_m, s.ts,
                                                                      reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1);
     ZT_LAUNCH_CHECK();
@@ -209,7 +214,7 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     s.on = s.buf; s.oe = s.buf + per;
     s.od = reinterpret_cast<float *>(s.buf + 2 * per); s.ow = reinterpret_cast<float *>(s.buf + 3 * per);
     for (int j = 0; j < g.n; ++j) { s.key[j] = g.eidx[j]; s.B[j] = g.B[j]; }
-    s.n = g.n; s.n_done = 0; s.Btot = g.Btot; s.token = 0; s.launched = false; s.used = true;
+    s.n = g.n; s.n_done = 0; s.Btot = g.Btot; s.token = 0; s.launched = false; s.used = true; s.waited = false;
     s.q_lo = 0; s.q_hi = 0;
     *out = &s;
     return ZT_OK;
@@ -228,7 +233,7 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
         int rc = zt::tppr_stream_ex(d.tppr, s.nodes, s.ts, s.eidx, s.Btot, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
                                     true, &done, s.n > 1 ? (int32_t)s.B[0] : 0);
         if (rc != ZT_OK) return rc;
-        if (done != nullptr) { s.ready_ev = done; s.launched = true; return ZT_OK; }
+        if (done != nullptr) { s.ready_ev = done; s.launched = true; s.waited = false; return ZT_OK; }
     } else {
         // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): start from zeros
         const int64_t n = row_hi - row_lo;
@@ -247,6 +252,7 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
     }
     ZT_HIP(hipEventRecord(s.ready, p->side));
     s.launched = true;
+    s.waited = false;
     s.q_lo = row_lo; s.q_hi = row_hi;
     return ZT_OK;
 }
@@ -430,9 +436,16 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         *hi = Bn == B ? row_hi : (row_hi * 3 * Bn) / (3 * B);
     };
     int rc, j = 0;
-    ZT_HIP(hipEventRecord(p->entry, p->main_s));           // everything the caller enqueued before this call (make_group)
     // ---- this batch's T-PPR query: made ahead by an earlier step, or now (with as many followers as allowed) ----
     zt_pipeline::Slot *s = find_slot(p, cur, &j);
+    // `entry` = everything the caller enqueued before this call: what a group staged on another stream must wait for
+    // (make_group).  Recorded up front -- BEFORE the main stream is told to wait for the T-PPR update -- by the calls
+    // that stage groups as a rule: a batch nobody has seen, or the first member of its group (the group after next is
+    // planned then).  The other members' steps skip it, and the wait for an update the main stream has already been
+    // told to wait for: two packets less between the GRU of one batch and the aggregation of the next (~5 us of
+    // command-processor time each; round 4).  A call that stages a group after all records it late (make_group).
+    p->entry_recorded = false;
+    if (s == nullptr || j == 0) { ZT_HIP(hipEventRecord(p->entry, p->main_s)); p->entry_recorded = true; }
     // (a batch nobody has queried ahead is queried ALONE: the aggregation waits for this launch, and a group would
     //  make it wait for the followers' updates as well; they form the next group, which runs beside this batch)
     if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, 1, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
@@ -441,7 +454,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     //  the strategy carries no state)
     if (pruning && s->launched && (s->q_lo != row_lo || s->q_hi != row_hi)) s->launched = false;
     if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
-    ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0));
+    if (!s->waited) { ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0)); s->waited = true; }
     // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
     int a = s->n - 1 - j;                     // ahead[0 .. a) are the rest of this group
     if (a < n_ahead && valid_batch(p, ahead + a)) {
