@@ -1475,11 +1475,12 @@ static int stream_cu_count(hipStream_t s)
     return c;
 }
 
-extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
-                        int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
-                        const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
-                        const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
-                        const float *proj_table_dev, int32_t weights_ready, void *stream)
+// zt_embed; mid_wait (pipeline.hip): an event the stream is told to wait for BETWEEN the aggregation and the output layer
+static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
+                      int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
+                      const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                      const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
+                      const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait)
 {
     if (!memory_dev || !efeat_dev || !wt || !status_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) {
         set_error("zt_embed: bad argument");
@@ -1585,6 +1586,7 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
                                                         wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
     }
     ZT_PROF_END(s, P_FC1_AGG);
+    if (mid_wait != nullptr) ZT_HIP(hipStreamWaitEvent(s, mid_wait, 0));
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const int hg = widek ? p.hg : 1;
     // small batches: the latency-organised kernel (one wave per tile, path and N-tile; 1 - 2 memory round trips);
@@ -1611,6 +1613,26 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
     ZT_PROF_END(s, P_EMBED_OUT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
+}
+
+extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
+                        int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
+                        const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                        const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
+                        const float *proj_table_dev, int32_t weights_ready, void *stream)
+{
+    return embed_impl(memory_dev, efeat_dev, num_nodes, num_edges, D, F, T, nodes_dev, N, M, k, nbr_dev, eix_dev, dt_dev, w_dev,
+                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, nullptr);
+}
+
+int zt::embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
+                 int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
+                 const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
+                 const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
+                 const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait)
+{
+    return embed_impl(memory_dev, efeat_dev, num_nodes, num_edges, D, F, T, nodes_dev, N, M, k, nbr_dev, eix_dev, dt_dev, w_dev,
+                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, mid_wait);
 }
 
 // Training forward of the neighbour half (backward: aggregate_bwd.hip):

@@ -44,6 +44,13 @@ int store_messages_ex(const float *memory_dev, const float *last_update_dev, con
                       int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
                       int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
                       bool *zeroed_out = nullptr, bool set_flags = true);
+// zt_embed with an event the stream waits for between the aggregation kernel and the output layer (pipeline.hip: the
+// message build; a wait packet right in front of the GRU costs the step ~6 us of command-processor time, here it is
+// processed while the aggregation runs)
+int embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T,
+             const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev, const int32_t *eix_dev,
+             const float *dt_dev, const float *w_dev, const zt_embed_weights *wt, float *out_dev, void *workspace_dev,
+             int32_t *status_dev, const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
 // the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)

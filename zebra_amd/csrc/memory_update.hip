@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                                              int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                              const float *__restrict__ Wm_p, float *__restrict__ P,
-                                             float *__restrict__ stage_h, float *__restrict__ stage_p)
+                                             float *__restrict__ stage_h, float *__restrict__ stage_p, int cap)
 {
     // stage_h != nullptr (the pipeline's staged form, gru_update_ex): the new rows and their projections go to
     // stage_h / stage_p [position in the row list][Hp] instead of the tables, last_update is left alone: k_gru_commit
@@ -132,8 +132,11 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = *n_rows;
     const int r0 = blockIdx.x * (GRU_MT * 16);
+    // the tile's node ids are requested TOGETHER with the row count, not after it (one dependent round trip less; an
+    // entry beyond the count is a stale id that nobody dereferences: every gather below is masked by g < nr)
+    const int id_spec = tid < GRU_MT * 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
+    const int total = *n_rows;
     if (r0 >= total) return;
     const int nr = (total - r0) < GRU_MT * 16 ? (total - r0) : GRU_MT * 16;
     const int Dp = Hp;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     const int nthr = 64 * GRU_WAVES;
     constexpr int GU = 8;
     int *rid = reinterpret_cast<int *>(A + (size_t)GRU_MT * 16 * lda);     // this tile's node ids
-    if (tid < GRU_MT * 16) rid[tid] = tid < nr ? rows[r0 + tid] : 0;
+    if (tid < GRU_MT * 16) rid[tid] = tid < nr ? id_spec : 0;
     __syncthreads();
     for (int f0 = tid; f0 < GRU_MT * 16 * Xp; f0 += nthr * GU) {
         float v[GU];
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     }
     if (stage_h == nullptr)
         for (int g = tid; g < nr; g += nthr) {
-            const int v = rows[r0 + g];
+            const int v = rid[g];
             last_update[v] = msg_ts[v];               // memory_updater.py:40
         }
     // ---- the projected table follows the rows just rewritten: P[v] = W_m memory'[v] (aggregate.hip, k_project_rows),
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
                                                              const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                              const float *__restrict__ Wm_p, float *__restrict__ P, int *tile_cnt,
-                                                             float *hnew, float *__restrict__ stage_p, int staged)
+                                                             float *hnew, float *__restrict__ stage_p, int staged, int cap)
 {
     // staged (see k_gru): the new rows stay in `hnew` ([position][Hp]), their projections go to stage_p, last_update is
     // left alone; the tile's last workgroup still computes the projections (they need a row's all N-tiles).
@@ -343,8 +346,10 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
     int *rid = reinterpret_cast<int *>(red + GS_WAVES * 4 * 64 * 4);     // [16] node ids; [16] = "this workgroup is the tile's last"
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
     GSTAMP(0);
-    const int total = *n_rows;
     const int r0 = blockIdx.x * 16, nt = blockIdx.y, NT = Hp / 16;
+    // (ids requested together with the row count: see k_gru)
+    const int id_spec = tid < 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
+    const int total = *n_rows;
     if (r0 >= total) return;
     const int nr = (total - r0) < 16 ? (total - r0) : 16;
     GSTAMP(1);
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
     const bool cin = col < D;
     const float bir = cin ? b_ih[col] : 0.f, biz = cin ? b_ih[D + col] : 0.f, bin = cin ? b_ih[2 * D + col] : 0.f;
     const float bhr = cin ? b_hh[col] : 0.f, bhz = cin ? b_hh[D + col] : 0.f, bhn = cin ? b_hh[2 * D + col] : 0.f;
-    if (tid < 16) rid[tid] = tid < nr ? rows[r0 + tid] : 0;
+    if (tid < 16) rid[tid] = tid < nr ? id_spec : 0;
     for (int f = tid; f < 16 * lda; f += 256) A[f] = 0.f;                // padding columns, rows beyond nr
     __syncthreads();
     GSTAMP(2);
@@ -740,7 +745,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         k_gru_split<<<dim3((unsigned)((max_rows + 15) / 16), (unsigned)(p.Hp / 16)), 64 * GS_WAVES, lds2, s>>>(
             memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih,
             wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew),
-            reinterpret_cast<float *>(ws + p.off_pnew), staged ? 1 : 0);
+            reinterpret_cast<float *>(ws + p.off_pnew), staged ? 1 : 0, (int)max_rows);
         ZT_PROF_END(s, P_GRU);
         ZT_LAUNCH_CHECK();
         return ZT_OK;
@@ -755,7 +760,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table,
                                    staged ? reinterpret_cast<float *>(ws + p.off_hnew) : nullptr,
-                                   staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr);
+                                   staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr, (int)max_rows);
     ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

@@ -35,6 +35,7 @@ struct zt_pipeline {
                                // stream's compute units: its workgroups move in as the aggregation's retire and run beside the
                                // output layer (and the scorer); the commit follows on the main stream
     hipEvent_t step_begin, msgs_done, gru_done;
+    bool early_msg_wait;       // ZT_EARLY_MSG_WAIT=0: the wait for the message build right in front of the GRU (A/B knob)
     bool stage_gru;            // ZT_GRU_STAGED=1 turns the staged form on (default: the GRU runs in line on the main stream)
     int group;                 // batches per T-PPR launch (streaming)
     struct Slot {
@@ -302,6 +303,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
     // (measured, round 4: C5 0.3516 against 0.3526 ms/step, 0.391 against 0.409 with the scorer at the tail -- but C2 0.093 ->
     //  0.141, C3 0.154 -> 0.224, C4 0.156 -> 0.181: two more stream-to-stream hand-offs on a step that is a chain of short
     //  kernels, and the output layer shares its compute units.  Off unless ZT_GRU_STAGED=1.)
+    p->early_msg_wait = !(getenv("ZT_EARLY_MSG_WAIT") && atoi(getenv("ZT_EARLY_MSG_WAIT")) == 0);
     p->stage_gru = getenv("ZT_GRU_STAGED") && atoi(getenv("ZT_GRU_STAGED")) != 0;
     ZT_HIP(hipEventCreateWithFlags(&p->gru_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
@@ -538,6 +540,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     const bool staged = p->stage_gru && zt::gru_can_stage(2 * B) && (d.proj_table == nullptr || p->embed_ready);
     const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
                                                                      : nullptr;
+    bool msgs_waited = false;
     if (staged) {
         ZT_HIP(hipStreamWaitEvent(p->gru_s, p->msgs_done, 0));
         rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
@@ -548,8 +551,12 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         ZT_HIP(hipEventRecord(p->gru_done, p->gru_s));
     }
     if (n_rows > 0) {
-        rc = zt_embed(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
-                      od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s);
+        // (the wait for the message build sits between the aggregation and the output layer -- the messages are ready long
+        //  before the aggregation ends -- so that the GRU follows the output layer without a packet in between)
+        msgs_waited = !staged && p->early_msg_wait;
+        rc = zt::embed_ex(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
+                          od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s,
+                          msgs_waited ? p->msgs_done : nullptr);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
         if (p->aff_on && whole) {                // compute_edge_probabilities' scorer (model/tgn_model.py:185-188) on the rows just written
@@ -576,7 +583,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         }
         return ZT_OK;
     }
-    ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
+    if (!msgs_waited) ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
     rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
                            nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, nullptr,
                            true);
