@@ -103,8 +103,10 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
     if (take) rows[base + __popcll(bm & ((1ull << lane) - 1ull))] = v;
 }
 
-constexpr int GRU_MT = 1;      // 16 rows per workgroup: the kernel's time is one workgroup's latency (<= 1 per CU),
-                               // so smaller tiles on more CUs win over weight-fragment reuse
+// k_gru<MT>, MT = 1:            16 rows per workgroup: the kernel's time is one workgroup's latency (<= 1 per CU),
+                               // so smaller tiles on more CUs win over weight-fragment reuse -- up to a few thousand rows;
+                               // beyond (k_gru<2>: C5's 8 192 rows = 512 tiles) every tile streams the 686 KB of gate weights
+                               // from L2 again, and 32-row tiles halve that traffic
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
@@ -118,6 +120,7 @@ __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *_
     Wp[i] = (r < D && c < K) ? W[((size_t)g * D + r) * K + c] : 0.f;
 }
 
+template <int MT>
 __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *last_update, const float *__restrict__ messages,
                                              const float *__restrict__ msg_ts, const int *__restrict__ rows,
                                              const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
@@ -132,49 +135,49 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * (GRU_MT * 16);
+    const int r0 = blockIdx.x * (MT * 16);
     // the tile's node ids are requested TOGETHER with the row count, not after it (one dependent round trip less; an
     // entry beyond the count is a stale id that nobody dereferences: every gather below is masked by g < nr)
-    const int id_spec = tid < GRU_MT * 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
+    const int id_spec = tid < MT * 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
     const int total = *n_rows;
     if (r0 >= total) return;
-    const int nr = (total - r0) < GRU_MT * 16 ? (total - r0) : GRU_MT * 16;
+    const int nr = (total - r0) < MT * 16 ? (total - r0) : MT * 16;
     const int Dp = Hp;
 
     // flat (row, column) gather, GU loads in flight per thread before any LDS store (see aggregate.hip)
     const int nthr = 64 * GRU_WAVES;
     constexpr int GU = 8;
-    int *rid = reinterpret_cast<int *>(A + (size_t)GRU_MT * 16 * lda);     // this tile's node ids
-    if (tid < GRU_MT * 16) rid[tid] = tid < nr ? id_spec : 0;
+    int *rid = reinterpret_cast<int *>(A + (size_t)MT * 16 * lda);     // this tile's node ids
+    if (tid < MT * 16) rid[tid] = tid < nr ? id_spec : 0;
     __syncthreads();
-    for (int f0 = tid; f0 < GRU_MT * 16 * Xp; f0 += nthr * GU) {
+    for (int f0 = tid; f0 < MT * 16 * Xp; f0 += nthr * GU) {
         float v[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * nthr;
             const int g = f / Xp, c = f - g * Xp;
-            v[u] = (f < GRU_MT * 16 * Xp && g < nr && c < msg_dim) ? messages[(size_t)rid[g] * msg_dim + c] : 0.f;
+            v[u] = (f < MT * 16 * Xp && g < nr && c < msg_dim) ? messages[(size_t)rid[g] * msg_dim + c] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
             const int f = f0 + u * nthr;
             const int g = f / Xp, c = f - g * Xp;
-            if (f < GRU_MT * 16 * Xp) A[(size_t)g * lda + c] = v[u];
+            if (f < MT * 16 * Xp) A[(size_t)g * lda + c] = v[u];
         }
     }
     {   // the memory columns: all of a thread's elements in flight before its first LDS store (one round trip, not four)
         constexpr int HU = 4;
-        for (int f0 = tid; f0 < GRU_MT * 16 * Hp; f0 += nthr * HU) {
+        for (int f0 = tid; f0 < MT * 16 * Hp; f0 += nthr * HU) {
             float v[HU];
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
                 const int f = f0 + u * nthr, g = f / Hp, c = f - g * Hp;
-                v[u] = (f < GRU_MT * 16 * Hp && g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
+                v[u] = (f < MT * 16 * Hp && g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < HU; ++u) {
                 const int f = f0 + u * nthr, g = f / Hp, c = f - g * Hp;
-                if (f < GRU_MT * 16 * Hp) A[(size_t)g * lda + Xp + c] = v[u];
+                if (f < MT * 16 * Hp) A[(size_t)g * lda + Xp + c] = v[u];
             }
         }
     }
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     const int NT = (D + 15) / 16;
     const int r16 = lane & 15, g4 = lane >> 4;
     // per (m-tile, n-tile): r, z (message + memory), n_i (message), n_h (memory)
-    f32x4 ar[GRU_MT][GRU_NTW], az[GRU_MT][GRU_NTW], ani[GRU_MT][GRU_NTW], anh[GRU_MT][GRU_NTW];
+    f32x4 ar[MT][GRU_NTW], az[MT][GRU_NTW], ani[MT][GRU_NTW], anh[MT][GRU_NTW];
 #pragma unroll
-    for (int a = 0; a < GRU_MT; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < GRU_NTW; ++b) {
             ar[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; az[a][b] = ar[a][b]; ani[a][b] = ar[a][b]; anh[a][b] = ar[a][b];
@@ -218,15 +221,15 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
 #pragma unroll
             for (int c = 0; c < GRU_CH; ++c) {
                 if (kc0 + c >= KC) break;
-                f32x4 av[GRU_MT];
+                f32x4 av[MT];
 #pragma unroll
-                for (int a = 0; a < GRU_MT; ++a)
+                for (int a = 0; a < MT; ++a)
                     av[a] = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + a_off + 16 * (kc0 + c) + 4 * g4);
 #pragma unroll
                 for (int b = 0; b < GRU_NTW; ++b) {
                     if (!live[b]) continue;
 #pragma unroll
-                    for (int a = 0; a < GRU_MT; ++a)
+                    for (int a = 0; a < MT; ++a)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             ar[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], wr[c][b][j], ar[a][b], 0, 0, 0);
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
         const float bir = b_ih[col], biz = b_ih[D + col], bin = b_ih[2 * D + col];
         const float bhr = b_hh[col], bhz = b_hh[D + col], bhn = b_hh[2 * D + col];
 #pragma unroll
-        for (int a = 0; a < GRU_MT; ++a)
+        for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int g = a * 16 + g4 * 4 + j;
@@ -283,20 +286,23 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
             for (int c = 0; c < 8; ++c)
                 wv[c] = c < KC ? *reinterpret_cast<const f32x4 *>(Wm_p + (size_t)(wave * 16 + r16) * Hp + 16 * c + 4 * g4)
                                : f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (c >= KC) break;
-                const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)r16 * lda + Xp + 16 * c + 4 * g4);
+            for (int a = 0; a < MT; ++a) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[c][j], acc, 0, 0, 0);
-            }
+                for (int c = 0; c < 8; ++c) {
+                    if (c >= KC) break;
+                    const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + Xp + 16 * c + 4 * g4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int g = g4 * 4 + j;
-                if (g < nr) {
-                    if (stage_p != nullptr) stage_p[(size_t)(r0 + g) * Hp + wave * 16 + r16] = acc[j];
-                    else P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[c][j], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int g = a * 16 + g4 * 4 + j;
+                    if (g < nr) {
+                        if (stage_p != nullptr) stage_p[(size_t)(r0 + g) * Hp + wave * 16 + r16] = acc[j];
+                        else P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
+                    }
                 }
             }
         }
@@ -522,7 +528,7 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.Xp = round_up(msg_dim, 16);
     p.Hp = round_up(D, 16);
     p.lda = p.Xp + p.Hp + 4;
-    p.lds = (size_t)GRU_MT * 16 * p.lda * 4 + GRU_MT * 16 * 4;   // A tile + node ids
+    p.lds = (size_t)2 * 16 * p.lda * 4 + 2 * 16 * 4;   // A tile + node ids of k_gru<2> (k_gru<1> uses half)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     // the packed weights come BEFORE the row list: their place does not depend on max_rows, so a workspace whose
@@ -750,17 +756,24 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         ZT_LAUNCH_CHECK();
         return ZT_OK;
     }
-    static size_t attr_lds = 0;
-    if (p.lds > 48 * 1024 && p.lds > attr_lds) {
-        ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)p.lds));
-        attr_lds = p.lds;
+    // many rows: 32-row tiles (half the weight traffic); ZT_GRU_MT2_MIN_ROWS moves the switch (tuning knob)
+    static const long long mt2_min = getenv("ZT_GRU_MT2_MIN_ROWS") ? atoll(getenv("ZT_GRU_MT2_MIN_ROWS")) : 4096;
+    const int mt = max_rows >= mt2_min ? 2 : 1;
+    const size_t lds = (size_t)mt * 16 * p.lda * 4 + mt * 16 * 4;
+    static size_t attr_lds[3] = {0, 0, 0};
+    if (lds > 48 * 1024 && lds > attr_lds[mt]) {
+        ZT_HIP(hipFuncSetAttribute(mt == 2 ? reinterpret_cast<const void *>(k_gru<2>) : reinterpret_cast<const void *>(k_gru<1>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds[mt] = lds;
     }
-    const unsigned grid = (unsigned)((max_rows + GRU_MT * 16 - 1) / (GRU_MT * 16));
-    k_gru<<<grid, 64 * GRU_WAVES, p.lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
-                                   p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table,
-                                   staged ? reinterpret_cast<float *>(ws + p.off_hnew) : nullptr,
-                                   staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr, (int)max_rows);
+    const unsigned grid = (unsigned)((max_rows + mt * 16 - 1) / (mt * 16));
+    float *sh = staged ? reinterpret_cast<float *>(ws + p.off_hnew) : nullptr, *sp = staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr;
+    if (mt == 2)
+        k_gru<2><<<grid, 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
+                                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table, sh, sp, (int)max_rows);
+    else
+        k_gru<1><<<grid, 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
+                                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table, sh, sp, (int)max_rows);
     ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
