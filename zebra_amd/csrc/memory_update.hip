@@ -104,9 +104,8 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 }
 
 // k_gru<MT>, MT = 1:            16 rows per workgroup: the kernel's time is one workgroup's latency (<= 1 per CU),
-                               // so smaller tiles on more CUs win over weight-fragment reuse -- up to a few thousand rows;
-                               // beyond (k_gru<2>: C5's 8 192 rows = 512 tiles) every tile streams the 686 KB of gate weights
-                               // from L2 again, and 32-row tiles halve that traffic
+                               // so smaller tiles on more CUs win over weight-fragment reuse -- also at C5's 8 192 rows
+                               // (512 tiles, each streaming the 686 KB of gate weights from L2: k_gru<2>, measured slower)
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
@@ -756,8 +755,9 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         ZT_LAUNCH_CHECK();
         return ZT_OK;
     }
-    // many rows: 32-row tiles (half the weight traffic); ZT_GRU_MT2_MIN_ROWS moves the switch (tuning knob)
-    static const long long mt2_min = getenv("ZT_GRU_MT2_MIN_ROWS") ? atoll(getenv("ZT_GRU_MT2_MIN_ROWS")) : 4096;
+    // 32-row tiles (k_gru<2>: half the weight traffic per row) from ZT_GRU_MT2_MIN_ROWS rows on -- by default never: measured
+    // at C5's 8 192 rows (tools/exp/ab_gru_mt.sh, one box, two runs each) 68.1 / 68.3 us against 64.0 / 64.1 with 16-row tiles
+    static const long long mt2_min = getenv("ZT_GRU_MT2_MIN_ROWS") ? atoll(getenv("ZT_GRU_MT2_MIN_ROWS")) : (1ll << 62);
     const int mt = max_rows >= mt2_min ? 2 : 1;
     const size_t lds = (size_t)mt * 16 * p.lda * 4 + mt * 16 * 4;
     static size_t attr_lds[3] = {0, 0, 0};
