@@ -444,7 +444,7 @@ int zt_pipeline_step(zt_pipeline *p, const zt_batch *cur, const zt_batch *next, 
  * With zt_pipeline_set_group(p, g), g <= 4, the streaming T-PPR update of g consecutive batches runs as ONE launch
  * (edges applied in order across them, exactly as in separate calls; every batch's output rows form their own
  * block), which pays a launch's fixed costs once per group; the pipeline then queries the group after the current
- * one and plans the one after that, so 3 g batches in sight keep it full (a group is only filled while a follower of it is in sight; fewer: smaller groups).  Batches of
+ * one and plans the one after that, so 3 g + 1 batches in sight keep it full (a group takes at most n - 1 of the n followers in sight along -- the last three batches of a stream are queried one by one --; fewer: smaller groups).  Batches of
  * a group are equally long (the last may be shorter) and together at most 16384 edges.  zt_pipeline_step is this
  * call with ahead = {next, plan}.  The pruning strategy carries no state between batches: its group is 1. */
 int zt_pipeline_set_group(zt_pipeline *p, int32_t group);

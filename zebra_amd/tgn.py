@@ -175,7 +175,8 @@ class TGN(torch.nn.Module):
         ``self.main_stream``.  With it, ``step_device`` takes ``prefetch`` (the NEXT batch: its T-PPR query is
         issued at once -- it must be the batch of the next call) and ``plan`` (the one after it), or ``ahead`` = the
         list of batches that follow, in order.  ``group`` > 1 (streaming strategy): the T-PPR update of that many
-        consecutive batches runs as one launch (zt_pipeline_set_group); 3 * group batches of ``ahead`` keep it full."""
+        consecutive batches runs as one launch (zt_pipeline_set_group); 3 * group + 1 batches of ``ahead`` keep it full
+        (synth.pipeline_look)."""
         if getattr(self, "_pipe", None) is not None:
             torch.cuda.synchronize(self.device)
             check(lib().zt_pipeline_destroy(self._pipe))
