@@ -272,6 +272,11 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
     memset(p, 0, sizeof(*p));
     p->d = *desc;
     p->group = 1;
+    // the staged memory update and its stream (below): only when asked for
+    // (measured, round 4: C5 0.3516 against 0.3526 ms/step, 0.391 against 0.409 with the scorer at the tail -- but C2 0.093 ->
+    //  0.141, C3 0.154 -> 0.224, C4 0.156 -> 0.181: two more stream-to-stream hand-offs on a step that is a chain of short
+    //  kernels, and the output layer shares its compute units.  Off unless ZT_GRU_STAGED=1.)
+    p->stage_gru = getenv("ZT_GRU_STAGED") && atoi(getenv("ZT_GRU_STAGED")) != 0;
     if (tppr_cus > 0) {
         hipDeviceProp_t prop;
         int dev = 0;
@@ -284,7 +289,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         // they fit beside k_stream's workgroups -- the aggregation kernel fills the register files of its own
         void *c = nullptr, *g = nullptr;
         if (rc == ZT_OK) rc = zt_stream_create_masked(&c, 0, tppr_cus);
-        if (rc == ZT_OK) rc = zt_stream_create_masked(&g, tppr_cus, prop.multiProcessorCount);
+        if (rc == ZT_OK && p->stage_gru) rc = zt_stream_create_masked(&g, tppr_cus, prop.multiProcessorCount);
         if (rc != ZT_OK) {                     // (round-3 advisor: the streams already created leaked here)
             if (a) (void)zt_stream_destroy(a);
             if (b) (void)zt_stream_destroy(b);
@@ -298,13 +303,9 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->msg_s, hipStreamNonBlocking));
-        ZT_HIP(hipStreamCreateWithFlags(&p->gru_s, hipStreamNonBlocking));
+        if (p->stage_gru) ZT_HIP(hipStreamCreateWithFlags(&p->gru_s, hipStreamNonBlocking));
     }
-    // (measured, round 4: C5 0.3516 against 0.3526 ms/step, 0.391 against 0.409 with the scorer at the tail -- but C2 0.093 ->
-    //  0.141, C3 0.154 -> 0.224, C4 0.156 -> 0.181: two more stream-to-stream hand-offs on a step that is a chain of short
-    //  kernels, and the output layer shares its compute units.  Off unless ZT_GRU_STAGED=1.)
     p->early_msg_wait = !(getenv("ZT_EARLY_MSG_WAIT") && atoi(getenv("ZT_EARLY_MSG_WAIT")) == 0);
-    p->stage_gru = getenv("ZT_GRU_STAGED") && atoi(getenv("ZT_GRU_STAGED")) != 0;
     ZT_HIP(hipEventCreateWithFlags(&p->gru_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->msgs_done, hipEventDisableTiming | zt::sync_event_flags()));
@@ -342,7 +343,8 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
     (void)hipStreamDestroy(p->side); (void)hipStreamDestroy(p->main_s); (void)hipStreamDestroy(p->plan_s);
-    (void)hipStreamDestroy(p->msg_s); (void)hipStreamDestroy(p->gru_s);
+    (void)hipStreamDestroy(p->msg_s);
+    if (p->gru_s) (void)hipStreamDestroy(p->gru_s);
     (void)hipEventDestroy(p->gru_done);
     (void)hipEventDestroy(p->scored[0]); (void)hipEventDestroy(p->scored[1]);
     (void)hipEventDestroy(p->entry); (void)hipEventDestroy(p->step_begin); (void)hipEventDestroy(p->msgs_done);
