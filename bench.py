@@ -629,7 +629,7 @@ def main():
                          "group of batches on its own stream, is timed at every launch)")
     ap.add_argument("--tppr-cus", type=int, default=-1,
                     help="pin the T-PPR stream to this many compute units (CU mask) and everything else to the rest "
-                         "(0 = no masks; default: whole XCDs -- 96 at bs >= 2048, else 32 -- for the streaming strategy, "
+                         "(0 = no masks; default: two whole XCDs = 64 for the streaming strategy, "
                          "0 for the pruning strategy, whose query kernel wants the whole chip)")
     ap.add_argument("--group", type=int, default=-1,
                     help="consecutive batches whose streaming T-PPR update runs as ONE launch (zt_pipeline_set_group); "

@@ -91,18 +91,19 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     both call it, so the tests run exactly the launch configuration that is timed.
     group: as many batches per T-PPR launch as fit (<= 16384 edges, <= 4), fewer for a short region (the first
     and the last batches of a region are queried one by one, which a 20-step run pays for with large groups);
-    1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD leaves the
-    main stream a straggler XCD) -- three for the T-PPR stream at C5's batch (its general queue needs ~53 workgroups
-    beside the hub chains: tppr_prepass.hip, d_chain_budget), two for small batches (16 hub chains x 2 models + a
-    general queue need 48 workgroups: on one XCD only 10 chains fit, measured 0.181 -> 0.153 ms/step on C3); no masks
-    for the pruning strategy, whose query kernel wants the whole chip.  (C5 on two XCDs with 5-8 chains was measured
-    in round 4 -- aggregation 216 -> 180 us on 192 CUs, k_stream 1 246 -> 1 267 us per four batches: 0.360 against 0.353
-    ms/step at 200 steps, the same at 20 -- and not adopted.)"""
+    1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD costs the
+    aggregation 55-75 %) -- two for the T-PPR stream: 16 hub chains x 2 models + a general queue need 48 workgroups
+    (on one XCD only 10 chains fit, measured 0.181 -> 0.153 ms/step on C3); at C5's batch the general queue needs ~53
+    of the 64 workgroups itself and the prepass keeps 5 chains per model (tppr_prepass.hip: d_chain_budget), which
+    costs k_stream 3 % against three XCDs with 16 chains and gives the main stream -- the bound -- 192 CUs
+    (aggregation 214 -> 176 us): C5 0.341 -> 0.333 ms/step at 200 steps, 0.385 -> 0.379 at 20 (one box, two runs each,
+    profiles/r4/experiments/cus_and_chains_c5.log); no masks for the pruning strategy, whose query kernel wants the
+    whole chip."""
     streaming = wl["strategy"] == "streaming"
     if group < 1:
         group = max(1, min(4, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
     if tppr_cus < 0:
-        tppr_cus = (96 if wl["bs"] >= 2048 else 64) if streaming else 0
+        tppr_cus = 64 if streaming else 0
     return tppr_cus, group
 
 
