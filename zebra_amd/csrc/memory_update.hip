@@ -73,6 +73,92 @@ __global__ __launch_bounds__(256) void k_build_messages(
     if (lane == 0) scratch[v] = -1;
 }
 
+// The same, TWO batch positions per wavefront with every load of both in flight before the first store (D, T <= 128,
+// F <= 256).  On the pipeline's message stream this kernel runs beside k_stream's workgroups, which leave room for ONE
+// more wave per SIMD: the kernel's time is (positions) x (a wave's chain of dependent round trips) / (4 waves per CU), and
+// a wave that carries two positions through that chain halves it (C5 on 64 CUs: 190 -> ~100 us).
+__global__ __launch_bounds__(256) void k_build_messages2(
+    const float *__restrict__ memory, const float *__restrict__ last_update, const float *__restrict__ efeat,
+    const float *__restrict__ time_w, long long num_nodes, long long num_edges, int D, int F, int T,
+    const int *__restrict__ src, const int *__restrict__ dst, const double *__restrict__ ts,
+    const long long *__restrict__ eidx, long long B, float *messages, float *msg_ts, unsigned char *flags,
+    int *scratch, int *uniq_ids, int *n_uniq, const int *status, long long pos_lo, long long pos_hi, int set_flags)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long half = (2 * B + 1) / 2;                  // wave w takes positions w and w + half
+    if (wv >= half) return;
+    const bool rejected = *status == ZT_ERR_RANGE;          // whole call rejected: only restore scratch
+    const int msg = 2 * D + F + T;
+    long long p[2] = {wv, wv + half};
+    int v[2], partner[2];
+    bool own[2], write[2];
+    float tf[2], lu[2];
+    long long e[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        own[q] = false; write[q] = false; v[q] = 0; partner[q] = 0; tf[q] = 0.f; lu[q] = 0.f; e[q] = 0;
+        if (p[q] < 2 * B) {
+            const long long i = p[q] < B ? p[q] : p[q] - B;
+            const int a = src[i], b = dst[i];
+            v[q] = p[q] < B ? a : b; partner[q] = p[q] < B ? b : a;
+            tf[q] = (float)ts[i];                            // edge_times .float() (tgn_model.py:213)
+            e[q] = eidx[i];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (p[q] < 2 * B && v[q] >= 0 && v[q] < num_nodes) { own[q] = scratch[v[q]] == (int)p[q]; lu[q] = last_update[v[q]]; }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) write[q] = own[q] && !rejected && p[q] >= pos_lo && p[q] < pos_hi;
+    // ---- all loads of both rows ----
+    float a1[2][2], a2[2][2], ef[2][4], tw[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) tw[u] = (lane + 64 * u) < T ? time_w[lane + 64 * u] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float *m1 = memory + (size_t)v[q] * D, *m2 = memory + (size_t)partner[q] * D;
+        const float *er = efeat + (size_t)e[q] * F;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = lane + 64 * u;
+            a1[q][u] = (write[q] && c < D) ? m1[c] : 0.f;
+            a2[q][u] = (write[q] && c < D) ? m2[c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = lane + 64 * u;
+            ef[q][u] = (write[q] && c < F) ? er[c] : 0.f;
+        }
+    }
+    // ---- stores ----
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (write[q]) {
+            float *row = messages + (size_t)v[q] * msg;
+            const float delta = tf[q] - lu[q];               // :221
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = lane + 64 * u;
+                if (c < D) { row[c] = a1[q][u]; row[D + c] = a2[q][u]; }
+                if (c < T) row[2 * D + F + c] = time_cosf(delta * tw[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + 64 * u;
+                if (c < F) row[2 * D + c] = ef[q][u];
+            }
+            if (lane == 0) {
+                msg_ts[v[q]] = tf[q];
+                if (set_flags) flags[v[q]] = 1;
+                if (uniq_ids) uniq_ids[atomicAdd(n_uniq, 1)] = v[q];
+                else if (n_uniq) atomicAdd(n_uniq, 1);
+            }
+        }
+        if (own[q] && lane == 0) scratch[v[q]] = -1;
+    }
+}
+
 // ------------------------------------------------------------------- GRU ----
 // Compact the flagged subset of ids (or of all nodes) into rows[]; clear the
 // flags of every id considered (Memory.clear_messages).
@@ -658,6 +744,12 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
     ZT_PROF_BEGIN(s, P_STORE_MSG);
     k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
                                                                scratch_dev, status_dev, zero_word_dev);
+    static const bool two_per_wave = !(getenv("ZT_MSG_TWO_PER_WAVE") && atoi(getenv("ZT_MSG_TWO_PER_WAVE")) == 0);   // (A/B knob)
+    if (two_per_wave && D <= 128 && T <= 128 && F <= 256)
+        k_build_messages2<<<(unsigned)(((2 * B + 1) / 2 + 3) / 4), 256, 0, s>>>(
+            memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
+            B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi, set_flags ? 1 : 0);
+    else
     k_build_messages<<<(unsigned)((2 * B + 3) / 4), 256, 0, s>>>(
         memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
         B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi, set_flags ? 1 : 0);
