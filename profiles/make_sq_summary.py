@@ -18,9 +18,12 @@ def main():
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"workload": workload, "launches_averaged": last, "kernels": {}}
-    for k in ("k_stream", "k_fc1_agg_reg<20, 0>", "k_fc1_agg_reg<40, 0>", "k_fc1_agg_d100<20>", "k_fc1_agg_d100<40>", "k_fc1_agg_d100<10>", "k_fc1_agg<true>", "k_embed_out", "k_gru",
-              "k_build_messages", "k_pruned_topk", "k_project_rows"):
-        if k not in agg:
+    # every kernel of the timed step that the pass instrumented, matched by PREFIX (template arguments and kernel
+    # generations change from round to round: a whitelist of exact names silently dropped the round-4 kernels)
+    prefixes = ("k_stream", "k_fc1_agg", "k_embed_out", "k_gru", "k_build_messages", "k_last_pos", "k_pruned_topk",
+                "k_project_rows", "k_affinity", "k_deps", "k_own", "k_reserve", "k_hot_select", "k_plan", "k_prepass")
+    for k in sorted(agg):
+        if not k.startswith(prefixes):
             continue
         c = {n: sum(v[-last:]) / len(v[-last:]) for n, v in agg[k].items()}
         wc, busy = c.get("SQ_WAVE_CYCLES", 0.0), c.get("SQ_BUSY_CYCLES", 0.0)
