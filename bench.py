@@ -264,7 +264,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     prefill = a.prefill_steps if (a.prefill_steps >= 0 and headline) else (wl["n_edges"] // 10) // bs
     # two timed regions: the metric's step (embeddings + T-PPR and memory updates: SURVEY.md 8d) and, behind it, the same
     # step with compute_edge_probabilities' scorer at its tail (model/tgn_model.py:185-188; 5 warm-up steps in between)
-    scored = world == 1 and not a.no_score and not (a.no_pipeline and headline)
+    scored = world == 1 and not a.no_score and not (a.no_pipeline and headline) and not a.exchange_world1
     n_steps_total = prefill + warmup + steps + ((5 + steps) if scored else 0)
     n_edges = n_steps_total * bs
     if n_edges > wl["n_edges"]:
@@ -273,6 +273,8 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     src, dst, neg, ts, eidx = make_stream(wl, n_edges, perm_seed=None if a.perm_seed < 0 else a.perm_seed)
     n_edge_rows = (wl["n_edges"] if F == 1 else n_edges) + 1      # F=1: the full |E|+1 zero table is cheap
     tgn = build_model(wl, device, n_edge_rows)
+    if world > 1 and os.environ.get("ZT_BENCH_REHEARSAL") == "1" and wl["strategy"] == "streaming":
+        tgn.embedding_module.tppr_finder.set_device_share(world)
     if wl["strategy"] == "pruning":
         import types
         from zebra_amd.tppr import get_neighbor_finder
@@ -290,16 +292,16 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         step = runner.step_device
     else:
         step = tgn.step_device
+    rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
 
     # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
     # its real shape against the oracle with exactly these settings)
     tppr_cus, group = synth.pipeline_settings(wl, steps, a.tppr_cus if headline else -1, a.group if headline else -1)
     no_pipeline = a.no_pipeline and headline
     if not no_pipeline:
-        # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b.  Several ranks: the same masks.
-        # torch.distributed runs the RCCL kernel of the row exchange on a stream of its own (ProcessGroupNCCL orders it
-        # against the current stream with events), so the masks neither confine nor block it.  ZT_BENCH_NO_MASKS=1
-        # switches them off.
+        # T-PPR query of batch b+1 on a side stream, beside aggregate/update of batch b.  Several ranks: the same masks; the
+        # row exchange (RCCL) is enqueued by the library on the CU-masked main stream, so it never lands on the T-PPR
+        # stream's compute units.  ZT_BENCH_NO_MASKS=1 switches the masks off.
         if os.environ.get("ZT_BENCH_NO_MASKS") == "1":
             tppr_cus = 0
         try:
@@ -311,6 +313,13 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     else:
         tppr_cus = 0
     main_stream = getattr(tgn, "main_stream", None)
+    # several ranks (or --exchange-world1): every step of the native pipeline ends with the row exchange, enqueued by the
+    # library itself (csrc/exchange.hip: pack -> ncclAllGather -> scatter -> projected-row refresh on the main stream); ranks
+    # rehearsing on ONE GPU cannot form an RCCL communicator and go through shared memory instead
+    xchg = None
+    if not no_pipeline and (world > 1 or a.exchange_world1):
+        xchg = "shm" if (rehearsal and world > 1) else "rccl"
+        tgn.enable_exchange(rank, world, transport=xchg, shm_name="zt_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), name))
 
     # views of every batch, made once: slicing tensors is host work that is not part of the path
     batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
@@ -319,9 +328,9 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                                 # it, and one more (a group is only full while a follower is in sight)
 
     # the batch loop itself: native (zt_pipeline_run: the region's steps from one host call -- the loop of
-    # evaluation/evaluation.py:19-45 in the library) unless --python-loop, several ranks (the row exchange between steps is
-    # torch.distributed) or no pipeline
-    native = world == 1 and not no_pipeline and not a.python_loop
+    # evaluation/evaluation.py:19-45 in the library, the row exchange of a multi-rank run included) unless --python-loop or
+    # no pipeline
+    native = not no_pipeline and not a.python_loop
     prepared = {}
 
     def prep(b0, nb):
@@ -402,7 +411,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         kern_a = {}
         if not a.no_profile:
             for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg", "embed_out",
-                       "store_messages", "gru_update", "gru_commit"):
+                       "store_messages", "gru_update", "exchange"):
                 n, ms = C.c_int64(), C.c_double()
                 lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
                 if n.value:
@@ -451,7 +460,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         kern = kern_a
     elif not a.no_profile:
         for kn in ("tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk", "embed_prep", "fc1_agg",
-                   "embed_out", "store_messages", "gru_update", "gru_commit"):
+                   "embed_out", "store_messages", "gru_update", "exchange"):
             n, ms = C.c_int64(), C.c_double()
             lib.zt_profile_read(kn.encode(), C.byref(n), C.byref(ms))
             if n.value:
@@ -576,9 +585,13 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                                                    wl["beta"], wl["strategy"], F, prefill, warmup),
                    "global_batch": bs, "tppr_launch_group": group, "tppr_cus": tppr_cus,
                    "clock_spin": spun, "step_loop": "native (zt_pipeline_run)" if native else "python",
+                   "row_exchange": None if xchg is None else ("in the native step: %s, %d rank%s, [id | memory row | last_update] per touched row"
+                                                               % ("RCCL ncclAllGather" if xchg == "rccl" else "shared memory (ranks share one GPU)",
+                                                                  world, "" if world == 1 else "s")),
                    "node_ids": "id == popularity rank" if a.perm_seed < 0 else "shuffled (perm_seed %d)" % a.perm_seed,
                    "parallelism": "replicated T-PPR + row-sharded aggregate x%d" % world},
         "host_enqueue_ms_per_step": 1e3 * t_host / steps,
+        "exchange_us_per_step": kern["exchange"]["avg_us"] if "exchange" in kern else None,
         # the replicated part of a multi-GPU step: every rank replays the whole batch's T-PPR chain (streaming strategy), so
         # this much of the step does not shrink with N -- a flat curve is explained by the line itself
         "chain_bound_ms_per_step": (kern["tppr_stream"]["avg_us"] * kern["tppr_stream"]["launches"] / steps / 1e3)
@@ -636,6 +649,10 @@ def main():
                          "default: as many as fit a launch (<= 16384 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--python-loop", action="store_true",
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
+    ap.add_argument("--exchange-world1", action="store_true",
+                    help="one rank WITH the row exchange of a multi-GPU run in its step loop (a world-1 RCCL communicator made by the "
+                         "library): what a one-GPU box can show of the N > 1 step -- host enqueue and kernel time of pack / all-gather "
+                         "/ scatter / refresh")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the T-PPR query on the main stream instead of overlapping it with the previous batch")
     ap.add_argument("--perm-seed", type=int, default=7,
@@ -677,9 +694,8 @@ def main():
     rehearsal = os.environ.get("ZT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-        # several ranks on ONE GPU: their k_stream grids would compete for the same CUs, and hub-chain
-        # workgroups need their whole grid resident -> no chains in the rehearsal
-        os.environ.setdefault("ZT_STREAM_CHAINS", "0")
+        # (several ranks on ONE GPU: every rank's T-PPR launches take 1 / world of the stream's CUs and run without hub
+        #  chains -- run_workload: tppr_finder.set_device_share)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -701,7 +717,7 @@ def main():
         leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
         r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
         if r is not None:
-            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "chain_bound_ms_per_step", "with_scorer",
+            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_bound_ms_per_step", "with_scorer",
                                               "roofline", "roofline_throughput_kernel", "cpu_baseline", "algorithmic", "kernels")}
     if rank == 0:
         out["rccl_ranks"] = world if (world > 1 and not rehearsal) else 0

@@ -51,6 +51,27 @@ const char *zt_version(void);
 int zt_stream_create_masked(void **stream_out, int32_t cu_lo, int32_t cu_hi);
 int zt_stream_destroy(void *stream);
 
+/* Kernel selection, for VALIDATION.  Several steps of the path have more than one kernel -- a latency-organised
+ * one for small batches, a throughput-organised one for large ones, a generic one for shapes outside the reference's
+ * default widths (train.py:33-36) -- and the library picks by shape.  zt_set_kernel_choice pins the pick process-wide
+ * (value 0 = the library's choice again) so that tests can hold the kernels against each other, and against the
+ * oracle, on the same inputs.  A pinned kernel that cannot take a shape falls back to the library's pick.  Not a
+ * tuning interface: every kernel of a selector computes the same function. */
+#define ZT_CHOICE_AGGREGATE 0   /* neighbour aggregation (zt_embed): ZT_AGG_GENERIC */
+#define ZT_CHOICE_EMBED_OUT 1   /* output layers (zt_embed): ZT_OUT_TILED, ZT_OUT_LATENCY, ZT_OUT_PERSIST */
+#define ZT_CHOICE_GRU 2         /* zt_gru_update: ZT_GRU_TILE, ZT_GRU_SPLIT */
+#define ZT_CHOICE_MESSAGES 3    /* zt_store_messages: ZT_MSG_ONE, ZT_MSG_TWO (batch positions per wavefront) */
+#define ZT_CHOICE_COUNT 4
+#define ZT_AGG_GENERIC 1
+#define ZT_OUT_TILED 1
+#define ZT_OUT_LATENCY 2
+#define ZT_OUT_PERSIST 3
+#define ZT_GRU_TILE 1
+#define ZT_GRU_SPLIT 2
+#define ZT_MSG_ONE 1
+#define ZT_MSG_TWO 2
+int zt_set_kernel_choice(int32_t which, int32_t value);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (replaces
  * the reference's unsynchronised wall-clock accumulators t_tppr etc.,
  * modules/embedding_module.py:73,220-225).  Names: tppr_prepass, tppr_stream,
@@ -73,6 +94,12 @@ typedef struct zt_tppr zt_tppr;
 int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32_t n_tppr,
                    const double *alpha_host, const double *beta_host);
 int zt_tppr_destroy(zt_tppr *h);
+/* Processes whose T-PPR update kernels share this device's compute units (default 1: the device is this
+ * process's own -- one rank per GPU, the supported multi-GPU layout).  n > 1 (several ranks rehearsing on
+ * ONE GPU): every launch takes 1/n of the CUs of its stream, so that the grids of all sharers are resident
+ * together, and runs without hub chains, whose workgroups wait for one another.  New work; the reference
+ * is one process on one device (train.py:145-146). */
+int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes);
 
 /* tppr_finder.reset_tppr (utils/util.py:419-434). */
 int zt_tppr_reset(zt_tppr *h, void *stream);
@@ -461,6 +488,39 @@ int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *
 /* n consecutive whole-batch steps from one host call (the batch loop of evaluation/evaluation.py:19-45): step b sees
  * batches b + 1 .. b + look as `ahead`, never beyond the n given; its [3 B_b][D (M + 1)] embeddings go to
  * out_emb_dev + b * out_stride floats (out_stride 0: one buffer, overwritten every step). */
+/* ---- the row exchange of a multi-GPU run inside the native step loop (no reference counterpart: the
+ * reference is one process on one device, train.py:145-146).  One process per GPU; T-PPR state and tables replicated;
+ * rank r embeds the rows shard_range(3B, r, world) of every batch, stores and applies the last messages of the winners at
+ * positions shard_range(2B, r, world), and after the GRU update of the batch the rows every rank rewrote -- [id | memory
+ * row | last_update], and [message row | message time] when with_messages -- are all-gathered with ONE fixed-size
+ * collective (cap_rows >= ceil(2 max_B / world) rows per rank), scattered into the local tables, and the projected table
+ * follows: all on the pipeline's main stream, enqueued by zt_pipeline_step_ahead / zt_pipeline_run themselves once
+ * zt_pipeline_set_exchange has been called (row_lo .. pos_hi of the step call are then this rank's shard, as before).
+ *   ZT_XCHG_RCCL: RCCL's ncclAllGather (xGMI), one rank per GPU; unique_id = the 128 bytes zt_exchange_unique_id wrote
+ *                 on rank 0, distributed by the caller; zt_exchange_create is collective (ncclCommInitRank);
+ *   ZT_XCHG_SHM : tests / rehearsals with several ranks on ONE GPU (RCCL refuses that layout): a POSIX shared-memory
+ *                 segment named shm_name, two host synchronisations per step.
+ * with_messages = 0 is enough for the eval protocol: a batch's messages are consumed by the GRU update of the step that
+ * stored them (model/tgn_model.py:159-172); a caller that compares the messages table across ranks switches it on. */
+#define ZT_XCHG_RCCL 1
+#define ZT_XCHG_SHM 2
+typedef struct {
+    int32_t rank, world, transport, with_messages;
+    const void *unique_id;         /* ZT_XCHG_RCCL: 128 bytes */
+    const char *shm_name;          /* ZT_XCHG_SHM */
+    int64_t cap_rows;
+    float *memory, *last_update, *messages, *msg_ts;   /* the tables of zt_pipeline_desc */
+    int32_t D, msg_dim;
+} zt_exchange_desc;
+typedef struct zt_exchange zt_exchange;
+int zt_exchange_unique_id(void *id_out, int64_t bytes);
+int zt_exchange_create(zt_exchange **out, const zt_exchange_desc *desc);
+int zt_exchange_set_tables(zt_exchange *x, float *memory, float *last_update, float *messages, float *msg_ts);
+int zt_exchange_destroy(zt_exchange *x);
+/* x != NULL: every step of this pipeline ends with the exchange (and zt_pipeline_run shards every batch by x's rank and
+ * world: out_emb_dev + b * out_stride then receives the rank's rows_hi - rows_lo embedding rows of step b); NULL: off.
+ * The pipeline does not own x. */
+int zt_pipeline_set_exchange(zt_pipeline *p, zt_exchange *x);
 int zt_pipeline_run(zt_pipeline *p, const zt_batch *batches, int32_t n, int32_t look, float *out_emb_dev,
                     int64_t out_stride);
 

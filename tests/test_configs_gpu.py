@@ -166,18 +166,3 @@ def test_wiki_talk_scale_config_vs_oracle(oracle):
     state and tables compared on the rows the stream touched (the others were never written on either side)."""
     worst, cus, grp = _run(oracle, "c5", 0, 6, 30, 20, touched_only=True)
     assert (cus, grp) == (64, 2)
-
-
-@pytest.mark.parametrize("name", ["c2", "c4"])
-def test_staged_gru_vs_oracle(oracle, name, monkeypatch):
-    """The pipeline's optional staged memory update (ZT_GRU_STAGED=1: the GRU's gate products on a stream of their own,
-    results in the workspace, a commit kernel on the main stream -- csrc/pipeline.hip, memory_update.hip: k_gru /
-    k_gru_split with stage buffers, k_gru_commit) gives the same step as the in-line update: C2's shape (k_gru_split's
-    row count) and C4's (k_gru's) against the oracle (model/tgn_model.py:155-172, modules/memory_updater.py:29-57)."""
-    from zebra_amd import synth
-    monkeypatch.setenv("ZT_GRU_STAGED", "1")
-    wl = synth.WORKLOADS[name]
-    if name == "c4":
-        _run(oracle, name, 1000, 4, 12, 200, csr_edges=wl["n_edges"])
-    else:
-        _run(oracle, name, 0, 20, 16, 200)

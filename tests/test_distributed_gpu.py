@@ -34,13 +34,13 @@ def _run(rank, world, port, cfg, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
-        os.environ["ZT_STREAM_CHAINS"] = "0"     # ranks share one GPU here: hub chains need a whole grid resident
-    if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         N, E, D, F, T, k, al, be, seed, bs = cfg[:10]
         strategy = cfg[10] if len(cfg) > 10 else "streaming"
         group = cfg[11] if len(cfg) > 11 else 0                # > 0: through the native pipeline, T-PPR launches over `group` batches
+        native = cfg[12] if len(cfg) > 12 else None            # "msg" / "nomsg": the exchange INSIDE the native batch loop
+                                                               # (TGN.enable_exchange, shared-memory transport: ranks share a GPU)
         src, dst, neg, ts, eidx = I.make_stream("bipartite" if strategy == "streaming" else "general", N, E, seed)
         w = I.model_weights(D, F, T, len(al), seed)
         _, efeat = I.random_tables(N, E + 1, D, F, seed)
@@ -50,6 +50,8 @@ def _run(rank, world, port, cfg, out):
             from zebra_amd.tppr import get_neighbor_finder
             nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
         tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf).eval()
+        if world > 1 and strategy == "streaming":        # ranks share one GPU here: hub chains need a whole grid resident
+            tgn.embedding_module.tppr_finder.set_device_share(world)
         runner = ShardedTGN(tgn, rank, world) if world > 1 else tgn
         dev = torch.device("cuda")
         t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
@@ -58,8 +60,23 @@ def _run(rank, world, port, cfg, out):
         if group and world > 1:
             tgn.enable_pipeline(tppr_cus=0, max_batch=bs, group=group)
         main = (getattr(tgn, "main_stream", None) if group and world > 1 else None) or torch.cuda.current_stream()
+        if native and world > 1:
+            # zt_pipeline_run shards every batch by (rank, world) and ends every step with pack -> all-gather -> scatter ->
+            # projected-row refresh itself: no Python, no torch.distributed between two steps
+            tgn.enable_exchange(rank, world, transport="shm", with_messages=(native == "msg"), shm_name="zt_test_%d" % port)
+            H = D * (len(al) + 1)
+            rows_max = max(shard_range(3 * len(c[0]), rank, world)[1] - shard_range(3 * len(c[0]), rank, world)[0] for c in batches)
+            o = torch.zeros((len(batches), rows_max, H), dtype=torch.float32, device=dev)
+            with torch.cuda.stream(main):
+                tgn.run_device(tgn.prepare_run(batches), out=o)
+            torch.cuda.synchronize()
+            for b, c in enumerate(batches):
+                lo, hi = shard_range(3 * len(c[0]), rank, world)
+                embs.append(o[b, : hi - lo].cpu().numpy())
         with torch.cuda.stream(main):
             for b, cur in enumerate(batches):
+                if native and world > 1:
+                    break
                 if group and world > 1:
                     embs.append(runner.step_device(*cur, ahead=batches[b + 1: b + 3 * group]).cpu().numpy())
                 else:
@@ -92,12 +109,19 @@ CFGS = {
     # rows its own step asks for (round-2 advisor), and the view ahead ends inside a group
     "pruning_pipe_uneven": (900, 2890, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 303, 250, "pruning", 1),
     "streaming_pipe_uneven": (600, 2390, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 304, 250, "streaming", 3),
+    # the exchange inside the native batch loop (round 5): message rows in the payload, so that table can be compared too
+    "streaming_native": (600, 2390, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 305, 250, "streaming", 2, "msg"),
+    "pruning_native": (900, 2890, 100, 1, 100, 40, [0.1, 0.1], [0.5, 0.95], 306, 250, "pruning", 1, "msg"),
+    # ... and the payload of a real run: [id | memory row | last_update] only
+    "streaming_native_nomsg": (600, 2400, 100, 172, 100, 20, [0.1, 0.1], [0.5, 0.95], 307, 200, "streaming", 2, "nomsg"),
 }
 
 
 @pytest.mark.parametrize("world,cfg_name", [(2, "streaming"), (3, "streaming"), (2, "pruning_c4"), (4, "pruning_c4"),
                                             (2, "streaming_pipe1"), (2, "streaming_pipe"), (3, "pruning_pipe"),
-                                            (4, "pruning_pipe_uneven"), (4, "streaming_pipe_uneven")])
+                                            (4, "pruning_pipe_uneven"), (4, "streaming_pipe_uneven"),
+                                            (2, "streaming_native"), (3, "streaming_native"), (4, "pruning_native"),
+                                            (2, "streaming_native_nomsg")])
 def test_sharded_equals_single(world, cfg_name):
     cfg = CFGS[cfg_name]
     mgr = mp.get_context("spawn").Manager()      # never fork a process that holds GPU handles
@@ -111,7 +135,9 @@ def test_sharded_equals_single(world, cfg_name):
         for b, e in enumerate(o["emb"]):
             lo, hi = o["shards"][b]
             assert np.array_equal(e, single["emb"][b][lo:hi]), "rank %d batch %d embeddings differ" % (r, b)
-        for kk in ("memory", "last_update", "messages", "ts", "flags"):
+        # (the payload of a real run leaves the message rows out: an eval step never reads another rank's messages)
+        tabs = ("memory", "last_update", "flags") if cfg_name.endswith("_nomsg") else ("memory", "last_update", "messages", "ts", "flags")
+        for kk in tabs:
             assert np.array_equal(o[kk], single[kk]), "rank %d %s differs from the single-GPU run" % (r, kk)
         for kk in o["state"]:
             assert np.array_equal(o["state"][kk], single["state"][kk])
@@ -154,7 +180,6 @@ def _train_run(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
-        os.environ["ZT_STREAM_CHAINS"] = "0"
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         N, E, D, F, T, k, al, be, seed, bs = 300, 640, 100, 4, 100, 20, [0.1, 0.1], [0.5, 0.95], 303, 160
@@ -162,6 +187,8 @@ def _train_run(rank, world, port, out):
         w = I.model_weights(D, F, T, len(al), seed)
         _, efeat = I.random_tables(N, E + 1, D, F, seed)
         tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat)
+        if world > 1:
+            tgn.embedding_module.tppr_finder.set_device_share(world)
         tgn.train(True)
         crit = torch.nn.BCELoss()
         runner = ShardedTGN(tgn, rank, world)
@@ -226,12 +253,23 @@ def _nccl_run(rank, port, out):
         t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
         batches = [tuple(x[b * bs:(b + 1) * bs] for x in t) for b in range(E // bs)]
         res = {}
-        for mode in ("plain", "sharded"):
+        for mode in ("plain", "sharded", "native"):
             tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
             embs = []
             if mode == "plain":
                 for cur in batches:
                     embs.append(tgn.step_device(*cur).cpu().numpy())
+            elif mode == "native":
+                # the exchange inside the library's batch loop: an RCCL communicator made by the library itself (world 1 is
+                # what one GPU allows), ncclAllGather on the CU-masked main stream
+                tgn.enable_pipeline(tppr_cus=64, max_batch=bs, group=2)
+                tgn.enable_exchange(0, 1, transport="rccl")
+                o = torch.zeros((len(batches), 3 * bs, D * 3), dtype=torch.float32, device=dev)
+                with torch.cuda.stream(tgn.main_stream):
+                    tgn.run_device(tgn.prepare_run(batches), out=o)
+                torch.cuda.synchronize()
+                embs = [o[b].cpu().numpy() for b in range(len(batches))]
+                tgn.enable_pipeline(False)
             else:
                 tgn.enable_pipeline(tppr_cus=64, max_batch=bs, group=2)
                 runner = ShardedTGN(tgn, 0, 1)
@@ -253,9 +291,11 @@ def test_rccl_exchange_on_cu_masked_streams():
     mgr = mp.get_context("spawn").Manager()
     out = mgr.dict()
     mp.spawn(_nccl_run, args=(_free_port(), out), nprocs=1, join=True)
-    a, b = out[0]["plain"], out[0]["sharded"]
+    a, b, c = out[0]["plain"], out[0]["sharded"], out[0]["native"]
     assert all(np.array_equal(x, y) for x, y in zip(a[0], b[0]))
     assert np.array_equal(a[1], b[1])
+    assert all(np.array_equal(x, y) for x, y in zip(a[0], c[0]))
+    assert np.array_equal(a[1], c[1])
 
 
 def test_bench_gpus_2_rehearsal():

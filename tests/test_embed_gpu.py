@@ -219,16 +219,15 @@ def test_grouped_tppr_launches_match_sequential(group, look, ragged):
                 assert np.array_equal(outs["seq"][m][kk], outs[mode][m][kk])
 
 
-@pytest.mark.parametrize("F,n", [(172, 400), (172, 37), (1, 512), (1, 2000), (4, 1)])
+@pytest.mark.parametrize("F,n", [(172, 400), (172, 37), (1, 512), (1, 2000), (4, 1), (1, 8192), (172, 1203)])
 def test_gru_kernels_agree(F, n):
-    """k_gru_split (a workgroup per 16 rows x N-tile, new rows committed by the tile's last workgroup: used up to 512 rows)
-    against k_gru (ZT_GRU_SPLIT_MAX_ROWS=0) and torch's GRUCell on the same flagged rows: memory, last_update, the projected
-    table; flags cleared; ragged last tile; rows the update does not name stay untouched."""
-    import os
-    import subprocess
-    import sys
+    """The two organisations of the memory update -- k_gru (16 rows per workgroup, weights streamed per tile: the library's
+    pick beyond 512 rows) and k_gru_split (a workgroup per 16 rows x N-tile, new rows committed by the tile's last workgroup)
+    -- pinned one after the other (zt_set_kernel_choice) against torch's GRUCell on the same flagged rows: memory,
+    last_update, the projected table; flags cleared; ragged last tile; rows the update does not name stay untouched."""
+    from zebra_amd import _capi
     D = T = 100
-    N, E1 = 5000, 100
+    N, E1 = 12000, 100
     w = I.model_weights(D, F, T, 2, 31)
     _, efeat = I.random_tables(N, E1, D, F, 31)
     g = torch.Generator().manual_seed(F + n)
@@ -237,49 +236,128 @@ def test_gru_kernels_agree(F, n):
     ts = torch.rand(N, generator=g) * 1e6
     ids = (torch.randperm(N - 1, generator=g)[:n] + 1).to(torch.int32)
     outs = {}
-    for mode in ("split", "tile"):
-        os.environ["ZT_GRU_SPLIT_MAX_ROWS"] = "100000" if mode == "split" else "0"
-        # the switch is read once per process: run each mode in a child
-        code = """
-import sys, numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
-import inputs as I
-from helpers import build_tgn
-D = T = 100; F = %d; N = %d
-w = I.model_weights(D, F, T, 2, 31)
-_, efeat = I.random_tables(N, 100, D, F, 31)
-tgn = build_tgn(N, 100, D, F, T, 20, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
-d = np.load(sys.argv[1])
-m = tgn.memory
-m.messages.copy_(torch.from_numpy(d["msg"]).cuda()); m.memory.copy_(torch.from_numpy(d["mem"]).cuda()); m.timestamps.copy_(torch.from_numpy(d["ts"]).cuda())
-ids = torch.from_numpy(d["ids"]).cuda()
-m._flag_buf[ids.long()] = 1
-tgn.memory_updater.update_device(m, ids, ids.numel())
-torch.cuda.synchronize()
-np.savez(sys.argv[2], mem=m.memory.cpu().numpy(), lu=m.last_update.cpu().numpy(), flags=m._flag_buf.cpu().numpy())
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
-       os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"), F, N)
-        import tempfile
-        with tempfile.TemporaryDirectory() as td:
-            np.savez(os.path.join(td, "in.npz"), msg=msg.numpy(), mem=mem0.numpy(), ts=ts.numpy(), ids=ids.numpy())
-            r = subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
-                               env=dict(os.environ), capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs[mode] = dict(np.load(os.path.join(td, "out.npz")))
-    del os.environ["ZT_GRU_SPLIT_MAX_ROWS"]
+    tgn = build_tgn(N, E1, D, F, T, 20, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
+    m = tgn.memory
+    try:
+        for mode, choice in (("tile", _capi.GRU_TILE), ("split", _capi.GRU_SPLIT), ("auto", 0)):
+            _capi.set_kernel_choice(_capi.CHOICE_GRU, choice)
+            m.messages.copy_(msg.cuda()); m.memory.copy_(mem0.cuda()); m.timestamps.copy_(ts.cuda())
+            m.last_update.zero_()
+            ids_d = ids.cuda()
+            m._flag_buf[ids_d.long()] = 1
+            table = tgn.embedding_module._projection(m)                     # the projected table follows the update
+            tgn.memory_updater.update_device(m, ids_d, ids_d.numel())
+            torch.cuda.synchronize()
+            outs[mode] = dict(mem=m.memory.cpu().numpy(), lu=m.last_update.cpu().numpy(), flags=m._flag_buf.cpu().numpy()[:N])
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_GRU, 0)
     cell = torch.nn.GRUCell(2 * D + F + T, D)
     with torch.no_grad():
         cell.weight_ih.copy_(torch.from_numpy(w["w_ih"])); cell.weight_hh.copy_(torch.from_numpy(w["w_hh"]))
         cell.bias_ih.copy_(torch.from_numpy(w["b_ih"])); cell.bias_hh.copy_(torch.from_numpy(w["b_hh"]))
         want = mem0.clone()
         want[ids.long()] = cell(msg[ids.long()], mem0[ids.long()])
-    for mode in ("split", "tile"):
-        o = outs[mode]
+    for mode, o in outs.items():
         assert np.abs(o["mem"] - want.numpy()).max() <= 1e-5, mode
         lu = np.zeros(N, np.float32); lu[ids.numpy()] = ts.numpy()[ids.numpy()]
         assert np.array_equal(o["lu"], lu), mode
         assert not o["flags"].any(), mode
     assert np.abs(outs["split"]["mem"] - outs["tile"]["mem"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("F,B", [(1, 4096), (172, 600), (300, 50), (4, 7)])
+def test_message_kernels_agree(oracle, F, B):
+    """k_build_messages2 (two batch positions per wavefront: the library's pick for D, T <= 128, F <= 256) against
+    k_build_messages (one; pinned with zt_set_kernel_choice; F = 300 takes it either way) on the same batch -- self-loops, a
+    node at many positions, a position shard -- : messages, timestamps, the winners' list and the flags equal bit for bit,
+    the scratch back at -1; and against the oracle's last-message rule (model/tgn_model.py:204-226).  An out-of-range id
+    rejects the whole call (ZT_ERR_RANGE) and leaves the tables and the scratch as they were, with either kernel."""
+    from zebra_amd import _capi
+    D = T = 100
+    N, E1 = 3000, 9000
+    w = I.model_weights(D, F, T, 2, 5)
+    mem_t, efeat = I.random_tables(N, E1, D, F, 5)
+    rng = np.random.RandomState(F + B)
+    src = rng.randint(1, N, B).astype(np.int32); dst = rng.randint(1, N, B).astype(np.int32)
+    src[::7] = 11                                    # a node at many positions
+    dst[3::11] = src[3::11]                          # self-loops
+    ts = np.cumsum(rng.rand(B) * 50.0) + 1.0e5
+    eidx = rng.randint(1, E1, B).astype(np.int64)
+    tgn = build_tgn(N, E1, D, F, T, 20, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
+    m = tgn.memory
+    lu0 = (torch.rand(N) * 9.0e4)
+    outs = {}
+    try:
+        for mode, choice in (("two", 0), ("one", _capi.MSG_ONE)):
+            _capi.set_kernel_choice(_capi.CHOICE_MESSAGES, choice)
+            for pos in (None, (B // 3, 2 * B - B // 5)):
+                m.memory.copy_(torch.from_numpy(mem_t).cuda()); m.last_update.copy_(lu0.cuda())
+                m.messages.zero_(); m.timestamps.zero_(); m._flag_buf.zero_()
+                args = [torch.from_numpy(a).cuda() for a in (src, dst, ts, eidx)]
+                tgn.store_messages_device(*args, pos_range=pos)
+                torch.cuda.synchronize()
+                assert int(tgn._status.item()) == 0
+                outs[(mode, pos is None)] = dict(msg=m.messages.cpu().numpy(), ts=m.timestamps.cpu().numpy(),
+                                                 flags=m._flag_buf.cpu().numpy()[:N].copy(), scratch=tgn._scratch.cpu().numpy())
+            # an id out of range: the call is rejected as a whole
+            bad = src.copy(); bad[B // 2] = N + 5
+            before = m.messages.clone()
+            tgn.store_messages_device(torch.from_numpy(bad).cuda(), *args[1:])
+            torch.cuda.synchronize()
+            assert int(tgn._status.item()) == _capi.ZT_ERR_RANGE, mode
+            tgn._status.zero_()
+            assert torch.equal(before, m.messages) and bool((tgn._scratch == -1).all()), mode
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_MESSAGES, 0)
+    for whole in (True, False):
+        a, b = outs[("two", whole)], outs[("one", whole)]
+        for kk in a:
+            assert np.array_equal(a[kk], b[kk]), (kk, whole)
+        assert (a["scratch"] == -1).all()
+    # the oracle's rule on the whole batch
+    mo = oracle.MemoryOracle(N, D, 2 * D + F + T)
+    mo.memory[:] = mem_t; mo.last_update[:] = lu0.numpy()
+    mo.store_messages(efeat, I.time_encode_weights(T), src, dst, ts, eidx)
+    got = outs[("two", True)]
+    touched = np.unique(np.concatenate([src, dst]))
+    assert np.abs(got["msg"][touched] - mo.messages[touched]).max() <= 1e-4
+    assert np.array_equal(got["ts"][touched], mo.timestamps[touched])
+    assert np.array_equal(got["flags"].astype(bool), mo.flags.astype(bool)[:N])
+
+
+@pytest.mark.parametrize("F,k,n", [(1, 20, 12288), (1, 40, 3000), (172, 20, 1800), (172, 40, 1030), (1, 20, 5), (4, 20, 2051)])
+def test_output_layer_kernels_agree(F, k, n):
+    """The three organisations of the output layers (fc2 of every model on the reduced rows, the source transform;
+    modules/embedding_module.py:243-246,272-276,320-328): k_embed_out (32-row workgroups, weights streamed), k_embed_out2
+    (a wave per 16 rows x path x N-tile: the pick up to 1 024 rows) and k_embed_out3 (persistent, weights resident in LDS,
+    a wave per 16 rows x all N-tiles: beyond), pinned one after the other on the same aggregation: equal to the bit (the
+    same sums in the same order), a ragged last tile, the partial-sum groups of the wide aggregation kernel included."""
+    from zebra_amd import _capi
+    D = T = 100
+    N, E1 = 5000, 20000
+    g = torch.Generator().manual_seed(3 + F + k + n)
+    w = I.model_weights(D, F, T, 2, 9)
+    _, efeat = I.random_tables(N, E1, D, F, 9)
+    tgn = build_tgn(N, E1, D, F, T, k, [0.1, 0.1], [0.5, 0.95], w, efeat).eval()
+    dev = tgn.device
+    tgn.memory.memory.copy_(torch.randn((N, D), generator=g).to(dev))
+    nodes = torch.randint(0, N, (n,), generator=g, dtype=torch.int32).to(dev)
+    on = torch.randint(0, N, (2, n, k), generator=g, dtype=torch.int32)
+    oe = torch.randint(0, E1, (2, n, k), generator=g, dtype=torch.int32)
+    od = torch.rand((2, n, k), generator=g) * 3.0e6
+    ow = torch.rand((2, n, k), generator=g)
+    ow[:, ::5] = 0.0                                      # rows whose weights sum to 0 (the bias of fc2 drops out: S = 0)
+    args = [t.to(dev).contiguous() for t in (on, oe, od.float(), ow.float())]
+    em = tgn.embedding_module
+    outs = {}
+    try:
+        for mode, choice in (("tiled", _capi.OUT_TILED), ("latency", _capi.OUT_LATENCY), ("persist", _capi.OUT_PERSIST), ("auto", 0)):
+            _capi.set_kernel_choice(_capi.CHOICE_EMBED_OUT, choice)
+            outs[mode] = em.embed_device(tgn.memory.memory, nodes, *args, memory_obj=tgn.memory).cpu().numpy()
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_EMBED_OUT, 0)
+    for mode in ("latency", "persist", "auto"):
+        assert np.array_equal(outs["tiled"], outs[mode]), mode
 
 
 @pytest.mark.parametrize("strategy,group", [("streaming", 1), ("streaming", 3), ("pruning", 1)])
@@ -1093,7 +1171,7 @@ def test_fused_training_dropout(F, k):
 def test_specialised_aggregate_equals_generic(F, k, n):
     """The specialised aggregate kernels -- k_fc1_agg_reg (F <= 4, k in {20, 40}), k_fc1_agg_wide (F = 172, k in
     {20, 40}: weights resident in LDS, M-tile units, group partial sums), k_fc1_agg_d100 (the other D = T = 100
-    shapes) -- against the generic table kernel (ZT_AGG_GENERIC=1) on the same inputs: ragged last tile, empty rows
+    shapes) -- against the generic table kernel (zt_set_kernel_choice) on the same inputs: ragged last tile, empty rows
     (all-zero weights), time gaps on both sides of the 4e6 switch."""
     import os
     D = T = 100
@@ -1115,11 +1193,12 @@ def test_specialised_aggregate_equals_generic(F, k, n):
     args = [t.to(dev).contiguous() for t in (on, oe, od.float(), ow.float())]
     em = tgn.embedding_module
     fast = em.embed_device(tgn.memory.memory, nodes, *args, memory_obj=tgn.memory).cpu().numpy()
-    os.environ["ZT_AGG_GENERIC"] = "1"
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_AGGREGATE, _capi.AGG_GENERIC)
     try:
         slow = em.embed_device(tgn.memory.memory, nodes, *args, memory_obj=tgn.memory).cpu().numpy()
     finally:
-        del os.environ["ZT_AGG_GENERIC"]
+        _capi.set_kernel_choice(_capi.CHOICE_AGGREGATE, 0)
     plain = em.embed_device(tgn.memory.memory, nodes, *args).cpu().numpy()          # no table at all
     assert np.abs(fast - slow).max() <= 2e-5 * max(1.0, np.abs(slow).max())
     assert np.abs(fast - plain).max() <= 1e-4 * max(1.0, np.abs(plain).max())

@@ -21,14 +21,29 @@ ZT_ERR_ARG, ZT_ERR_RANGE, ZT_ERR_HIP, ZT_ERR_UNSUPPORTED, ZT_ERR_TIMEOUT = -1, -
 
 # every symbol include/zebra_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
-    "zt_last_error", "zt_version", "zt_profile_enable", "zt_profile_reset", "zt_profile_read", "zt_stream_create_masked", "zt_stream_destroy",
-    "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
+    "zt_last_error", "zt_version", "zt_set_kernel_choice", "zt_profile_enable", "zt_profile_reset", "zt_profile_read", "zt_stream_create_masked", "zt_stream_destroy",
+    "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_set_device_share", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
     "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention",
     "zt_affinity_workspace_bytes", "zt_affinity", "zt_link_metrics", "zt_pipeline_set_scoring", "zt_pipeline_last_scores", "zt_pipeline_run",
+    "zt_exchange_unique_id", "zt_exchange_create", "zt_exchange_set_tables", "zt_exchange_destroy", "zt_pipeline_set_exchange",
 ]
+
+
+# zt_set_kernel_choice selectors / values (include/zebra_amd.h)
+CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES = 0, 1, 2, 3
+AGG_GENERIC = 1
+OUT_TILED, OUT_LATENCY, OUT_PERSIST = 1, 2, 3
+GRU_TILE, GRU_SPLIT = 1, 2
+MSG_ONE, MSG_TWO = 1, 2
+
+
+def set_kernel_choice(which, value):
+    """Pin one of the kernels of a step process-wide (0: the library picks by shape again) -- for tests that hold the
+    kernels against each other."""
+    check(lib().zt_set_kernel_choice(C.c_int32(which), C.c_int32(value)), "zt_set_kernel_choice")
 
 
 class RowTables(C.Structure):
@@ -62,6 +77,16 @@ class PipelineDesc(C.Structure):
                 ("ew", EmbedWeights), ("gw", GruWeights),
                 ("embed_ws", C.c_void_p), ("gru_ws", C.c_void_p), ("proj_table", C.c_void_p), ("status", C.c_void_p),
                 ("max_B", C.c_int64)]
+
+
+XCHG_RCCL, XCHG_SHM = 1, 2
+
+
+class ExchangeDesc(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("transport", C.c_int32), ("with_messages", C.c_int32),
+                ("unique_id", C.c_void_p), ("shm_name", C.c_char_p), ("cap_rows", C.c_int64),
+                ("memory", C.c_void_p), ("last_update", C.c_void_p), ("messages", C.c_void_p), ("msg_ts", C.c_void_p),
+                ("D", C.c_int32), ("msg_dim", C.c_int32)]
 
 
 class Batch(C.Structure):

@@ -29,6 +29,7 @@ SOURCES = {
     "train_ops.hip": [],
     "attention.hip": [],
     "scoring.hip": [],
+    "exchange.hip": [],
     "pipeline.hip": [],
 }
 # NOT part of the product library: direct access to device primitives for the tests (tests load it beside the library)
@@ -61,7 +62,7 @@ def build(force=False, verbose=False):
             rebuilt = True
         objs.append(op)
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lrt"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

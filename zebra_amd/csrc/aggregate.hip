@@ -18,8 +18,6 @@
 //   k_embed_out fc2 on the reduced rows, transform_source on memory[nodes]
 //               (three D x D layers, also f32 MFMA) and the concat into out[N, D*(M+1)].
 // Arithmetic is float32 throughout (parity tolerance for embeddings: 1e-4).
-#include <atomic>
-
 #include "common.hpp"
 
 using namespace zt;
@@ -1260,6 +1258,211 @@ __global__ __launch_bounds__(64) void k_embed_out2(
 }
 
 // ---------------------------------------------------------------------------
+// k_embed_out3 (round 5): the same three layers, PERSISTENT, for batches beyond k_embed_out2's reach.  k_embed_out's time
+// at 3 000-12 000 rows was rounds of dependent weight-fragment fetches from L2 per 32-row workgroup (35-40 us for 1 GFLOP
+// at C5's batch).  Here the weights live in LDS for the launch, in the order the MFMAs consume them (fragment (N-tile b,
+// k-chunk c) = 64 lanes x 4 floats, one conflict-free ds_read_b128 per four MFMAs), one workgroup per CU of the stream,
+// and every WAVE strides over (16 rows x ALL seven N-tiles) units by itself: the A operand comes straight from memory
+// into the MFMA lanes (float4 at columns 16 c + 4 g, as in k_embed_out2), the next unit's rows are requested before the
+// current unit's MFMAs, a row is read once.  Workgroups [0, n_src) take the source path (fc1s and fc2s resident: 98 KB, the
+// hidden rows through 7 KB of the wave's own LDS), the others fc2 of the M models (49 KB).  Same accumulation order as
+// the other two kernels (k-chunks first to last), so the three agree to the bit.  D = 100 (Dp = 112).
+// ---------------------------------------------------------------------------
+constexpr int EO3_NT = 7, EO3_KC = 7, EO3_DP = 112, EO3_LDY = 116;
+constexpr int EO3_FRAG = EO3_NT * EO3_KC * 256;      // floats of one weight matrix in fragment order
+
+__device__ __forceinline__ void eo3_fill(float *Wl, const float *__restrict__ Wp, int tid)
+{
+    constexpr int PER = (EO3_NT * EO3_KC * 64 + 255) / 256;             // fragments-lanes per thread: all in flight, then stored
+    f32x4 v[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int idx = tid + q * 256, frag = idx >> 6, ln = idx & 63;
+        const int b = frag / EO3_KC, c = frag - b * EO3_KC;
+        v[q] = idx < EO3_NT * EO3_KC * 64
+                   ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)(16 * b + (ln & 15)) * EO3_DP + 16 * c + 4 * (ln >> 4))
+                   : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int idx = tid + q * 256;
+        if (idx < EO3_NT * EO3_KC * 64) reinterpret_cast<f32x4 *>(Wl)[idx] = v[q];
+    }
+}
+
+template <int HG>
+__global__ __launch_bounds__(AGG_THREADS, 1) void k_embed_out3(
+    const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
+    const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
+    const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
+    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status, int n_src)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *W0 = reinterpret_cast<float *>(smem);                         // fc2 (neighbour role) / fc1s (source role)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
+    const int OW = D * (M + 1);
+    const long long tiles = (N + 15) / 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    bool cin[EO3_KC];                                                    // this lane's float4 of chunk c lies inside the row
+#pragma unroll
+    for (int c = 0; c < EO3_KC; ++c) cin[c] = 16 * c + 4 * g4 < D;
+    const f32x4 *Wf0 = reinterpret_cast<const f32x4 *>(W0) + lane;
+
+    if ((int)blockIdx.x < n_src) {
+        // ---------------- source path: memory[nodes] -> fc1s -> relu -> fc2s ----------------
+        float *W1 = W0 + EO3_FRAG;                                       // fc2s
+        float *Y = W1 + EO3_FRAG + wave * 16 * EO3_LDY;                  // this wave's hidden rows
+        eo3_fill(W0, fc1s_p, tid);
+        eo3_fill(W1, fc2s_p, tid);
+        float b1v[EO3_NT], b2v[EO3_NT];
+#pragma unroll
+        for (int b = 0; b < EO3_NT; ++b) {
+            b1v[b] = 16 * b + r16 < D ? fc1s_b[16 * b + r16] : 0.f;
+            b2v[b] = 16 * b + r16 < D ? fc2s_b[16 * b + r16] : 0.f;
+        }
+        const f32x4 *Wf1 = reinterpret_cast<const f32x4 *>(W1) + lane;
+        const long long stride = (long long)n_src * AGG_WAVES;
+        long long t = (long long)blockIdx.x * AGG_WAVES + wave;
+        // ids two units ahead, rows one unit ahead
+        auto node_of = [&](long long tt) -> int { return (tt < tiles && tt * 16 + r16 < N) ? nodes[tt * 16 + r16] : -1; };
+        auto rows_of = [&](int nd, f32x4 (&a)[EO3_KC]) {
+            const bool ok = nd >= 0 && nd < num_nodes;
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c)
+                a[c] = (ok && cin[c]) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)nd * D + 16 * c + 4 * g4) : zero4;
+        };
+        int nd_cur = node_of(t), nd_nxt = node_of(t + stride);
+        f32x4 a[EO3_KC], an[EO3_KC];
+        if (t < tiles) rows_of(nd_cur, a);
+        __syncthreads();                                                 // both weight images are in LDS
+        for (; t < tiles; t += stride) {
+            const long long r0 = t * 16;
+            if (r0 + r16 < N && (nd_cur < 0 || nd_cur >= num_nodes)) atomicExch(status, ZT_ERR_RANGE);
+            rows_of(nd_nxt, an);                                         // the next unit's rows, under this unit's MFMAs
+            nd_cur = nd_nxt;
+            nd_nxt = node_of(t + 2 * stride);
+            f32x4 acc1[EO3_NT];
+#pragma unroll
+            for (int b = 0; b < EO3_NT; ++b) acc1[b] = zero4;
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c) {
+                f32x4 w[EO3_NT];
+#pragma unroll
+                for (int b = 0; b < EO3_NT; ++b) w[b] = Wf0[(b * EO3_KC + c) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)                                  // consecutive MFMAs on different accumulators
+#pragma unroll
+                    for (int b = 0; b < EO3_NT; ++b) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], w[b][j], acc1[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < EO3_NT; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc1[b][j] + b1v[b];
+                    Y[(4 * g4 + j) * EO3_LDY + 16 * b + r16] = (16 * b + r16 < D && v > 0.f) ? v : 0.f;
+                }
+            wave_sync();
+            f32x4 acc[EO3_NT];
+#pragma unroll
+            for (int b = 0; b < EO3_NT; ++b) acc[b] = zero4;
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(Y + r16 * EO3_LDY + 16 * c + 4 * g4);
+                f32x4 w[EO3_NT];
+#pragma unroll
+                for (int b = 0; b < EO3_NT; ++b) w[b] = Wf1[(b * EO3_KC + c) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < EO3_NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[j], w[b][j], acc[b], 0, 0, 0);
+            }
+#pragma unroll
+            for (int b = 0; b < EO3_NT; ++b) {
+                const int col = 16 * b + r16;
+                if (col < D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + col] = acc[b][j] + b2v[b];
+                }
+            }
+            wave_sync();                                                 // Y is free for the next unit
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c) a[c] = an[c];
+        }
+        return;
+    }
+    // ---------------- neighbour paths: fc2 on the reduced rows of model m ----------------
+    eo3_fill(W0, fc2_p, tid);
+    float b2v[EO3_NT];
+#pragma unroll
+    for (int b = 0; b < EO3_NT; ++b) b2v[b] = 16 * b + r16 < D ? fc2_b[16 * b + r16] : 0.f;
+    const long long units = tiles * M;
+    const long long stride = (long long)((int)gridDim.x - n_src) * AGG_WAVES;
+    long long u = (long long)((int)blockIdx.x - n_src) * AGG_WAVES + wave;
+    // a unit's A operand: a query row's HG partial-sum groups (k_fc1_agg_wide), added first to last.  HG = 1: the next
+    // unit's rows are requested under this unit's MFMAs; HG > 1 (F = 172: at most a few units per wave at those batch
+    // sizes): groups [q0, q0 + GQ) at a time, at the top of the unit
+    constexpr int GQ = HG == 1 ? 1 : 5;
+    auto rows_of = [&](long long uu, int q0, f32x4 (&g)[GQ][EO3_KC]) {
+        const long long m = uu / tiles, r = (uu - m * tiles) * 16 + r16;
+        const bool rin = uu < units && r < N;
+        const float *hp = H + (((size_t)m * N + (rin ? r : 0)) * HG + q0) * D + 4 * g4;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q)
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c) g[q][c] = (rin && cin[c]) ? *reinterpret_cast<const f32x4 *>(hp + (size_t)q * D + 16 * c) : zero4;
+    };
+    f32x4 gn[GQ][EO3_KC];
+    if (HG == 1) rows_of(u, 0, gn);
+    __syncthreads();                                                     // the weight image is in LDS
+    for (; u < units; u += stride) {
+        const long long m = u / tiles, r0 = (u - m * tiles) * 16;
+        f32x4 a[EO3_KC];
+        if (HG == 1) {
+#pragma unroll
+            for (int c = 0; c < EO3_KC; ++c) a[c] = gn[0][c];
+        } else {
+#pragma nounroll
+            for (int q0 = 0; q0 < HG; q0 += GQ) {
+                rows_of(u, q0, gn);
+#pragma unroll
+                for (int c = 0; c < EO3_KC; ++c) {
+                    if (q0 == 0) a[c] = gn[0][c]; else a[c] += gn[0][c];
+#pragma unroll
+                    for (int q = 1; q < GQ; ++q) a[c] += gn[q][c];
+                }
+            }
+        }
+        float sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sv[j] = r0 + 4 * g4 + j < N ? S[(size_t)m * N + r0 + 4 * g4 + j] : 0.f;
+        if (HG == 1) rows_of(u + stride, 0, gn);                         // the next unit's rows, under this unit's MFMAs
+        f32x4 acc[EO3_NT];
+#pragma unroll
+        for (int b = 0; b < EO3_NT; ++b) acc[b] = zero4;
+#pragma unroll
+        for (int c = 0; c < EO3_KC; ++c) {
+            f32x4 w[EO3_NT];
+#pragma unroll
+            for (int b = 0; b < EO3_NT; ++b) w[b] = Wf0[(b * EO3_KC + c) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < EO3_NT; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], w[b][j], acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < EO3_NT; ++b) {
+            const int col = 16 * b + r16;
+            if (col < D) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + (size_t)D * (m + 1) + col] = acc[b][j] + b2v[b] * sv[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Projected memory table: P[v][0..Dp) = W_m memory[v] (W_m = the memory columns of fc1, zero padded to
 // [Dp][Dp]; columns >= D of P are zero).  rows == nullptr: every node; else the n rows listed (ids < 0 or
 // beyond *count are skipped): the rows a batch's GRU update / exchange has just rewritten.
@@ -1321,8 +1524,7 @@ struct EmbedPlan {
 bool tile_shape(int Kp, int Dp, int k, int T, int *lda_out, int *mt_out, int *rq_out, size_t *lds_out)
 {
     const int lda = Kp + 4;
-    static const int mt_env = getenv("ZT_AGG_MT") ? atoi(getenv("ZT_AGG_MT")) : 0;
-    int mt = (mt_env >= 1 && mt_env <= MAX_MT) ? mt_env : MAX_MT;
+    int mt = MAX_MT;
     while (mt > 1 && ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
     int rq = (mt * 16) / k;
     if (rq < 1) {
@@ -1449,32 +1651,6 @@ extern "C" int zt_project_memory(const float *memory_dev, int64_t num_nodes, int
     return ZT_OK;
 }
 
-// CUs the stream may use (CU-masked streams: the size of the mask).  Queried per call: a cache keyed by the stream
-// handle goes stale when a pipeline is destroyed and the runtime hands the same handle value to a stream with another
-// mask (round-3 advisor); the query is microseconds next to the kernels it sizes.
-static int stream_cu_count(hipStream_t s)
-{
-    static std::atomic<int> total{0};
-    int tot = total.load(std::memory_order_relaxed);
-    if (tot == 0) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        tot = prop.multiProcessorCount;
-        total.store(tot, std::memory_order_relaxed);
-    }
-    uint32_t mask[32] = {0};
-    int c = tot;
-    if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
-        int n = 0;
-        for (int q = 0; q < 32; ++q) n += __builtin_popcount(mask[q]);
-        if (n > 0 && n < tot) c = n;
-    } else {
-        (void)hipGetLastError();
-    }
-    return c;
-}
-
 // zt_embed; mid_wait (pipeline.hip): an event the stream is told to wait for BETWEEN the aggregation and the output layer
 static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
                       int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
@@ -1519,9 +1695,9 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds[tab ? 1 : 0] = lds;
     }
-    // the reference's default widths take the specialised kernel (ZT_AGG_GENERIC=1: always the generic one)
-    const bool d100 = tab && D == 100 && T == 100 && p.mt2 == 5 && (k == 10 || k == 20 || k == 40) &&
-                      !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
+    // the reference's default widths take the specialised kernels (zt_set_kernel_choice(ZT_CHOICE_AGGREGATE, ZT_AGG_GENERIC): the generic one)
+    const bool generic = zt::kernel_choice(ZT_CHOICE_AGGREGATE) == ZT_AGG_GENERIC;
+    const bool d100 = tab && D == 100 && T == 100 && p.mt2 == 5 && (k == 10 || k == 20 || k == 40) && !generic;
     static size_t attr_fast[3] = {0, 0, 0};
     if (d100 && lds > 48 * 1024) {
         const int ki = k == 10 ? 0 : (k == 20 ? 1 : 2);
@@ -1533,12 +1709,10 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
             attr_fast[ki] = lds;
         }
     }
-    // register-resident kernel: D = T = 100, F + T <= 104, k in {20, 40} (ZT_AGG_REG=0: off)
-    static const bool reg_ok = !(getenv("ZT_AGG_REG") && atoi(getenv("ZT_AGG_REG")) == 0);
-    const bool regk = reg_ok && tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p == 112 &&
-                      !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
-    // wide edge features (F = 172), D = T = 100, k in {20, 40}: weights resident in LDS (aggregate_wide.hip; ZT_AGG_WIDE=0: off)
-    const bool widek = tab && p.hg > 1 && !(getenv("ZT_AGG_GENERIC") && atoi(getenv("ZT_AGG_GENERIC")) != 0);
+    // register-resident kernel: D = T = 100, F + T <= 104, k in {20, 40}
+    const bool regk = tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p == 112 && !generic;
+    // wide edge features (F = 172), D = T = 100, k in {20, 40}: weights resident in LDS (aggregate_wide.hip)
+    const bool widek = tab && p.hg > 1 && !generic;
     ZT_PROF_BEGIN(s, P_FC1_AGG);
     if (widek) {
         const int rc = fc1_agg_wide_launch(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, N, M, k, nbr_dev, eix_dev,
@@ -1589,11 +1763,22 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     if (mid_wait != nullptr) ZT_HIP(hipStreamWaitEvent(s, mid_wait, 0));
     ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const int hg = widek ? p.hg : 1;
-    // small batches: the latency-organised kernel (one wave per tile, path and N-tile; 1 - 2 memory round trips);
-    // large ones: the throughput-organised one (weights amortised over 32-row tiles, several workgroups per CU).
-    // ZT_EMBED_OUT2_MAX_ROWS moves the switch (tuning knob; both kernels give the same results to rounding).
-    static const long long eo2_max = getenv("ZT_EMBED_OUT2_MAX_ROWS") ? atoll(getenv("ZT_EMBED_OUT2_MAX_ROWS")) : 1024;
-    if (N <= eo2_max && D % 4 == 0 && (p.Dp == 112 || p.Dp == 128) && (hg == 1 || hg == 5 || hg == 10)) {
+    // small batches: the latency-organised kernel (one wave per tile, path and N-tile; 1 - 2 memory round trips); large ones:
+    // the persistent one (weights resident in LDS, a wave per 16 rows x all N-tiles); other widths: the tiled one (weights
+    // streamed from L2 per 32-row workgroup).  zt_set_kernel_choice(ZT_CHOICE_EMBED_OUT, ..) pins one; the three give the
+    // same results (tests/test_embed_gpu.py).
+    const int oc = zt::kernel_choice(ZT_CHOICE_EMBED_OUT);
+    const bool hg_ok = hg == 1 || hg == 5 || hg == 10;
+    const bool can2 = D % 4 == 0 && (p.Dp == 112 || p.Dp == 128) && hg_ok;
+    const bool can3 = D % 4 == 0 && p.Dp == EO3_DP && hg_ok;
+    const bool use2 = can2 && (oc == ZT_OUT_LATENCY || (oc == 0 && N <= 1024));
+    // (alone on the chip, tools/exp/p23_kernels.py: 12 288 rows persist 26 us / tiled 32 / latency 53 -- 29 / 38 / 66 on 192 CUs;
+    //  3 000 rows 17 / 18 / 23; 1 800 rows with partial-sum groups 19 / 17.5 / 22; 600 rows 16.5 / 17 / 12)
+    //  In the pipeline the persistent workgroups (130 KB of LDS, a whole register file per wave) do not fit beside another
+    //  stream's kernels: C4 (3 000 rows, no CU masks, k_pruned_topk running beside) 36 us against the tiled kernel's 20; C5
+    //  (12 288 rows, the main stream's CUs to itself) 29 against 38.  So: from 8 192 rows on.
+    const bool use3 = can3 && !use2 && (oc == ZT_OUT_PERSIST || (oc == 0 && N >= 8192));
+    if (use2) {
         // one wave per (16 rows, path, N-tile), striding over the row tiles with its weights in registers
         const long long tiles = (N + 15) / 16;
         const dim3 grid((unsigned)(tiles < 256 ? tiles : 256), (unsigned)(M + 1), (unsigned)(p.Dp / 16));
@@ -1602,6 +1787,29 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         if (p.Dp == 112) { if (hg == 1) ZT_EO2(7, 1); else if (hg == 5) ZT_EO2(7, 5); else ZT_EO2(7, 10); }
         else             { if (hg == 1) ZT_EO2(8, 1); else if (hg == 5) ZT_EO2(8, 5); else ZT_EO2(8, 10); }
 #undef ZT_EO2
+    } else if (use3) {
+        // one workgroup per CU of the stream; the source path's two layers are as many MFMAs per row as M models' fc2
+        const long long tiles = (N + 15) / 16;
+        long long wgs = zt::stream_cu_count(s);
+        const long long want = (tiles * (M + 2) + AGG_WAVES - 1) / AGG_WAVES;       // (units of 196 MFMAs) / waves
+        if (wgs > want) wgs = want;
+        if (wgs < 2) wgs = 2;
+        int n_src = (int)((2 * wgs + (M + 2) / 2) / (M + 2));
+        if (n_src < 1) n_src = 1;
+        if (n_src > wgs - 1) n_src = (int)wgs - 1;
+        const size_t lds3 = (size_t)(2 * EO3_FRAG + AGG_WAVES * 16 * EO3_LDY) * 4;
+        static bool attr3[3] = {false, false, false};
+        const int hi = hg == 1 ? 0 : (hg == 5 ? 1 : 2);
+        if (!attr3[hi]) {
+            const void *fn = hg == 1 ? reinterpret_cast<const void *>(k_embed_out3<1>)
+                                     : (hg == 5 ? reinterpret_cast<const void *>(k_embed_out3<5>) : reinterpret_cast<const void *>(k_embed_out3<10>));
+            ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            attr3[hi] = true;
+        }
+#define ZT_EO3(HGV) k_embed_out3<HGV><<<(unsigned)wgs, AGG_THREADS, lds3, s>>>(memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, \
+            wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b, out_dev, status_dev, n_src)
+        if (hg == 1) ZT_EO3(1); else if (hg == 5) ZT_EO3(5); else ZT_EO3(10);
+#undef ZT_EO3
     } else {
         const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
 #define ZT_EO(HGV) k_embed_out<HGV><<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>( \

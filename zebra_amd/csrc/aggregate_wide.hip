@@ -365,8 +365,7 @@ namespace zt {
 
 bool fc1_agg_wide_supported(int D, int F, int T, int k)
 {
-    static const bool on = !(getenv("ZT_AGG_WIDE") && atoi(getenv("ZT_AGG_WIDE")) == 0);
-    return on && D == WD && T == WT && F == WF && (k == 20 || k == 40);
+    return D == WD && T == WT && F == WF && (k == 20 || k == 40);
 }
 
 size_t fc1_agg_wide_weight_bytes() { return (size_t)WPACK_FLOATS * 4; }

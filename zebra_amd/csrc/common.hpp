@@ -17,7 +17,7 @@ void set_error(const char *fmt, ...);
 // an event pair is recorded on the launch stream around the kernel; elapsed
 // times are summed per kernel name when the profile is read.
 enum ProfId { P_PREPASS = 0, P_STREAM, P_CLEANUP, P_PRUNE, P_EMBED_PREP, P_FC1_AGG, P_EMBED_OUT, P_STORE_MSG, P_GRU,
-              P_SCORE, P_GRU_COMMIT, P_COUNT };
+              P_SCORE, P_EXCHANGE, P_COUNT };
 extern bool g_prof_on;
 void prof_begin(hipStream_t s, int id);
 void prof_end(hipStream_t s, int id);
@@ -26,17 +26,13 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
                    int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                    float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
                    hipEvent_t *done_out, int32_t sub_B);
-// zt_gru_update with the projected-table refresh folded into the GRU kernel (memory_update.hip); wm_p from embed_wm_ptr
+// zt_gru_update with the projected-table refresh folded into the GRU kernel (memory_update.hip); wm_p from embed_wm_ptr.
+// counter_zeroed: the row counter (first word of the workspace) is zero already; select_done: the row list and the counter
+// are filled (pipeline.hip: the message kernel hands its list of winners over), no compaction of flagged ids
 int gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                   const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, void *select_stream = nullptr,
-                  bool select_done = false, bool staged = false);
-// staged = true: the kernel only READS the tables (new rows and projections go to the workspace); gru_commit_ex, later and
-// possibly on another stream, writes them to memory / proj_table / last_update.  Same workspace and id count for both.
-bool gru_can_stage(int64_t max_rows);
-int gru_commit_ex(float *memory_dev, float *last_update_dev, const float *msg_ts_dev, int32_t D, int32_t msg_dim,
-                  int64_t max_rows, void *workspace_dev, float *proj_table, void *stream);
+                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, bool select_done = false);
 // zt_store_messages_range that also zeroes one int (the GRU update's row counter: first word of its workspace)
 int store_messages_ex(const float *memory_dev, const float *last_update_dev, const float *efeat_dev, const float *time_w_dev,
                       int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,
@@ -60,14 +56,20 @@ void fc1_agg_wide_pack(const float *fc1_w_dev, const float *time_w_dev, const fl
 int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w, long long num_nodes, long long num_edges,
                         long long N, int M, int k, const int *nbr, const int *eix, const float *dt, const float *w,
                         const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s);
+void tppr_hint_cus(zt_tppr *h, hipStream_t s);      // tppr_prepass.hip: plan for the compute units of stream s
+// exchange.hip: the row exchange of one step of a multi-GPU run on `stream` (pack -> all-gather -> scatter); the ids of
+// the rows written (-1: padding) come back for the projected-row refresh
+int exchange_step(zt_exchange *x, const int32_t *rows_dev, const int32_t *count_dev, void *stream, const int32_t **ids_out,
+                  int64_t *n_ids_out);
+void exchange_shape(const zt_exchange *x, int *rank, int *world);
 constexpr int TPPR_MAX_LAUNCH = 16384;     // edges one T-PPR launch can cover (tppr_stream.hip: MAX_CHUNK)
 
-// extra flags for events that only order streams of this device (experiment knob: ZT_EVENT_FLAGS, hex)
-inline unsigned sync_event_flags()
-{
-    static const unsigned f = getenv("ZT_EVENT_FLAGS") ? (unsigned)strtoul(getenv("ZT_EVENT_FLAGS"), nullptr, 16) : 0u;
-    return f;
-}
+// flags of the events that only order streams of this device
+inline unsigned sync_event_flags() { return 0u; }
+// zt_set_kernel_choice: 0 = the library picks by shape (runtime.hip)
+int kernel_choice(int which);
+// CUs a stream may use (CU-masked streams: the size of the mask; queried per call -- runtime.hip)
+int stream_cu_count(hipStream_t s);
 #define ZT_PROF_BEGIN(s, id) do { if (zt::g_prof_on) zt::prof_begin((s), (id)); } while (0)
 #define ZT_PROF_END(s, id) do { if (zt::g_prof_on) zt::prof_end((s), (id)); } while (0)
 

@@ -211,12 +211,8 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                                              const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
                                              int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
-                                             const float *__restrict__ Wm_p, float *__restrict__ P,
-                                             float *__restrict__ stage_h, float *__restrict__ stage_p, int cap)
+                                             const float *__restrict__ Wm_p, float *__restrict__ P, int cap)
 {
-    // stage_h != nullptr (the pipeline's staged form, gru_update_ex): the new rows and their projections go to
-    // stage_h / stage_p [position in the row list][Hp] instead of the tables, last_update is left alone: k_gru_commit
-    // writes all three later.  The kernel then only READS the tables and may run beside the aggregation that reads them too.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,16 +346,14 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
                 const float n = tanhf(ani[a][b][j] + bin + r * (anh[a][b][j] + bhn));
                 const float hold = A[(size_t)g * lda + Xp + col];
                 const float hnew = (1.f - z) * n + z * hold;
-                if (stage_h != nullptr) stage_h[(size_t)(r0 + g) * Hp + col] = hnew;
-                else memory[(size_t)rid[g] * D + col] = hnew;
+                memory[(size_t)rid[g] * D + col] = hnew;
                 if (P != nullptr) A[(size_t)g * lda + Xp + col] = hnew;    // (this thread alone reads and writes the element)
             }
     }
-    if (stage_h == nullptr)
-        for (int g = tid; g < nr; g += nthr) {
-            const int v = rid[g];
-            last_update[v] = msg_ts[v];               // memory_updater.py:40
-        }
+    for (int g = tid; g < nr; g += nthr) {
+        const int v = rid[g];
+        last_update[v] = msg_ts[v];               // memory_updater.py:40
+    }
     // ---- the projected table follows the rows just rewritten: P[v] = W_m memory'[v] (aggregate.hip, k_project_rows),
     // ---- here from the new rows while they are still in LDS: one kernel and one pass over the rows less per step
     if (P != nullptr) {
@@ -384,10 +378,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int g = a * 16 + g4 * 4 + j;
-                    if (g < nr) {
-                        if (stage_p != nullptr) stage_p[(size_t)(r0 + g) * Hp + wave * 16 + r16] = acc[j];
-                        else P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
-                    }
+                    if (g < nr) P[(size_t)rid[g] * Hp + wave * 16 + r16] = acc[j];
                 }
             }
         }
@@ -419,7 +410,6 @@ constexpr int GS_MAXCH = 10;         // chunks of 16 k-columns per wave: (Xp + H
 constexpr int GS_STAGE = 37;         // staged elements per thread: 16 (msg + D) <= 37 * 256
 constexpr int GS_TILE_COUNTERS = 512;
 constexpr int GS_MAX_ROWS = GS_TILE_COUNTERS * 16;
-constexpr long long GRU_STAGE_MAX_ROWS = 65536;     // staged updates (and their workspace areas) up to this many ids
 
 __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, float *last_update, const float *__restrict__ messages,
                                                              const float *__restrict__ msg_ts, const int *__restrict__ rows,
@@ -427,10 +417,8 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
                                                              const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
                                                              const float *__restrict__ b_ih, const float *__restrict__ b_hh,
                                                              const float *__restrict__ Wm_p, float *__restrict__ P, int *tile_cnt,
-                                                             float *hnew, float *__restrict__ stage_p, int staged, int cap)
+                                                             float *hnew, int cap)
 {
-    // staged (see k_gru): the new rows stay in `hnew` ([position][Hp]), their projections go to stage_p, last_update is
-    // left alone; the tile's last workgroup still computes the projections (they need a row's all N-tiles).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *A = reinterpret_cast<float *>(smem);                          // [16][lda]: [message (Xp) | memory (Hp)], zero padded
     float *red = A + 16 * lda;                                           // [4 waves][4 sums][64 lanes][4]
@@ -527,9 +515,9 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
                 st_agent(reinterpret_cast<int *>(hnew + (size_t)(r0 + g) * Hp + col), __float_as_int((1.f - z) * n + z * hold));
             }
         }
-        if (!staged && nt == 0 && lane < nr) { const int v = rid[lane]; last_update[v] = msg_ts[v]; }      // memory_updater.py:40
-        // ---- arrive: the tile's last workgroup commits ----
-        __threadfence();
+        if (nt == 0 && lane < nr) { const int v = rid[lane]; last_update[v] = msg_ts[v]; }      // memory_updater.py:40
+        // ---- arrive: the tile's last workgroup commits (sc1 stores drained, no fence: see k_gru_persist) ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int done = 0;
         if (lane == 0) done = atomicAdd(&tile_cnt[blockIdx.x], 1);
         done = __builtin_amdgcn_readfirstlane(done);
@@ -538,8 +526,8 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
     __syncthreads();
     GSTAMP(6);
     if (rid[16] == 0) return;
-    // ---- every N-tile of these 16 rows has been computed from the OLD rows: new rows -> memory table, -> projected table ----
-    __threadfence();
+    // ---- every N-tile of these 16 rows has been computed from the OLD rows: new rows -> memory table, -> projected table
+    // (read with sc1 loads: served by L2, where the other workgroups' drained sc1 stores are) ----
     {
         constexpr int CU = 7;                                            // 16 x Hp <= 7 * 256
         float v[CU];
@@ -552,7 +540,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
         for (int q = 0; q < CU; ++q) {
             const int f = tid + q * 256, g = f / Hp, c = f - g * Hp;
             if (g < 16 && c < Hp) A[g * lda + Xp + c] = v[q];
-            if (!staged && g < nr && c < D) memory[(size_t)rid[g] * D + c] = v[q];
+            if (g < nr && c < D) memory[(size_t)rid[g] * D + c] = v[q];
         }
     }
     GSTAMP(7);
@@ -575,37 +563,22 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int g = 4 * g4 + j;
-            if (g < nr) {
-                if (staged) stage_p[(size_t)(r0 + g) * Hp + 16 * b + r16] = acc[j];
-                else P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
-            }
+            if (g < nr) P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
         }
     }
 }
 
-// The second half of a staged update: row i of the list -> memory[rows[i]] = stage_h[i], P[rows[i]] = stage_p[i],
-// last_update[rows[i]] = msg_ts[rows[i]] (memory_updater.py:40).  One wavefront per row.
-__global__ __launch_bounds__(256) void k_gru_commit(float *__restrict__ memory, float *__restrict__ last_update,
-                                                    const float *__restrict__ msg_ts, const int *__restrict__ rows,
-                                                    const int *__restrict__ n_rows, int D, int Hp,
-                                                    const float *__restrict__ stage_h, const float *__restrict__ stage_p,
-                                                    float *__restrict__ P)
-{
-    const int lane = threadIdx.x & 63, total = *n_rows;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += gridDim.x * 4) {
-        const int v = rows[i];
-        for (int c = lane; c < Hp; c += 64) {
-            const float h = stage_h[(size_t)i * Hp + c];
-            if (c < D) memory[(size_t)v * D + c] = h;
-            if (P != nullptr) P[(size_t)v * Hp + c] = stage_p[(size_t)i * Hp + c];
-        }
-        if (lane == 0) last_update[v] = msg_ts[v];
-    }
-}
+// (Round 5, measured and removed: k_gru_persist -- k_gru_split with a workgroup's weight fragments kept in registers over a
+//  loop of row tiles, the next tile's rows in flight under the current tile's MFMAs.  The split needs a cross-workgroup
+//  arrival per tile -- drained sc1 stores, a returning atomic, two barriers -- that a persistent loop pays per TILE where
+//  k_gru_split pays it once per workgroup: 8 192 rows 137 us against k_gru's 66, 2 000 rows 47 against 30, 1 200 rows
+//  (message 472 wide) 43 against 37; only at 400 rows 25 against 27.  tools/exp/p23_kernels.py, profiles/r5/experiments/.)
+constexpr int GP_TILE_COUNTERS = GS_TILE_COUNTERS;
+constexpr long long GP_MAX_ROWS = (long long)GS_MAX_ROWS;
 
 struct GruPlan {
     int Xp, Hp, lda;
-    size_t lds, off_rows, off_cnt, off_wih, off_whh, off_tiles, off_hnew, off_pnew, total;
+    size_t lds, off_rows, off_cnt, off_wih, off_whh, off_tiles, off_hnew, total;
 };
 
 void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
@@ -621,12 +594,10 @@ void gru_plan(int64_t max_rows, int D, int msg_dim, GruPlan &p)
     p.off_cnt = take(256);
     p.off_wih = take((size_t)3 * p.Hp * p.Xp * 4);
     p.off_whh = take((size_t)3 * p.Hp * p.Hp * 4);
-    p.off_tiles = take((size_t)GS_TILE_COUNTERS * 4);                    // k_gru_split: arrival counters per tile (zeroed with the weights)
+    p.off_tiles = take((size_t)GP_TILE_COUNTERS * 4);                    // k_gru_split / k_gru_persist: arrival counters per tile (zeroed with the weights)
     p.off_rows = take((size_t)(max_rows > 0 ? max_rows : 1) * 4);
-    // new rows until the commit (k_gru_split always; k_gru in the staged form) and, staged, their projections
-    const size_t stage = max_rows > 0 && max_rows <= GRU_STAGE_MAX_ROWS ? (size_t)((max_rows + 15) / 16 * 16) * p.Hp * 4 : 0;
-    p.off_hnew = take(stage);
-    p.off_pnew = take(stage);
+    // new rows until the tile's commit (k_gru_split, k_gru_persist)
+    p.off_hnew = take(max_rows > 0 && max_rows <= GP_MAX_ROWS ? (size_t)((max_rows + 15) / 16 * 16) * p.Hp * 4 : 0);
     p.total = o;
 }
 
@@ -744,8 +715,8 @@ int zt::store_messages_ex(const float *memory_dev, const float *last_update_dev,
     ZT_PROF_BEGIN(s, P_STORE_MSG);
     k_last_pos<<<(unsigned)((2 * B + 255) / 256), 256, 0, s>>>(src_dev, dst_dev, e64, B, num_nodes, num_edges,
                                                                scratch_dev, status_dev, zero_word_dev);
-    static const bool two_per_wave = !(getenv("ZT_MSG_TWO_PER_WAVE") && atoi(getenv("ZT_MSG_TWO_PER_WAVE")) == 0);   // (A/B knob)
-    if (two_per_wave && D <= 128 && T <= 128 && F <= 256)
+    // two positions per wave where the shape allows (zt_set_kernel_choice(ZT_CHOICE_MESSAGES, ZT_MSG_ONE) pins the other kernel)
+    if (zt::kernel_choice(ZT_CHOICE_MESSAGES) != ZT_MSG_ONE && D <= 128 && T <= 128 && F <= 256)
         k_build_messages2<<<(unsigned)(((2 * B + 1) / 2 + 3) / 4), 256, 0, s>>>(
             memory_dev, last_update_dev, efeat_dev, time_w_dev, num_nodes, num_edges, D, F, T, src_dev, dst_dev, ts_dev, e64,
             B, messages_dev, msg_ts_dev, flags_dev, scratch_dev, uniq_ids_dev, n_uniq_dev, status_dev, pos_lo, pos_hi, set_flags ? 1 : 0);
@@ -781,7 +752,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
                              const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready, void *stream)
 {
     return zt::gru_update_ex(memory_dev, last_update_dev, messages_dev, msg_ts_dev, flags_dev, num_nodes, D, msg_dim, ids_dev,
-                             n_ids, n_ids_dev, wt, workspace_dev, weights_ready, nullptr, nullptr, stream, false, nullptr, false);
+                             n_ids, n_ids_dev, wt, workspace_dev, weights_ready, nullptr, nullptr, stream, false, false);
 }
 
 // zt_gru_update with the refresh of the projected table folded in (pipeline.hip): wm_p = W_m padded to [Dp][Dp]
@@ -789,8 +760,7 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
 int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                       uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                       const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, void *select_stream, bool select_done,
-                      bool staged)
+                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, bool select_done)
 {
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
@@ -803,36 +773,30 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
     GruPlan p;
     gru_plan(max_rows, D, msg_dim, p);
     if (p.lds > 150 * 1024) { set_error("zt_gru_update: message width %d too large", msg_dim); return ZT_ERR_UNSUPPORTED; }
-    if (staged && max_rows > GRU_STAGE_MAX_ROWS) { set_error("zt_gru_update: staged form for at most %lld ids", GRU_STAGE_MAX_ROWS); return ZT_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     char *ws = reinterpret_cast<char *>(workspace_dev);
     int *cnt = reinterpret_cast<int *>(ws + p.off_cnt);
     int *rows = reinterpret_cast<int *>(ws + p.off_rows);
     float *wih = reinterpret_cast<float *>(ws + p.off_wih);
     float *whh = reinterpret_cast<float *>(ws + p.off_whh);
-    // select_stream (pipeline.hip): the compaction of the flagged ids runs where the flags were set -- on the message
-    // stream, behind the message kernels and beside the aggregation -- instead of on the caller's stream in front of the
-    // GRU; the caller orders `stream` behind it
-    hipStream_t sel = select_stream ? (hipStream_t)select_stream : s;
-    if (!counter_zeroed && !select_done) ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), sel));
-    if (select_stream) {
-        k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, sel>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev, rows, cnt);
-        ZT_LAUNCH_CHECK();
-        return ZT_OK;                           // (the GRU itself: a second call with select_done)
-    }
+    if (!counter_zeroed && !select_done) ZT_HIP(hipMemsetAsync(cnt, 0, sizeof(int), s));
     ZT_PROF_BEGIN(s, P_GRU);
     if (!select_done)
         k_select_flagged<<<(unsigned)((max_rows + 255) / 256), 256, 0, s>>>(ids_dev, n_ids, n_ids_dev, num_nodes, flags_dev, rows, cnt);
     if (!weights_ready) {                       // gate-packed, padded copies: once per weight change
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
-        ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GS_TILE_COUNTERS * 4, s));
+        ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GP_TILE_COUNTERS * 4, s));
     }
-    // few rows: a workgroup per (tile, N-tile) -- the whole chip works on what k_gru gives to a tenth of it; many rows: k_gru
-    // (several workgroups per CU, a row tile's weights fetched once).  ZT_GRU_SPLIT_MAX_ROWS moves the switch (tuning knob).
-    static const long long split_max = getenv("ZT_GRU_SPLIT_MAX_ROWS") ? atoll(getenv("ZT_GRU_SPLIT_MAX_ROWS")) : 512;
-    if (max_rows <= split_max && max_rows <= GS_MAX_ROWS && (p.Xp + p.Hp) / 16 <= GS_WAVES * GS_MAXCH &&
-        16 * (msg_dim + D) <= GS_STAGE * 256 && 16 * p.Hp <= 7 * 256) {
+    // Two organisations of the same update (zt_set_kernel_choice(ZT_CHOICE_GRU, ..) pins one; tests hold them against each
+    // other and torch's GRUCell):
+    //   k_gru_split   <= 512 rows: a workgroup per (16 rows, N-tile) -- the whole chip works on what k_gru gives a tenth of it;
+    //   k_gru         beyond: 16 rows per workgroup, the gate weights streamed from L2 per tile.
+    const int choice = zt::kernel_choice(ZT_CHOICE_GRU);
+    const bool fits = max_rows <= GS_MAX_ROWS && (p.Xp + p.Hp) / 16 <= GS_WAVES * GS_MAXCH && 16 * (msg_dim + D) <= GS_STAGE * 256 &&
+                      16 * p.Hp <= 7 * 256;
+    const bool split = fits && (choice == ZT_GRU_SPLIT || (choice == 0 && max_rows <= 512));
+    if (split) {
         const size_t lds2 = ((size_t)16 * p.lda + (size_t)GS_WAVES * 4 * 64 * 4) * 4 + 32 * 4;
         static size_t attr2 = 0;
         if (lds2 > 48 * 1024 && lds2 > attr2) {
@@ -842,57 +806,19 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         k_gru_split<<<dim3((unsigned)((max_rows + 15) / 16), (unsigned)(p.Hp / 16)), 64 * GS_WAVES, lds2, s>>>(
             memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih,
             wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew),
-            reinterpret_cast<float *>(ws + p.off_pnew), staged ? 1 : 0, (int)max_rows);
-        ZT_PROF_END(s, P_GRU);
-        ZT_LAUNCH_CHECK();
-        return ZT_OK;
+            (int)max_rows);
+    } else {
+        const size_t lds = (size_t)16 * p.lda * 4 + 16 * 4;
+        static size_t attr_lds = 0;
+        if (lds > 48 * 1024 && lds > attr_lds) {
+            ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_lds = lds;
+        }
+        k_gru<1><<<(unsigned)((max_rows + 15) / 16), 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt,
+                                                                         D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh,
+                                                                         wm_p, proj_table, (int)max_rows);
     }
-    // 32-row tiles (k_gru<2>: half the weight traffic per row) from ZT_GRU_MT2_MIN_ROWS rows on -- by default never: measured
-    // at C5's 8 192 rows (tools/exp/ab_gru_mt.sh, one box, two runs each) 68.1 / 68.3 us against 64.0 / 64.1 with 16-row tiles
-    static const long long mt2_min = getenv("ZT_GRU_MT2_MIN_ROWS") ? atoll(getenv("ZT_GRU_MT2_MIN_ROWS")) : (1ll << 62);
-    const int mt = max_rows >= mt2_min ? 2 : 1;
-    const size_t lds = (size_t)mt * 16 * p.lda * 4 + mt * 16 * 4;
-    static size_t attr_lds[3] = {0, 0, 0};
-    if (lds > 48 * 1024 && lds > attr_lds[mt]) {
-        ZT_HIP(hipFuncSetAttribute(mt == 2 ? reinterpret_cast<const void *>(k_gru<2>) : reinterpret_cast<const void *>(k_gru<1>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds[mt] = lds;
-    }
-    const unsigned grid = (unsigned)((max_rows + mt * 16 - 1) / (mt * 16));
-    float *sh = staged ? reinterpret_cast<float *>(ws + p.off_hnew) : nullptr, *sp = staged ? reinterpret_cast<float *>(ws + p.off_pnew) : nullptr;
-    if (mt == 2)
-        k_gru<2><<<grid, 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
-                                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table, sh, sp, (int)max_rows);
-    else
-        k_gru<1><<<grid, 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp,
-                                                    p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh, wm_p, proj_table, sh, sp, (int)max_rows);
     ZT_PROF_END(s, P_GRU);
-    ZT_LAUNCH_CHECK();
-    return ZT_OK;
-}
-
-bool zt::gru_can_stage(int64_t max_rows) { return max_rows > 0 && max_rows <= GRU_STAGE_MAX_ROWS; }
-
-// The commit of a staged gru_update_ex (same workspace, same max_rows): rows, projections and last_update into the tables.
-int zt::gru_commit_ex(float *memory_dev, float *last_update_dev, const float *msg_ts_dev, int32_t D, int32_t msg_dim,
-                      int64_t max_rows, void *workspace_dev, float *proj_table, void *stream)
-{
-    if (!memory_dev || !last_update_dev || !msg_ts_dev || !workspace_dev || D <= 0 || msg_dim <= 0 || !gru_can_stage(max_rows)) {
-        set_error("zt_gru_commit: bad argument");
-        return ZT_ERR_ARG;
-    }
-    GruPlan p;
-    gru_plan(max_rows, D, msg_dim, p);
-    char *ws = reinterpret_cast<char *>(workspace_dev);
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((max_rows + 3) / 4);
-    ZT_PROF_BEGIN(s, P_GRU_COMMIT);
-    k_gru_commit<<<grid < 2048u ? grid : 2048u, 256, 0, s>>>(memory_dev, last_update_dev, msg_ts_dev,
-                                                             reinterpret_cast<const int *>(ws + p.off_rows),
-                                                             reinterpret_cast<const int *>(ws + p.off_cnt), D, p.Hp,
-                                                             reinterpret_cast<const float *>(ws + p.off_hnew),
-                                                             reinterpret_cast<const float *>(ws + p.off_pnew), proj_table);
-    ZT_PROF_END(s, P_GRU_COMMIT);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

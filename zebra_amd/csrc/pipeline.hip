@@ -31,12 +31,7 @@ struct zt_pipeline {
     zt_pipeline_desc d;
     hipStream_t side, main_s, plan_s;
     hipStream_t msg_s;         // the message build of the current batch, beside its aggregation (reads the memory tables only)
-    hipStream_t gru_s;         // the GRU's gate products of the current batch (staged: they only read the tables), on the main
-                               // stream's compute units: its workgroups move in as the aggregation's retire and run beside the
-                               // output layer (and the scorer); the commit follows on the main stream
-    hipEvent_t step_begin, msgs_done, gru_done;
-    bool early_msg_wait;       // ZT_EARLY_MSG_WAIT=0: the wait for the message build right in front of the GRU (A/B knob)
-    bool stage_gru;            // ZT_GRU_STAGED=1 turns the staged form on (default: the GRU runs in line on the main stream)
+    hipEvent_t step_begin, msgs_done;
     int group;                 // batches per T-PPR launch (streaming)
     struct Slot {
         int32_t *nodes;        // [3 * cap]   src of every member | dst ... | neg ...   (role stride = Btot)
@@ -78,6 +73,7 @@ struct zt_pipeline {
     hipEvent_t scored[2];
     int score_n;               // scorings enqueued so far (parity = which half / which event)
     int64_t score_B;           // batch size of the last one
+    zt_exchange *xchg;         // zt_pipeline_set_exchange: the row exchange of a multi-GPU run at the end of every step (or NULL)
 };
 
 namespace {
@@ -185,9 +181,7 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     // them along: the last THREE batches of a region are queried one by one (round 4; two before: the driver's 20-step
     // run ended with a two-batch launch and two aggregations behind it) and the aggregation of each runs beside the update
     // of the next.  A full group needs want + 1 followers in sight (synth.pipeline_look).
-    static const bool taper3 = !(getenv("ZT_GROUP_TAPER") && atoi(getenv("ZT_GROUP_TAPER")) == 0);     // (A/B knob: 0 = round 3's rule)
-    if (taper3) { if (n_more <= want) want = n_more >= 2 ? n_more - 1 : 1; }
-    else if (n_more < want) want = n_more >= 1 ? n_more : 1;
+    if (n_more <= want) want = n_more >= 2 ? n_more - 1 : 1;
     for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
         const zt_batch *b = more + q;
         // members are equally long, except that the last one may be shorter; everything fits one launch and the slot
@@ -272,11 +266,6 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
     memset(p, 0, sizeof(*p));
     p->d = *desc;
     p->group = 1;
-    // the staged memory update and its stream (below): only when asked for
-    // (measured, round 4: C5 0.3516 against 0.3526 ms/step, 0.391 against 0.409 with the scorer at the tail -- but C2 0.093 ->
-    //  0.141, C3 0.154 -> 0.224, C4 0.156 -> 0.181: two more stream-to-stream hand-offs on a step that is a chain of short
-    //  kernels, and the output layer shares its compute units.  Off unless ZT_GRU_STAGED=1.)
-    p->stage_gru = getenv("ZT_GRU_STAGED") && atoi(getenv("ZT_GRU_STAGED")) != 0;
     if (tppr_cus > 0) {
         hipDeviceProp_t prop;
         int dev = 0;
@@ -287,26 +276,22 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         if (rc == ZT_OK) rc = zt_stream_create_masked(&b, tppr_cus, prop.multiProcessorCount);
         // the message kernels are small (a few dozen registers, no LDS): they share the T-PPR stream's compute units, where
         // they fit beside k_stream's workgroups -- the aggregation kernel fills the register files of its own
-        void *c = nullptr, *g = nullptr;
+        void *c = nullptr;
         if (rc == ZT_OK) rc = zt_stream_create_masked(&c, 0, tppr_cus);
-        if (rc == ZT_OK && p->stage_gru) rc = zt_stream_create_masked(&g, tppr_cus, prop.multiProcessorCount);
         if (rc != ZT_OK) {                     // (round-3 advisor: the streams already created leaked here)
             if (a) (void)zt_stream_destroy(a);
             if (b) (void)zt_stream_destroy(b);
             if (c) (void)zt_stream_destroy(c);
-            if (g) (void)zt_stream_destroy(g);
             delete p;
             return rc;
         }
-        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c; p->gru_s = (hipStream_t)g;
+        p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c;
     } else {
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->msg_s, hipStreamNonBlocking));
-        if (p->stage_gru) ZT_HIP(hipStreamCreateWithFlags(&p->gru_s, hipStreamNonBlocking));
     }
-    p->early_msg_wait = !(getenv("ZT_EARLY_MSG_WAIT") && atoi(getenv("ZT_EARLY_MSG_WAIT")) == 0);
-    ZT_HIP(hipEventCreateWithFlags(&p->gru_done, hipEventDisableTiming | zt::sync_event_flags()));
+    if (desc->tppr != nullptr) zt::tppr_hint_cus(desc->tppr, p->side);      // the first plans are made for THIS stream's CUs
     ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->msgs_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->scored[0], hipEventDisableTiming | zt::sync_event_flags()));
@@ -344,8 +329,6 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
     (void)hipStreamDestroy(p->side); (void)hipStreamDestroy(p->main_s); (void)hipStreamDestroy(p->plan_s);
     (void)hipStreamDestroy(p->msg_s);
-    if (p->gru_s) (void)hipStreamDestroy(p->gru_s);
-    (void)hipEventDestroy(p->gru_done);
     (void)hipEventDestroy(p->scored[0]); (void)hipEventDestroy(p->scored[1]);
     (void)hipEventDestroy(p->entry); (void)hipEventDestroy(p->step_begin); (void)hipEventDestroy(p->msgs_done);
     delete p;
@@ -396,6 +379,13 @@ extern "C" int zt_pipeline_last_scores(zt_pipeline *p, void *stream, float **pro
     ZT_HIP(hipStreamWaitEvent((hipStream_t)stream, p->scored[par], 0));
     *prob_out = p->prob + (size_t)par * 2 * p->d.max_B;
     if (B_out) *B_out = p->score_B;
+    return ZT_OK;
+}
+
+extern "C" int zt_pipeline_set_exchange(zt_pipeline *p, zt_exchange *x)
+{
+    if (!p) return ZT_ERR_ARG;
+    p->xchg = x;
     return ZT_OK;
 }
 
@@ -534,28 +524,13 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     if (rc != ZT_OK) return rc;
     if (!cnt_zeroed) ZT_HIP(hipMemsetAsync(gru_cnt, 0, sizeof(int), p->msg_s));       // (B == 0 cannot get here; belt and braces)
     ZT_HIP(hipEventRecord(p->msgs_done, p->msg_s));
-    // ---- P3 (the gate products): staged -- the kernel only reads the tables, its results wait in the GRU workspace --, on a
-    // stream of its own over the main stream's compute units, behind the message build.  The aggregation kernels there are
-    // persistent with a whole register file each, so the GRU's workgroups move in as those retire and run beside the output
-    // layer and the scorer; the commit (rows, projections, last_update into the tables) follows on the main stream.  Needs the
-    // padded W_m of an earlier step (embed_ready) when there is a projected table; otherwise the update runs in line below.
-    const bool staged = p->stage_gru && zt::gru_can_stage(2 * B) && (d.proj_table == nullptr || p->embed_ready);
     const float *wm_p = (d.proj_table != nullptr && p->embed_ready) ? zt::embed_wm_ptr(d.embed_ws, 3 * d.max_B, d.D, d.F, d.T, d.M, d.k)
                                                                      : nullptr;
     bool msgs_waited = false;
-    if (staged) {
-        ZT_HIP(hipStreamWaitEvent(p->gru_s, p->msgs_done, 0));
-        rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                               nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->gru_s, true, nullptr,
-                               true, true);
-        if (rc != ZT_OK) return rc;
-        p->gru_ready = true;
-        ZT_HIP(hipEventRecord(p->gru_done, p->gru_s));
-    }
     if (n_rows > 0) {
         // (the wait for the message build sits between the aggregation and the output layer -- the messages are ready long
         //  before the aggregation ends -- so that the GRU follows the output layer without a packet in between)
-        msgs_waited = !staged && p->early_msg_wait;
+        msgs_waited = true;
         rc = zt::embed_ex(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                           od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s,
                           msgs_waited ? p->msgs_done : nullptr);
@@ -572,23 +547,11 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
             p->score_B = B;
         }
     }
-    // ---- P3: the staged update's commit, or the whole GRU update over the messages built beside the aggregation; the
-    // refresh of the projected rows rides inside the GRU kernel once the padded W_m is in the embed workspace ----
-    if (staged) {
-        ZT_HIP(hipStreamWaitEvent(p->main_s, p->gru_done, 0));
-        rc = zt::gru_commit_ex(d.memory, d.last_update, d.msg_ts, d.D, msg_dim, 2 * B, d.gru_ws, wm_p ? d.proj_table : nullptr, p->main_s);
-        if (rc != ZT_OK) return rc;
-        s->key[j] = nullptr;
-        if (++s->n_done >= s->n) {
-            ZT_HIP(hipEventRecord(s->consumed, p->main_s));
-            s->n = 0;
-        }
-        return ZT_OK;
-    }
+    // ---- P3: the GRU update over the messages built beside the aggregation; the refresh of the projected rows rides
+    // inside the GRU kernel once the padded W_m is in the embed workspace ----
     if (!msgs_waited) ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
     rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, nullptr,
-                           true);
+                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, true);
     if (rc != ZT_OK) return rc;
     p->gru_ready = true;
     if (d.proj_table != nullptr && wm_p == nullptr) {
@@ -598,6 +561,20 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
                                reinterpret_cast<const int32_t *>(gw), 2 * B, d.proj_table, d.embed_ws, 3 * d.max_B, d.M, d.k,
                                p->main_s);
         if (rc != ZT_OK) return rc;
+    }
+    // ---- multi-GPU: the rows every rank's GRU update rewrote, all-gathered and scattered into the local tables; the
+    // projected table follows the rows the other ranks wrote (this rank's own were refreshed by its GRU kernel) ----
+    if (p->xchg != nullptr) {
+        const int32_t *xids = nullptr;
+        int64_t n_x = 0;
+        rc = zt::exchange_step(p->xchg, gru_rows, gru_cnt, p->main_s, &xids, &n_x);
+        if (rc != ZT_OK) return rc;
+        if (d.proj_table != nullptr) {
+            rc = zt_project_memory(d.memory, d.num_nodes, d.D, d.F, d.T, &d.ew, p->embed_ready ? 1 : 0, xids, nullptr, n_x, d.proj_table,
+                                   d.embed_ws, 3 * d.max_B, d.M, d.k, p->main_s);
+            if (rc != ZT_OK) return rc;
+            p->embed_ready = true;                 // (a rank whose row shard was empty: the padded weights were made just now)
+        }
     }
     // the member is used up; with the last one the slot is free again
     s->key[j] = nullptr;
@@ -617,10 +594,17 @@ extern "C" int zt_pipeline_run(zt_pipeline *p, const zt_batch *batches, int32_t 
                                int64_t out_stride)
 {
     if (!p || !batches || n < 0 || look < 0 || !out_emb_dev || out_stride < 0) { set_error("zt_pipeline_run: bad argument"); return ZT_ERR_ARG; }
+    int rank = 0, world = 1;
+    if (p->xchg != nullptr) zt::exchange_shape(p->xchg, &rank, &world);
     for (int32_t b = 0; b < n; ++b) {
         const int32_t na = (b + 1 + look <= n) ? look : (n - b - 1);
-        const int rc = zt_pipeline_step_ahead(p, &batches[b], na > 0 ? &batches[b + 1] : nullptr, na, 0, 3 * batches[b].B, 0,
-                                              2 * batches[b].B, out_emb_dev + (size_t)b * (size_t)out_stride);
+        // a multi-GPU run: this rank's contiguous shard of the batch's 3B rows and of its 2B positions (zebra_amd/distributed.py:
+        // shard_range); one GPU: everything
+        const int64_t B = batches[b].B;
+        const int64_t r0 = (3 * B * rank) / world, r1 = (3 * B * (rank + 1)) / world;
+        const int64_t p0 = (2 * B * rank) / world, p1 = (2 * B * (rank + 1)) / world;
+        const int rc = zt_pipeline_step_ahead(p, &batches[b], na > 0 ? &batches[b + 1] : nullptr, na, r0, r1, p0, p1,
+                                              out_emb_dev + (size_t)b * (size_t)out_stride);
         if (rc != ZT_OK) return rc;
     }
     return ZT_OK;

@@ -28,7 +28,7 @@ double g_prof_ms[P_COUNT];
 long long g_prof_n[P_COUNT];
 const char *const g_prof_names[P_COUNT] = {"tppr_prepass", "tppr_stream", "tppr_cleanup", "pruned_topk",
                                            "embed_prep", "fc1_agg", "embed_out", "store_messages", "gru_update", "score",
-                                           "gru_commit"};
+                                           "exchange"};
 hipEvent_t prof_event()
 {
     hipEvent_t e;
@@ -61,9 +61,47 @@ void prof_end(hipStream_t s, int id)
     g_prof_open[id] = -1;
 }
 
+
+// ---- kernel selection overrides (zt_set_kernel_choice) ---------------------------------
+namespace { int g_choice[ZT_CHOICE_COUNT] = {0}; }
+int kernel_choice(int which) { return (which >= 0 && which < ZT_CHOICE_COUNT) ? g_choice[which] : 0; }
+
+// CUs the stream may use (CU-masked streams: the size of the mask).  Queried per call: a cache keyed by the stream
+// handle goes stale when a pipeline is destroyed and the runtime hands the same handle value to a stream with another
+// mask (round-3 advisor); the query is microseconds next to the kernels it sizes.
+int stream_cu_count(hipStream_t s)
+{
+    static int total = 0;
+    int tot = total;
+    if (tot == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        tot = prop.multiProcessorCount;
+        total = tot;
+    }
+    uint32_t mask[32] = {0};
+    int c = tot;
+    if (hipExtStreamGetCUMask(s, 32, mask) == hipSuccess) {
+        int n = 0;
+        for (int q = 0; q < 32; ++q) n += __builtin_popcount(mask[q]);
+        if (n > 0 && n < tot) c = n;
+    } else {
+        (void)hipGetLastError();
+    }
+    return c;
+}
+
 }  // namespace zt
 
 using namespace zt;
+
+extern "C" int zt_set_kernel_choice(int32_t which, int32_t value)
+{
+    if (which < 0 || which >= ZT_CHOICE_COUNT || value < 0) { set_error("zt_set_kernel_choice: unknown selector %d", which); return ZT_ERR_ARG; }
+    g_choice[which] = value;
+    return ZT_OK;
+}
 
 extern "C" int zt_profile_enable(int on)
 {

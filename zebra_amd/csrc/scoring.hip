@@ -391,9 +391,9 @@ extern "C" int zt_affinity(const float *emb_dev, int64_t B, int32_t H, const zt_
     const dim3 grid((unsigned)(tiles < 160 ? tiles : 160), (unsigned)(p.Hp / 16));
     float *part = reinterpret_cast<float *>(ws + p.off_part);
     int *cnt = reinterpret_cast<int *>(ws + p.off_cnt);
-    // small batches: the latency-organised kernel; large ones: the tiled one (ZT_AFFINITY_TILED_MIN_B moves the switch:
-    // a tuning knob, both give the same probabilities to rounding)
-    static const long long tiled_min = getenv("ZT_AFFINITY_TILED_MIN_B") ? atoll(getenv("ZT_AFFINITY_TILED_MIN_B")) : 512;
+    // small batches: the latency-organised kernel; large ones: the tiled one (both give the same probabilities to rounding;
+    // where the switch sits: tools/exp/score_bench.py)
+    constexpr long long tiled_min = 512;
     ZT_PROF_BEGIN(s, P_SCORE);
     if (B >= tiled_min) {
         // 16 edges per workgroup while that fills the chip once (two workgroups fit a CU), 32 beyond

@@ -325,7 +325,7 @@ __global__ void k_reset_ctl(int *ctl) { if (threadIdx.x < 6 && threadIdx.x != 2 
 // launches above cost more on the host and in launch gaps than the work itself).  Same steps, same arrays, same
 // results; the steps are separated by workgroup barriers instead of kernel boundaries.
 constexpr int PRE_FUSED_MAX = 4096;      // (round 4: was 12288 -- a C5 batch's 12 288 accesses took 412 us in one workgroup,
-                                        //  110 us as ten launches; ZT_PREPASS_FUSED_MAX overrides)
+                                        //  110 us as ten launches)
 constexpr int PRE_THREADS = 1024;
 __global__ __launch_bounds__(PRE_THREADS) void k_prepass_fused(
     const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride, int B, int n_roles,
@@ -375,10 +375,17 @@ int zt::tppr_stream_cus(const zt_tppr *h, hipStream_t s)
     return (c > 0 && c < h->n_cu) ? c : h->n_cu;
 }
 
-// hub chains a grid can carry: at most two thirds of its workgroups, so the general queue always keeps waves
-int zt::tppr_chains_for_grid(int grid, int n_models)
+// the stream a pipeline will launch k_stream on is known before the first plan: plan for ITS compute units (round-4 advisor:
+// the first plans of a pipeline assumed the whole chip and planned more chains than the masked stream's grid wants)
+void zt::tppr_hint_cus(zt_tppr *h, hipStream_t s) { if (h) h->run_cus = tppr_stream_cus(h, s); }
+
+// hub chains a grid can carry: at most two thirds of its workgroups, so the general queue always keeps waves.  Chain
+// workgroups wait for each other's versions and for the general queue's partner tasks: they need the WHOLE grid resident,
+// which only a process that has the stream's CUs to itself can promise (share > 1: no chains; ZT_STREAM_CHAINS=0: none either).
+int zt::tppr_chains_for_grid(const zt_tppr *h, int grid, int n_models)
 {
     static const int chains_env = getenv("ZT_STREAM_CHAINS") ? atoi(getenv("ZT_STREAM_CHAINS")) : MAX_CHAINS;
+    if (h->share > 1) return 0;
     int max_chains = (2 * grid) / (3 * n_models);
     if (max_chains > chains_env) max_chains = chains_env;
     if (max_chains > MAX_CHAINS) max_chains = MAX_CHAINS;
@@ -391,11 +398,15 @@ void zt::tppr_launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *
     long long waves = (long long)B * n_models;
     // The kernel is latency-bound (waves mostly sleep on their predecessors): a few waves per CU
     // drain the independent tasks fast enough, and leave LDS / issue slots to a concurrently
-    // running aggregation kernel.  ZT_STREAM_WGS_PER_CU overrides (workgroups of 8 waves).
-    static const double wgs_per_cu = getenv("ZT_STREAM_WGS_PER_CU") ? atof(getenv("ZT_STREAM_WGS_PER_CU")) : 1.0;
+    // running aggregation kernel: one workgroup (8 waves) per CU.
+    constexpr double wgs_per_cu = 1.0;
     // Every workgroup of the grid must be resident at once (chain workgroups wait on each other's rows):
     // the CUs of the stream that runs k_stream (a CU-masked stream offers fewer) times the workgroups one
     // CU holds (asked from the runtime at create time).
+    // (processes sharing the device -- a rehearsal of several ranks on one GPU -- take their share of the CUs each, so that
+    //  the grids of all of them are resident together)
+    const int share = h->share > 1 ? h->share : 1;
+    if (cus / share >= 1) cus /= share; else cus = 1;
     long long max_waves = (long long)(cus * TPPR_WAVES_PER_WG * wgs_per_cu);
     const long long resident = (long long)cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1) * TPPR_WAVES_PER_WG;
     if (max_waves > resident) max_waves = resident;
@@ -404,7 +415,7 @@ void zt::tppr_launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *
     const int grid = (int)((waves + TPPR_WAVES_PER_WG - 1) / TPPR_WAVES_PER_WG);
     *grid_out = grid;
     // the chain hand-off (two-stage mailbox) is built on the register-resident merge: k <= 30
-    *max_chains_out = h->k <= TPPR_REG_K_MAX ? tppr_chains_for_grid(grid, n_models) : 0;
+    *max_chains_out = h->k <= TPPR_REG_K_MAX ? tppr_chains_for_grid(h, grid, n_models) : 0;
 }
 
 // The dependency prepass of one launch into plan set q, on stream s.  It reads only the node and
@@ -420,15 +431,9 @@ int zt::tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long
     const int n_models = model < 0 ? h->M : 1;
     int grid, max_chains;
     tppr_launch_shape(h, h->run_cus > 0 ? h->run_cus : h->n_cu, B, n_models, &grid, &max_chains);
-    static const bool fused_ok = !(getenv("ZT_PREPASS_FUSED") && atoi(getenv("ZT_PREPASS_FUSED")) == 0);
-    // (ZT_DEPS_SORT_MIN: the group size from which the dependencies come from the cooperative sort; 0 = never -- A/B knob)
-    static const int big_min_env = getenv("ZT_DEPS_SORT_MIN") ? atoi(getenv("ZT_DEPS_SORT_MIN")) : BIG_MIN;
-    const int big_min = big_min_env > 0 ? big_min_env : 0x7fffffff;
-    // (ZT_CHAIN_BUDGET=0: as many chains as the grid allows, whatever the general queue's load -- A/B knob)
-    static const bool budget_on = !(getenv("ZT_CHAIN_BUDGET") && atoi(getenv("ZT_CHAIN_BUDGET")) == 0);
-    const int budget_grid = budget_on ? grid : 0;
-    static const int fused_max = getenv("ZT_PREPASS_FUSED_MAX") ? atoi(getenv("ZT_PREPASS_FUSED_MAX")) : PRE_FUSED_MAX;
-    if (fused_ok && A <= fused_max && A <= 12288) {
+    const int big_min = BIG_MIN;               // group size from which the dependencies come from the cooperative sort
+    const int budget_grid = grid;              // chains are budgeted against the general queue's load (d_chain_budget)
+    if (A <= PRE_FUSED_MAX) {
         ZT_PROF_BEGIN(s, P_PREPASS);
         k_prepass_fused<<<1, PRE_THREADS, 0, s>>>(nodes, eidx, role_stride, B, n_roles, h->N, h->cnt, h->slot, h->off, h->list,
                                                   h->wo, h->pflag, h->nxt, h->ctl, h->latch_dev, h->hot_node, h->hot_cnt,

@@ -80,7 +80,8 @@ struct zt_tppr {
     int *ctl;
     unsigned epoch;
     int n_cu;
-    int run_cus;     // CUs of the stream the last k_stream ran on (0: not known yet)
+    int run_cus;     // CUs of the stream the last k_stream ran on (0: not known yet; zt_pipeline_create tells ahead of the first plan)
+    int share;       // processes whose T-PPR kernels share this device's CUs (zt_tppr_set_device_share; 1 = the device is ours)
     int wg_per_cu;   // k_stream workgroups one CU can hold (hipOccupancyMaxActiveBlocksPerMultiprocessor)
     // Failure latch in host-mapped memory: the first ZT_ERR_RANGE / ZT_ERR_TIMEOUT of any launch is written
     // here by the device (system scope), so the NEXT host call on the handle fails without a synchronisation
@@ -143,7 +144,8 @@ constexpr int TPPR_WAVES_PER_WG = 8;       // waves of a k_stream workgroup (a h
 constexpr int TPPR_REG_K_MAX = 30;         // the register-resident merge and the hub chains serve k <= 30 (tppr_rows.hpp)
 // tppr_prepass.hip
 int tppr_stream_cus(const zt_tppr *h, hipStream_t s);
-int tppr_chains_for_grid(int grid, int n_models);
+int tppr_chains_for_grid(const zt_tppr *h, int grid, int n_models);
+void tppr_hint_cus(zt_tppr *h, hipStream_t s);
 void tppr_launch_shape(const zt_tppr *h, int cus, int B, int n_models, int *grid_out, int *max_chains_out);
 int tppr_plan_chunk(zt_tppr *h, int q, const int32_t *nodes, const long long *eidx, long long role_stride, int B, int n_roles,
                     int model, hipStream_t s);

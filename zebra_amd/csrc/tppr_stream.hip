@@ -246,6 +246,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, WAVE * WAVES_PER_WG, 0));
     h->wg_per_cu = per_cu;
     h->epoch = 0;
+    h->share = 1;
     int rc = zt_tppr_reset(h, nullptr);
     if (rc != ZT_OK) return rc;
     ZT_HIP(hipDeviceSynchronize());
@@ -269,6 +270,14 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
         (void)hipEventDestroy(P.planned); (void)hipEventDestroy(P.consumed);
     }
     delete h;
+    return ZT_OK;
+}
+
+extern "C" int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes)
+{
+    if (!h || n_processes < 1) { set_error("zt_tppr_set_device_share: bad argument"); return ZT_ERR_ARG; }
+    h->share = n_processes;
+    h->set[0].valid = h->set[1].valid = false;       // plans made for the other layout are void
     return ZT_OK;
 }
 
@@ -322,10 +331,11 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     // plus a general queue fit, otherwise every edge goes through the in-order queue, which needs no
     // residency (a task only waits on tasks already dequeued by resident waves).
     int grid = P.grid, use_chains = 1;
-    const int resident = h->run_cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1);
+    int resident = h->run_cus * (h->wg_per_cu > 0 ? h->wg_per_cu : 1) / (h->share > 1 ? h->share : 1);
+    if (resident < 1) resident = 1;
     if (grid > resident) {
         grid = resident;
-        use_chains = P.max_chains <= tppr_chains_for_grid(grid, model < 0 ? h->M : 1) ? 1 : 0;
+        use_chains = P.max_chains <= tppr_chains_for_grid(h, grid, model < 0 ? h->M : 1) ? 1 : 0;
     }
     if (use_chains && P.max_chains > 0 && h->hubver == nullptr) {
         // first launch with hub chains on this handle: [M][MAX_CHAINS][CH_MAX + 1][rg] granules, tags 0 (cleared on the
@@ -340,10 +350,13 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
     sa.sub_B = sub_B;
-    static const int chain_waves_env = getenv("ZT_CHAIN_WAVES") ? atoi(getenv("ZT_CHAIN_WAVES")) : 8;
-    sa.chain_waves = chain_waves_env < 1 ? 1 : (chain_waves_env > WAVES_PER_WG ? WAVES_PER_WG : chain_waves_env);
-    static const int crit_multi_env = getenv("ZT_CRIT_MULTI") ? atoi(getenv("ZT_CRIT_MULTI")) : 0;
+    sa.chain_waves = WAVES_PER_WG;             // (4 / 6 / 8 waves per chain: 1874 / 1557 / 1432 us per four-batch C5 launch, round 3)
+#ifdef ZT_CRIT
+    static const int crit_multi_env = getenv("ZT_CRIT_MULTI") ? atoi(getenv("ZT_CRIT_MULTI")) : 0;    // (diagnostic build only)
     sa.crit_multi = crit_multi_env;
+#else
+    sa.crit_multi = 0;
+#endif
 #ifdef ZT_WAITLOG
     {
         void *wl = nullptr;

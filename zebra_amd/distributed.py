@@ -198,6 +198,8 @@ class ShardedTGN:
             # P3: winners at positions [p0, p1) -- only this rank's winners are flagged, the GRU compacts them
             emb = tgn.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=check_status, prefetch=prefetch,
                                   plan=plan, rows=(r0, r1), positions=(p0, p1), ahead=ahead)
+            if getattr(tgn, "_xchg", None) is not None:         # the native step has exchanged the rows itself (enable_exchange)
+                return emb
             rows, count = tgn.memory_updater.last_rows()
             m = tgn.memory
             got = exchange_touched_rows([m.memory, m.last_update, m.messages, m.timestamps], rows, count,

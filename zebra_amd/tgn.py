@@ -102,17 +102,24 @@ class TGN(torch.nn.Module):
         return B
 
     # ------------------------------------------------------------------ link scorer (tgn_model.py:185-188) on the device
-    def _affinity_state(self, max_B):
-        """(workspace, weights struct, weights_ready) of the HIP scorer; None when the hidden width has no kernel."""
+    def _affinity_state(self, max_B, who="direct"):
+        """(workspace, weights struct, weights_ready) of the HIP scorer for one CONSUMER -- "direct": score_device, which
+        packs the weights in the call that finds them changed; "pipe": the native pipeline, which packs them in its next
+        whole-batch step, on its own stream -- ; None when the hidden width has no kernel.  Each consumer has its own
+        workspace (packed weights, partial scores, arrival counters) and its own packed-for key: the two pack at different
+        times and run on different streams (round-4 advisor)."""
         a = self.affinity_score
         H = a.fc1.weight.shape[0]
         need = lib().zt_affinity_workspace_bytes(C.c_int64(max(1, max_B)), C.c_int32(H))
         if need < 0:
             return None
-        st = getattr(self, "_aff", None)
+        allst = getattr(self, "_aff", None)
+        if allst is None:
+            allst = self._aff = {}
+        st = allst.get(who)
         key = tuple((t.data_ptr(), t._version) for t in (a.fc1.weight, a.fc1.bias, a.fc2.weight, a.fc2.bias))
         if st is None or st["ws"].numel() < need or st["max_B"] < max_B:
-            st = self._aff = dict(ws=torch.empty(int(need), dtype=torch.uint8, device=self.device), max_B=int(max_B), key=None)
+            st = allst[who] = dict(ws=torch.empty(int(need), dtype=torch.uint8, device=self.device), max_B=int(max_B), key=None)
         w = _capi.AffinityWeights()
         w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b = (a.fc1.weight.data_ptr(), a.fc1.bias.data_ptr(), a.fc2.weight.data_ptr(),
                                               a.fc2.bias.data_ptr())
@@ -157,7 +164,7 @@ class TGN(torch.nn.Module):
                 check(lib().zt_pipeline_set_scoring(self._pipe, None, None, None), "zt_pipeline_set_scoring")
             return
         max_b = self._pipe_args[1]
-        st = self._affinity_state(max_b)
+        st = self._affinity_state(max_b, "pipe")
         if st is None:
             raise ValueError("no HIP scorer for hidden width %d" % self.affinity_score.fc1.weight.shape[0])
         st, w, ready = st
@@ -180,6 +187,10 @@ class TGN(torch.nn.Module):
         if getattr(self, "_pipe", None) is not None:
             torch.cuda.synchronize(self.device)
             check(lib().zt_pipeline_destroy(self._pipe))
+        if getattr(self, "_xchg", None) is not None:
+            check(lib().zt_exchange_destroy(self._xchg))
+        self._xchg = None
+        self._xchg_args = None
         self._pipe = None
         self._pipe_sig = None
         self._pipe_keep = None
@@ -193,6 +204,52 @@ class TGN(torch.nn.Module):
         self._pipe_refresh(create=True)
         self._pipe_score_set = False
         self._pipe_scoring_sync(force=True)
+
+    # -- multi-GPU: the row exchange INSIDE the native step (csrc/exchange.hip); SURVEY.md 8e
+    def enable_exchange(self, rank, world, transport="rccl", with_messages=False, group=None, shm_name=None):
+        """Every step of the native pipeline ends with the all-gather of the memory rows the ranks rewrote (and their scatter
+        and projected-row refresh), enqueued by the library itself: ``step_device(rows=, positions=)`` and ``run_device`` of
+        a sharded run then need no torch.distributed call between steps.  transport "rccl": one rank per GPU, the
+        communicator's id is broadcast over ``group`` (torch.distributed); "shm": ranks sharing ONE GPU (tests, rehearsals),
+        a POSIX shared-memory segment named ``shm_name``.  ``with_messages``: also exchange the message rows (only needed
+        to compare that table across ranks: the eval protocol never reads another rank's messages).  Collective."""
+        import torch.distributed as dist
+        if getattr(self, "_pipe", None) is None:
+            raise RuntimeError("enable_exchange needs enable_pipeline()")
+        max_b = self._pipe_args[1]
+        m = self.memory
+        d = _capi.ExchangeDesc()
+        d.rank, d.world, d.with_messages = int(rank), int(world), 1 if with_messages else 0
+        d.cap_rows = (2 * max_b + world - 1) // world
+        keep = None
+        if transport == "rccl":
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                check(lib().zt_exchange_unique_id(ptr(uid), C.c_int64(128)), "zt_exchange_unique_id")
+            if world > 1:
+                on_gpu = dist.get_backend(group) == "nccl"
+                t = uid.to(self.device) if on_gpu else uid
+                dist.broadcast(t, 0, group=group)
+                uid = t.cpu()
+            keep = uid.numpy().tobytes()
+            d.transport = _capi.XCHG_RCCL
+            d.unique_id = C.cast(C.c_char_p(keep), C.c_void_p)
+        elif transport == "shm":
+            if not shm_name:
+                raise ValueError("transport 'shm' needs shm_name")
+            keep = shm_name.encode()
+            d.transport = _capi.XCHG_SHM
+            d.shm_name = keep
+        else:
+            raise ValueError("transport must be 'rccl' or 'shm'")
+        d.memory, d.last_update, d.messages, d.msg_ts = (m.memory.data_ptr(), m.last_update.data_ptr(), m.messages.data_ptr(),
+                                                         m.timestamps.data_ptr())
+        d.D, d.msg_dim = self.memory_dimension, m.messages.shape[1]
+        h = C.c_void_p()
+        check(lib().zt_exchange_create(C.byref(h), C.byref(d)), "zt_exchange_create")
+        self._xchg = h
+        self._xchg_args = (int(rank), int(world), bool(with_messages))
+        check(lib().zt_pipeline_set_exchange(self._pipe, h), "zt_pipeline_set_exchange")
 
     def _pipe_signature(self):
         """Everything the native pipeline holds pointers to: (tables, weight versions)."""
@@ -254,6 +311,9 @@ class TGN(torch.nn.Module):
             self.main_stream = torch.cuda.ExternalStream(lib().zt_pipeline_main_stream(h), device=self.device)
         else:
             check(lib().zt_pipeline_update(self._pipe, C.byref(d), C.c_int32(1)), "zt_pipeline_update")
+            if getattr(self, "_xchg", None) is not None:      # the exchange follows the tables
+                check(lib().zt_exchange_set_tables(self._xchg, ptr(m.memory), ptr(m.last_update), ptr(m.messages),
+                                                   ptr(m.timestamps)), "zt_exchange_set_tables")
         em._ws_key = None                               # the pipeline remakes the padded weights at its next step
         mu._ws_key = None
         self._pipe_sig = self._pipe_signature()
@@ -368,15 +428,19 @@ class TGN(torch.nn.Module):
         self._pipe_want_stats(False)
         H = self.embedding_dimension * (self.embedding_module.n_tppr + 1)
         Bmax = max(int(arr[q].B) for q in range(n))
+        rows_max = 3 * Bmax
+        if getattr(self, "_xchg_args", None) is not None:          # a sharded run: step b writes this rank's rows only
+            rk, wd, _ = self._xchg_args
+            rows_max = max((3 * int(arr[q].B) * (rk + 1)) // wd - (3 * int(arr[q].B) * rk) // wd for q in range(n))
         if out is None:
             buf = getattr(self, "_run_scratch", None)
-            if buf is None or buf.numel() < 3 * Bmax * H:
-                buf = self._run_scratch = torch.empty(3 * Bmax * H, dtype=torch.float32, device=self.device)
+            if buf is None or buf.numel() < max(1, rows_max) * H:
+                buf = self._run_scratch = torch.empty(max(1, rows_max) * H, dtype=torch.float32, device=self.device)
             stride = 0
         else:
-            if out.shape != (n, 3 * Bmax, H) or out.dtype != torch.float32 or not out.is_contiguous():
-                raise ValueError("out must be a contiguous float32 [n, 3 B, H] tensor")
-            buf, stride = out, 3 * Bmax * H
+            if out.shape != (n, rows_max, H) or out.dtype != torch.float32 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float32 [n, rows, H] tensor (rows = 3 B, or this rank's shard of them)")
+            buf, stride = out, rows_max * H
         self._run_keep = keep
         check(lib().zt_pipeline_run(self._pipe, arr, C.c_int32(n), C.c_int32(3 * self._pipe_group + 1 if look is None else look),
                                     ptr(buf), C.c_int64(stride)), "zt_pipeline_run")
@@ -478,6 +542,9 @@ class TGN(torch.nn.Module):
                                                     edge_idxs, n_neighbors, train)
         if not train and not torch.is_grad_enabled() and s.is_cuda:
             # eval: the HIP scorer (csrc/scoring.hip) on the [3B, H] block the step returned; same shapes as below
+            if getattr(self, "_pipe", None) is not None and getattr(self, "_score_on", False):
+                prob = self.last_prob()                                  # the native step has scored this batch already
+                return prob[:n_samples].unsqueeze(1), prob[n_samples:].unsqueeze(1)
             full = getattr(self, "_last_node_embedding", None)           # the [3B, H] block s / dd / n are slices of
             if full is None or full.data_ptr() != s.data_ptr() or full.shape[0] != 3 * n_samples:
                 full = torch.cat([s, dd, n])

@@ -44,8 +44,14 @@ class _TpprState:
             except Exception:
                 pass
 
+    def set_device_share(self, n):
+        check(lib().zt_tppr_set_device_share(self.h, C.c_int32(n)), "zt_tppr_set_device_share")
+        self._share = int(n)
+
     def clone(self):
         o = _TpprState(*self.shape, self._alpha, self._beta)
+        if getattr(self, "_share", 1) > 1:
+            o.set_device_share(self._share)
         check(lib().zt_tppr_copy(o.h, self.h, stream_ptr()), "zt_tppr_copy")
         return o
 
@@ -117,7 +123,19 @@ class tppr_finder:
 
     # ------------------------------------------------------------ state mgmt
     def _new_state(self):
-        return _TpprState(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list)
+        st = _TpprState(self.num_nodes, self.k, self.n_tppr, self.alpha_list, self.beta_list)
+        if getattr(self, "_share", 1) > 1:
+            st.set_device_share(self._share)
+        return st
+
+    def set_device_share(self, n_processes):
+        """Several processes run their T-PPR updates on ONE GPU (ranks rehearsing on a one-GPU box): every launch takes
+        1 / n of its stream's compute units and runs without hub chains (zt_tppr_set_device_share).  One rank per GPU
+        -- the supported multi-GPU layout -- needs no call."""
+        self._share = int(n_processes)
+        self._live.set_device_share(self._share)
+        if self._val is not None:
+            self._val.set_device_share(self._share)
 
     def reset_val_tppr(self):                # utils/util.py:402-417
         self._val = None
