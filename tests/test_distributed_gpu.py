@@ -298,21 +298,27 @@ def test_rccl_exchange_on_cu_masked_streams():
     assert np.array_equal(a[1], c[1])
 
 
-def test_bench_gpus_2_rehearsal():
-    """`python bench.py --gpus 2` end to end on ONE GPU (ZT_BENCH_REHEARSAL=1: both ranks on cuda:0, gloo instead
-    of RCCL, no hub chains): the parent starts the two ranks, the sharded pipeline runs, rank 0's line says
-    n_gpus = 2.  (What the driver's scaling run does with RCCL on separate GPUs.)"""
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_bench_gpus_2_rehearsal(workload):
+    """`python bench.py --gpus 2` end to end on ONE GPU (ZT_BENCH_REHEARSAL=1: both ranks on cuda:0; every rank's T-PPR
+    launches take half the stream's CUs and run without hub chains -- zt_tppr_set_device_share --; the row exchange inside
+    the native step loop goes through shared memory, RCCL refusing two ranks on one device): the parent starts the two
+    ranks, the sharded native pipeline runs, rank 0's line says n_gpus = 2.  C2 with a short prefill; C5 as the default
+    command runs it -- CU masks on, the full 10 % prefill (2 441 batches), 10 000 001 nodes: the layout whose round-4
+    rehearsal ended in a dependency-wait time-out.  (What the driver's scaling run does with RCCL on
+    separate GPUs.)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["ZT_BENCH_REHEARSAL"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "6",
-                        "--warmup", "2", "--prefill-steps", "20", "--cpu-edges", "0"], env=env, capture_output=True,
-                       text=True, timeout=900)
+    extra = ["--prefill-steps", "20"] if workload == "c2" else ["--legs", "none", "--no-score"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", workload, "--steps", "6",
+                        "--warmup", "2", "--cpu-edges", "0"] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["value"] > 0
+    assert out["config"]["step_loop"].startswith("native")
