@@ -351,6 +351,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                 step(*batches[b], ahead=ahead)
 
     lib = _capi.lib()
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED if a.chain_pairs else 0)
     run(0, prefill)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
     torch.cuda.synchronize()
@@ -392,6 +393,8 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         # (two event records per timed launch are host calls too: every 4th launch of the main stream's kernels in the headline
         #  run, every 8th in the legs, whose small-batch steps are bound by host enqueue)
         lib.zt_profile_enable(a.profile_every if a.profile_every > 0 else (4 if headline else 8))
+    if wl["strategy"] == "streaming":
+        tgn.embedding_module.tppr_finder.chain_stats()          # (clears the counters: what follows is the timed region's)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -404,6 +407,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     sys.stderr.write("[bench] %s: host enqueue %.3f ms/step, wall %.3f ms/step\n" % (name, 1e3 * t_host / steps, 1e3 * dt / steps))
+    chain_stats = tgn.embedding_module.tppr_finder.chain_stats() if wl["strategy"] == "streaming" else None
     lib.zt_profile_enable(0)
     # ---- the second region: the same step + the link scorer (sharded runs score nothing: a rank holds a row shard) ----
     with_scorer = None
@@ -594,6 +598,11 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         "exchange_us_per_step": kern["exchange"]["avg_us"] if "exchange" in kern else None,
         # the replicated part of a multi-GPU step: every rank replays the whole batch's T-PPR chain (streaming strategy), so
         # this much of the step does not shrink with N -- a flat curve is explained by the line itself
+        # hub chains of the timed region, all chains and models: positions that shared a critical section with their neighbour
+        # (csrc/tppr_pair.hpp) against positions taken singly -- the hit rate of the paired hop, measured in the kernel
+        "chain_hops": None if chain_stats is None else dict(
+            chain_stats, paired_share=(2.0 * chain_stats["pairs_done"] /
+                                       max(1, 2 * chain_stats["pairs_claimed"] + chain_stats["singles"]))),
         "chain_bound_ms_per_step": (kern["tppr_stream"]["avg_us"] * kern["tppr_stream"]["launches"] / steps / 1e3)
                                    if "tppr_stream" in kern else None,
         "with_scorer": with_scorer,
@@ -649,6 +658,9 @@ def main():
                          "default: as many as fit a launch (<= 16384 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--python-loop", action="store_true",
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
+    ap.add_argument("--chain-pairs", action="store_true",
+                    help="hub chains take TWO positions per critical section where they can (csrc/tppr_pair.hpp; zt_set_kernel_choice: "
+                         "bit-exact, measured slower -- DESIGN.md section 5 --, off by default)")
     ap.add_argument("--exchange-world1", action="store_true",
                     help="one rank WITH the row exchange of a multi-GPU run in its step loop (a world-1 RCCL communicator made by the "
                          "library): what a one-GPU box can show of the N > 1 step -- host enqueue and kernel time of pack / all-gather "
@@ -717,7 +729,7 @@ def main():
         leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
         r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
         if r is not None:
-            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_bound_ms_per_step", "with_scorer",
+            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_hops", "chain_bound_ms_per_step", "with_scorer",
                                               "roofline", "roofline_throughput_kernel", "cpu_baseline", "algorithmic", "kernels")}
     if rank == 0:
         out["rccl_ranks"] = world if (world > 1 and not rehearsal) else 0

@@ -61,13 +61,17 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_EMBED_OUT 1   /* output layers (zt_embed): ZT_OUT_TILED, ZT_OUT_LATENCY, ZT_OUT_PERSIST */
 #define ZT_CHOICE_GRU 2         /* zt_gru_update: ZT_GRU_TILE, ZT_GRU_SPLIT */
 #define ZT_CHOICE_MESSAGES 3    /* zt_store_messages: ZT_MSG_ONE, ZT_MSG_TWO (batch positions per wavefront) */
-#define ZT_CHOICE_COUNT 4
+#define ZT_CHOICE_TPPR_CHAIN 4  /* hub chains of zt_tppr_stream: ZT_CHAIN_SINGLE (one position per critical section: the
+                                 * library's pick), ZT_CHAIN_PAIRED (two where the preconditions hold, csrc/tppr_pair.hpp) */
+#define ZT_CHOICE_COUNT 5
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
 #define ZT_OUT_LATENCY 2
 #define ZT_OUT_PERSIST 3
 #define ZT_GRU_TILE 1
 #define ZT_GRU_SPLIT 2
+#define ZT_CHAIN_SINGLE 1
+#define ZT_CHAIN_PAIRED 2
 #define ZT_MSG_ONE 1
 #define ZT_MSG_TWO 2
 int zt_set_kernel_choice(int32_t which, int32_t value);
@@ -100,6 +104,11 @@ int zt_tppr_destroy(zt_tppr *h);
  * together, and runs without hub chains, whose workgroups wait for one another.  New work; the reference
  * is one process on one device (train.py:145-146). */
 int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes);
+/* Statistics of the hub chains since the last call (synchronises `stream`, clears the counters): out5[0] pairs of
+ * consecutive chain positions claimed by one wavefront, [1] pairs applied in ONE critical section, [2] / [3] pairs left
+ * to the single hop before / inside the section (a precondition failed), [4] positions taken singly.
+ * (csrc/tppr_pair.hpp; the reference applies the edges one by one, utils/util.py:495-574.) */
+int zt_tppr_chain_stats(zt_tppr *h, int64_t *out5, void *stream);
 
 /* tppr_finder.reset_tppr (utils/util.py:419-434). */
 int zt_tppr_reset(zt_tppr *h, void *stream);

@@ -22,7 +22,7 @@ ZT_ERR_ARG, ZT_ERR_RANGE, ZT_ERR_HIP, ZT_ERR_UNSUPPORTED, ZT_ERR_TIMEOUT = -1, -
 # every symbol include/zebra_amd.h declares (tests check the library exports them all)
 SYMBOLS = [
     "zt_last_error", "zt_version", "zt_set_kernel_choice", "zt_profile_enable", "zt_profile_reset", "zt_profile_read", "zt_stream_create_masked", "zt_stream_destroy",
-    "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_set_device_share", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
+    "zt_tppr_create", "zt_tppr_destroy", "zt_tppr_set_device_share", "zt_tppr_chain_stats", "zt_tppr_reset", "zt_tppr_copy", "zt_tppr_stream", "zt_tppr_plan", "zt_tppr_status",
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
@@ -33,7 +33,8 @@ SYMBOLS = [
 
 
 # zt_set_kernel_choice selectors / values (include/zebra_amd.h)
-CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES = 0, 1, 2, 3
+CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES, CHOICE_TPPR_CHAIN = 0, 1, 2, 3, 4
+CHAIN_SINGLE, CHAIN_PAIRED = 1, 2
 AGG_GENERIC = 1
 OUT_TILED, OUT_LATENCY, OUT_PERSIST = 1, 2, 3
 GRU_TILE, GRU_SPLIT = 1, 2

@@ -24,7 +24,7 @@ namespace {
 // The one thing that does depend on identities is a key match (or the new key) falling on an entry whose slot
 // is still provisional: that hop waits for stage 2 first (process_edge).
 // seq_set / seq_ord = chain position + 1 once published (0 at launch).
-constexpr int MAIL_R = WAVES_PER_WG;
+constexpr int MAIL_R = WAVES_PER_WG;       // (16 slots, round 5: no difference -- single 1257 against 1267 us per four-batch C5 launch)
 struct MailSlot {
     u64 key[32];
     double ts[32];
@@ -84,6 +84,7 @@ struct StreamArgs {
     unsigned epoch;
     int chain_waves;   // waves of a chain workgroup that take chain hops (the others exit: the chain wave keeps its SIMD)
     int crit_multi;    // diagnostic build: stamps of launches over 3+ batches only (ZT_CRIT_MULTI=1: tools/exp/bench_crit.py)
+    int pairs;         // 1: chain waves take two consecutive positions in one critical section where they can (tppr_pair.hpp)
     int sub_B;         // > 0: the launch covers several consecutive batches of sub_B edges (the last may be shorter); the
                        // output rows of batch g form their own [n_models][n_roles][B_g][k] block, blocks back to back
 };

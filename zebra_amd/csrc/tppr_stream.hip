@@ -42,7 +42,7 @@
 //     quicksort replay on the ranks when ties decide, LDS / sequential replays
 //     for more than 64 candidates (numba_sort.hpp).
 #include "numba_sort.hpp"
-#include "tppr_chain.hpp"
+#include "tppr_pair.hpp"
 
 #include <cstdlib>
 #include <vector>
@@ -128,6 +128,38 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
 #define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
+            // ---- two positions in one critical section (tppr_pair.hpp): both edges have a partner other than the hub, not
+            // ---- the same one, and nobody has claimed position t + 1 yet ----
+            if (A.pairs && t >= 1 && t + 1 < len && h.k <= PAIR_K_MAX) {
+                const int pa = ZT_U(ch_partner[t]), pb = ZT_U(ch_partner[t + 1]);
+                if (pa >= 0 && pb >= 0 && pa != pb) {
+                    int old = 0;
+                    if (lane == 0) old = atomicCAS(&mail.head, t + 1, t + 2);
+                    old = ZT_U(old);
+                    if (old == t + 1) {
+                        chain_stat(h.ctl, lane, ST_PAIR_CLAIM);
+                        HopRec r1, r2;
+                        r1.partner = pa; r1.wo_p = ZT_U(ch_wop[t]); r1.pchain = ZT_U(ch_pch[t]);
+                        r2.partner = pb; r2.wo_p = ZT_U(ch_wop[t + 1]); r2.pchain = ZT_U(ch_pch[t + 1]);
+                        const int ea = ZT_U(ch_edge[t]), eb = ZT_U(ch_edge[t + 1]);
+                        const int e2 = t + 2 < len ? ZT_U(ch_edge[t + 2]) : -1, e0 = ZT_U(ch_edge[t - 1]);
+                        PairCtx X;
+                        X.rows = h.rows; X.hubver = h.hubver; X.cdone = h.cdone; X.ctl = h.ctl; X.tsv = A.tsv; X.eidx = A.eidx;
+                        X.N = h.N; X.m = A.m_lo + mo; X.alpha = h.alpha[X.m]; X.beta = h.beta[X.m]; X.epoch = A.epoch; X.k = h.k; X.rg = h.rg;
+                        const double nrm = chain_hop2(X, &L, lane, ea, eb, &mail, hub, e2, t, hint.norm_out, hint.tpos, c, r1, r2);
+                        if (nrm != 0.0) { hint.norm_out = nrm; hint.tpos = t + 1; continue; }
+                        // a precondition failed before anything was written: the two hops one after the other
+                        __builtin_amdgcn_s_setprio(1);
+                        if (!chain_hop(h, A, L, lane, ea, mo, &mail, hub, e0, eb, t, &hint, c, r1))
+                            process_edge(h, A, L, lane, ea, mo, &mail, hub, e0, eb, t, &hint, c);
+                        __builtin_amdgcn_s_setprio(1);
+                        if (!chain_hop(h, A, L, lane, eb, mo, &mail, hub, ea, e2, t + 1, &hint, c, r2))
+                            process_edge(h, A, L, lane, eb, mo, &mail, hub, ea, e2, t + 1, &hint, c);
+                        continue;
+                    }
+                }
+            }
+            chain_stat(h.ctl, lane, ST_SINGLE);
             const int pe = t > 0 ? ZT_U(ch_edge[t - 1]) : -1, ne = t + 1 < len ? ZT_U(ch_edge[t + 1]) : -1, ce = ZT_U(ch_edge[t]);
             HopRec rec;
             rec.partner = ZT_U(ch_partner[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pchain = ZT_U(ch_pch[t]);
@@ -281,6 +313,39 @@ extern "C" int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes)
     return ZT_OK;
 }
 
+// hub-chain statistics since the last call (summed over both plan sets, then cleared): out[0] pairs of positions claimed by
+// one wave, [1] pairs completed in ONE critical section, [2] pairs left to the single hop in preparation (norm not
+// predictable, a key shared between the partners' rows, a slot collision ...), [3] ... inside the section (a key of the hub's
+// row in a partner's, a tie that reaches across the first cut ...), [4] positions taken singly.
+extern "C" int zt_tppr_chain_stats(zt_tppr *h, int64_t *out5, void *stream)
+{
+    if (!h || !out5) return ZT_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    ZT_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < 5; ++q) out5[q] = 0;
+#ifdef ZT_PAIR_STAT
+    {
+        long long g[16] = {0};
+        ZT_HIP(hipMemcpyFromSymbol(g, HIP_SYMBOL(g_pstat), sizeof(g)));
+        long long z[16] = {0};
+        ZT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pstat), z, sizeof(z)));
+        if (g[4] > 0)
+            fprintf(stderr, "[pair-stat] %lld pairs: preparation %.0f clocks, waiting for the turn %.0f, critical section %.0f, off-chain halves %.0f\n",
+                    g[4], (double)g[0] / g[4], (double)g[2] / g[4], (double)g[1] / g[4], (double)g[3] / g[4]);
+        if (g[4] > 0)
+            fprintf(stderr, "[pair-stat]   section: row + checks %.0f, network %.0f, masks + tests + slots %.0f, ring slot %.0f\n",
+                    (double)g[5] / g[4], (double)g[6] / g[4], (double)g[7] / g[4], (double)g[8] / g[4]);
+    }
+#endif
+    for (int q = 0; q < 2; ++q) {
+        int c[5] = {0, 0, 0, 0, 0};
+        ZT_HIP(hipMemcpy(c, h->set[q].ctl + ST_PAIR_CLAIM, sizeof(c), hipMemcpyDeviceToHost));
+        ZT_HIP(hipMemset(h->set[q].ctl + ST_PAIR_CLAIM, 0, sizeof(c)));
+        for (int j = 0; j < 5; ++j) out5[j] += c[j];
+    }
+    return ZT_OK;
+}
+
 extern "C" int zt_tppr_reset(zt_tppr *h, void *stream)
 {
     if (!h) return ZT_ERR_ARG;
@@ -350,6 +415,9 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
     sa.sub_B = sub_B;
+    // two chain positions per critical section (tppr_pair.hpp): bit-exact, 79 % of C5's chain positions pair up -- and slower
+    // (the section 4.0-4.4 k clocks against 2 x 2.3 k, its preparation 25 k per pair: DESIGN.md section 5): on request only
+    sa.pairs = zt::kernel_choice(ZT_CHOICE_TPPR_CHAIN) == ZT_CHAIN_PAIRED ? 1 : 0;
     sa.chain_waves = WAVES_PER_WG;             // (4 / 6 / 8 waves per chain: 1874 / 1557 / 1432 us per four-batch C5 launch, round 3)
 #ifdef ZT_CRIT
     static const int crit_multi_env = getenv("ZT_CRIT_MULTI") ? atoi(getenv("ZT_CRIT_MULTI")) : 0;    // (diagnostic build only)

@@ -128,6 +128,13 @@ class tppr_finder:
             st.set_device_share(self._share)
         return st
 
+    def chain_stats(self):
+        """Hub-chain statistics of the live state since the last call: dict(pairs_claimed, pairs_done, pairs_left_in_prep,
+        pairs_left_in_section, singles) -- how often two chain positions shared one critical section (csrc/tppr_pair.hpp)."""
+        out = (C.c_int64 * 5)()
+        check(lib().zt_tppr_chain_stats(self._live.h, out, stream_ptr()), "zt_tppr_chain_stats")
+        return dict(zip(("pairs_claimed", "pairs_done", "pairs_left_in_prep", "pairs_left_in_section", "singles"), [int(x) for x in out]))
+
     def set_device_share(self, n_processes):
         """Several processes run their T-PPR updates on ONE GPU (ranks rehearsing on a one-GPU box): every launch takes
         1 / n of its stream's compute units and runs without hub chains (zt_tppr_set_device_share).  One rank per GPU
