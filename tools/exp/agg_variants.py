@@ -49,5 +49,5 @@ if len(sys.argv) > 1:
 else:
     for name, env in (("reg", {}), ("reg no cos", {"ZT_AGG_DBG": "1"}), ("reg bare epilogue", {"ZT_AGG_DBG": "2"}),
                       ("reg bare epilogue, no P", {"ZT_AGG_DBG": "6"}),
-                      ("reg mfma + bare epilogue only", {"ZT_AGG_DBG": "7"}), ("d100 (round 2)", {"ZT_AGG_REG": "0"})):
+                      ("reg mfma + bare epilogue only", {"ZT_AGG_DBG": "7"})):
         subprocess.run([sys.executable, __file__, name], env=dict(os.environ, **env), check=True)
