@@ -351,6 +351,11 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                 step(*batches[b], ahead=ahead)
 
     lib = _capi.lib()
+    if os.environ.get("ZT_DUMP_MAPS") and rank == 0:
+        # (diagnostics: the process's memory map, so that the raw addresses of a native stack trace -- a profiler crash --
+        #  can be put to library + offset afterwards: tools/symbolise.py)
+        with open("/proc/self/maps") as fi, open(os.environ["ZT_DUMP_MAPS"], "w") as fo:
+            fo.write(fi.read())
     _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED if a.chain_pairs else 0)
     run(0, prefill)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
@@ -481,11 +486,13 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction; see profiles/make_pmc_summary.py)
     pmc = {}
     pmc_edges = None
+    pmc_source = None
     if world == 1:
         for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % name)
             if os.path.isfile(pj):
                 summ = json.load(open(pj))
+                pmc_source = "profiles/%s/%s_pmc_summary.json (commit %s)" % (rnd, name, (summ.get("measured_on") or {}).get("commit"))
                 pmc = summ.get("kernels", {})
                 # per-launch bytes of the T-PPR kernel belong to a launch SHAPE: a summary measured on launches of another
                 # size is scaled by the edges per launch (the kernel's traffic is per edge -- rows read and written, tag
@@ -510,7 +517,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
             # the contract's `peak`; the share of the CUs the kernel can run on is given beside it
             cus_used = cus_total - (tppr_cus if (not no_pipeline and tppr_cus > 0) else 0)
             return dict(kernel=kn, bound="mfma", achieved=ach, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
-                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr, cus=cus_used,
+                        frac=ach / MFMA_F32_PEAK_TF, traffic=tr, traffic_source=pmc_source if tr is not None else None, cus=cus_used,
                         frac_of_own_cus=ach / (MFMA_F32_PEAK_TF * cus_used / cus_total),
                         note="FLOPs the kernel executes (fc2 runs after the k-reduction, in embed_out; W_m memory[v] "
                              "comes from the projected table); the reference formulation would count %.2fx more" % (M * af["p2"] / ex["fc1_agg"]) if kn == "fc1_agg" else None)
@@ -537,7 +544,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         # the streaming T-PPR kernel is bound by (hops of the longest per-node chain) x (latency of one hop), not by
         # HBM: `achieved` / `peak` / `frac` are still its algorithmic bytes against the HBM peak, for the record
         out_r = dict(kernel=kn, bound="latency" if kn == "tppr_stream" else "hbm", achieved=ach, peak=HBM_PEAK_GBS,
-                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, note=note)
+                     unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, traffic_source=pmc_source if tr is not None else None, note=note)
         if kn == "tppr_stream":
             out_r["edges_per_launch"] = per_launch
             # the yardstick that fits: the longest chain of edges through ONE node in a launch (every edge that touches
