@@ -54,6 +54,12 @@ namespace {
 #ifndef ZT_STREAM_BOUNDS
 #define ZT_STREAM_BOUNDS (WAVE * WAVES_PER_WG)      // (tools/exp/bounds_exp.sh: 768 = three waves per SIMD, 168 VGPRs)
 #endif
+// PAIRS: the instantiation whose chain waves may take two positions per critical section (tppr_pair.hpp).  A kernel of its
+// own: the paired hop is a real call that needs all 256 registers a wave may have at two waves per SIMD, and a k_stream of
+// 256 registers leaves the message kernels no room beside its workgroups on the T-PPR stream's CUs (round 5: with the call
+// merely PRESENT in the one kernel, k_last_pos waited 270 us per launch for a free register file and the driver-timed C5
+// step went from 0.38 to 0.54 ms).
+template <bool PAIRS>
 __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamArgs A)
 {
     __shared__ WaveLds lds[WAVES_PER_WG];
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
 #define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
             // ---- two positions in one critical section (tppr_pair.hpp): both edges have a partner other than the hub, not
             // ---- the same one, and nobody has claimed position t + 1 yet ----
-            if (A.pairs && t >= 1 && t + 1 < len && h.k <= PAIR_K_MAX) {
+            if (PAIRS && t >= 1 && t + 1 < len && h.k <= PAIR_K_MAX) {
                 const int pa = ZT_U(ch_partner[t]), pb = ZT_U(ch_partner[t + 1]);
                 if (pa >= 0 && pb >= 0 && pa != pb) {
                     int old = 0;
@@ -275,7 +281,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     // every workgroup of a k_stream grid that runs hub chains must be resident: ask the runtime how many
     // fit on a CU (LDS, registers) rather than estimating it
     int per_cu = 0;
-    ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream, WAVE * WAVES_PER_WG, 0));
+    ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<false>, WAVE * WAVES_PER_WG, 0));
     h->wg_per_cu = per_cu;
     h->epoch = 0;
     h->share = 1;
@@ -434,7 +440,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     }
 #endif
     ZT_PROF_BEGIN(s, P_STREAM);
-    k_stream<<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    if (sa.pairs) k_stream<true><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    else k_stream<false><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.consumed, s));
