@@ -356,7 +356,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         #  can be put to library + offset afterwards: tools/symbolise.py)
         with open("/proc/self/maps") as fi, open(os.environ["ZT_DUMP_MAPS"], "w") as fo:
             fo.write(fi.read())
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED if a.chain_pairs else 0)
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED if a.chain_pairs else (a.chain_mode or 0))
     run(0, prefill)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
     torch.cuda.synchronize()
@@ -665,6 +665,8 @@ def main():
                          "default: as many as fit a launch (<= 16384 edges), at most 4; 1 for the pruning strategy")
     ap.add_argument("--python-loop", action="store_true",
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
+    ap.add_argument("--chain-mode", type=int, default=0,
+                    help="hub chains of the T-PPR update: 0 the library's pick, 1 single hops through the mailbox, 3 spine (zt_set_kernel_choice)")
     ap.add_argument("--chain-pairs", action="store_true",
                     help="hub chains take TWO positions per critical section where they can (csrc/tppr_pair.hpp; zt_set_kernel_choice: "
                          "bit-exact, measured slower -- DESIGN.md section 5 --, off by default)")

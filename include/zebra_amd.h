@@ -62,7 +62,7 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_GRU 2         /* zt_gru_update: ZT_GRU_TILE, ZT_GRU_SPLIT */
 #define ZT_CHOICE_MESSAGES 3    /* zt_store_messages: ZT_MSG_ONE, ZT_MSG_TWO (batch positions per wavefront) */
 #define ZT_CHOICE_TPPR_CHAIN 4  /* hub chains of zt_tppr_stream: ZT_CHAIN_SINGLE (one position per critical section: the
-                                 * library's pick), ZT_CHAIN_PAIRED (two where the preconditions hold, csrc/tppr_pair.hpp) */
+                                 * library's pick), ZT_CHAIN_PAIRED (two where the preconditions hold, csrc/tppr_pair.hpp), ZT_CHAIN_SPINE (below) */
 #define ZT_CHOICE_COUNT 5
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
@@ -72,6 +72,7 @@ int zt_stream_destroy(void *stream);
 #define ZT_GRU_SPLIT 2
 #define ZT_CHAIN_SINGLE 1
 #define ZT_CHAIN_PAIRED 2
+#define ZT_CHAIN_SPINE 3   /* one wave per chain runs every critical section with the hub's row in registers (csrc/tppr_chain.hpp) */
 #define ZT_MSG_ONE 1
 #define ZT_MSG_TWO 2
 int zt_set_kernel_choice(int32_t which, int32_t value);

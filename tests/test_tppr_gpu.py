@@ -65,6 +65,54 @@ def test_streaming_golden_paired_hops(zt, name):
         _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
 
 
+@pytest.mark.parametrize("name", list(I.STREAM_CASES))
+def test_streaming_golden_spine(zt, name):
+    """The same goldens with hub chains in spine mode (csrc/tppr_chain.hpp: one wave per chain runs every critical section
+    with the hub's row in registers, the others prepare and finish; ZT_CHAIN_SPINE): bit for bit the reference's."""
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
+    try:
+        test_streaming_golden(zt, name)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
+
+
+def test_spine_dense_hub_and_soak(zt, oracle):
+    """Spine mode on the dense-hub graphs (long chains, hub-hub edges, exact ties), a slice of the randomised soak and a hub
+    stream long enough for chains, against the oracle; the chain statistics show the spine running the sections."""
+    from zebra_amd import _capi
+    import soak_tppr
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
+    try:
+        for seed in (1, 2):
+            test_dense_hub_graph_vs_oracle(zt, oracle, seed)
+        for seed in range(53000, 53040):
+            err = soak_tppr.one(seed, zt, oracle)
+            assert err is None, err
+        N, E, k, bs = 400, 8000, 20, 2000
+        rng = np.random.RandomState(5)
+        src = np.where(rng.rand(E) < 0.2, 7, rng.randint(1, N, E)).astype(np.int32)
+        dst = rng.randint(1, N, E).astype(np.int32)
+        neg = rng.randint(1, N, E).astype(np.int32)
+        ts = np.cumsum(rng.rand(E) * 10.0)
+        eidx = np.arange(1, E + 1, dtype=np.int64)
+        f = zt.tppr_finder(N, k, 2, [0.1, 0.1], [0.5, 0.95])
+        o = oracle.TpprOracle(N, k, 2, [0.1, 0.1], [0.5, 0.95])
+        f.chain_stats()
+        for s in range(0, E, bs):
+            nodes = np.concatenate([src[s:s + bs], dst[s:s + bs], neg[s:s + bs]])
+            a = f.streaming_topk(nodes, ts[s:s + bs], eidx[s:s + bs])
+            b = o.streaming_topk(nodes, ts[s:s + bs], eidx[s:s + bs])
+            for x, y in zip(a, b):
+                assert np.array_equal(np.stack(x), np.stack(y))
+        st = f.chain_stats()
+        assert st["pairs_done"] > st["pairs_left_in_section"] > 0, st      # (spine mode: sections run by the spine / left to helpers)
+        for m in range(2):
+            _cmp_state(f.export_state(m), o.export(m), "model %d" % m)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
+
+
 def test_paired_hops_dense_hub_and_soak(zt, oracle):
     """Paired chain hops on the dense-hub graphs (every edge touches one of a few hubs: long chains, hub-hub edges, exact
     ties) and a slice of the randomised soak, against the oracle; the chain statistics show pairs completing."""

@@ -24,7 +24,10 @@ namespace {
 // The one thing that does depend on identities is a key match (or the new key) falling on an entry whose slot
 // is still provisional: that hop waits for stage 2 first (process_edge).
 // seq_set / seq_ord = chain position + 1 once published (0 at launch).
-constexpr int MAIL_R = WAVES_PER_WG;       // (16 slots, round 5: no difference -- single 1257 against 1267 us per four-batch C5 launch)
+// (8 slots are enough when the wave that publishes position t also did its preparation; the spine -- tppr_chain.hpp, one
+//  wave that runs EVERY critical section with the row in its registers -- is up to a helper's whole cycle ahead of the
+//  off-chain halves that release the slots: 16)
+constexpr int MAIL_R = 2 * WAVES_PER_WG;
 struct MailSlot {
     u64 key[32];
     double ts[32];
@@ -63,11 +66,27 @@ __device__ __forceinline__ void mail_hdr_write(MailSlot *sl, double norm, int le
     v.w = unc;
     *reinterpret_cast<mail_v4u *>(&sl->norm) = v;
 }
+// Spine mode (chain_spine): what the helper wave of position t has prepared -- the partner's side of the candidate list,
+// sorted, in the helper's own WaveLds; here its uniform part -- and, written back by the spine, what that helper needs for
+// the off-chain half.  One record per position modulo PREP_R; a helper holds one position at a time.
+constexpr int PREP_R = 16;
+struct PrepHdr {
+    alignas(16) double norm;   // the norm the scale factors were worked out for (the spine compares it with the row's)
+    double scale_s1;
+    double norm_next, tnow;
+    u64 nkey;
+    unsigned meta;             // nb | lenp << 8 | pre_hash << 16 | wave << 20 | ok << 24
+    int seq;                   // position + 1 once posted (written last)
+    u64 S;                     // spine -> helper: the mask of run starts
+    int res;                   // spine -> helper: position + 1 = "the spine ran the section"; -(position + 1) = "yours" (written last)
+    int pad;
+};
 struct Mail {
 #ifdef ZT_CRIT
     long long t_start; // core clock when the workgroup started (diagnostic)
 #endif
     MailSlot slot[MAIL_R];
+    PrepHdr prep[PREP_R];
     int head;          // next position of the chain's edge list
 };
 

@@ -35,17 +35,6 @@ constexpr int PAIR_K_MAX = 20;       // k + 2 (k + 1) <= 62: lane 63 is the lane
 constexpr int PA = 20, PB = 41;      // home lanes: the hub's entries 0 .. k-1, partner 1's side PA + j, partner 2's side PB + j
 constexpr int HTAB2 = HTAB / 2;      // the wave's hash table in two halves: partner 1's keys in slots [0, HTAB2), partner 2's in [HTAB2, HTAB) (9-bit slots)
 
-// chain statistics (ctl[6 ..]): pairs claimed / completed in one section / left to the single hop in preparation / in the
-// section; hops taken singly
-#ifdef ZT_PAIR_STAT
-__device__ long long g_pstat[16];      // diagnostic build: clocks in preparation / critical sections / waiting / off-chain halves, pairs
-#endif
-enum { ST_PAIR_CLAIM = 6, ST_PAIR_DONE = 7, ST_PAIR_BAIL_PREP = 8, ST_PAIR_BAIL_CRIT = 9, ST_SINGLE = 10 };
-__device__ __forceinline__ void chain_stat(int *ctl, int lane, int which)
-{
-    if (lane == 0) __hip_atomic_fetch_add(ctl + which, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // What the paired hop needs of the handle and the launch, by VALUE: the function is a real call (inlined beside the single
 // hop and the general task it pushed the kernel past 256 registers), and a reference to the kernel's argument structs
 // would make the compiler keep copies of them in scratch memory.

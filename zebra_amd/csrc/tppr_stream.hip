@@ -59,9 +59,11 @@ namespace {
 // 256 registers leaves the message kernels no room beside its workgroups on the T-PPR stream's CUs (round 5: with the call
 // merely PRESENT in the one kernel, k_last_pos waited 270 us per launch for a free register file and the driver-timed C5
 // step went from 0.38 to 0.54 ms).
-template <bool PAIRS>
+// MODE 2 (spine, tppr_chain.hpp): one wave of a chain workgroup runs every critical section, the others prepare and finish.
+template <int MODE>
 __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamArgs A)
 {
+    constexpr bool PAIRS = MODE == 1;
     __shared__ WaveLds lds[WAVES_PER_WG];
     __shared__ Mail mail;
     __shared__ int ch_edge[CH_MAX], ch_partner[CH_MAX], ch_wop[CH_MAX], ch_pch[CH_MAX];   // chain workgroups: HopRec
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     if (threadIdx.x < MAIL_R) { mail.slot[threadIdx.x].seq_set = 0; mail.slot[threadIdx.x].seq_ord = 0; mail.slot[threadIdx.x].seq_free = 0; }
     if (threadIdx.x == 0) mail.head = 0;
+    if (MODE == 2 && threadIdx.x < PREP_R) { mail.prep[threadIdx.x].seq = 0; mail.prep[threadIdx.x].res = 0; }
 #ifdef ZT_CRIT
     if (threadIdx.x == 0) mail.t_start = (long long)__builtin_readcyclecounter();
 #endif
@@ -122,6 +125,8 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
         // partner's update, the emission -- runs elsewhere (process_chain_partner), but a hop's preparation and its
         // off-chain half (replay, order, stores) still add up to ~5 hop periods of one wave's time.
         if ((int)(threadIdx.x / WAVE) >= A.chain_waves) return;
+        const bool spine_on = MODE == 2 && h.k <= REG_K_MAX && len > 0;
+        if (spine_on && threadIdx.x < WAVE) { chain_spine(h, lds, lane, &mail, len); return; }
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
         // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
@@ -170,7 +175,8 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
             HopRec rec;
             rec.partner = ZT_U(ch_partner[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pchain = ZT_U(ch_pch[t]);
 #undef ZT_U
-            if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec))
+            if (spine_on && (pe < 0 || rec.partner < 0)) spine_post_none(&mail, lane, t);      // (chain_hop does not take these)
+            if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec, spine_on))
                 process_edge(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c);
         }
         return;                                           // chain workgroups take no general tasks (letting them join the
@@ -281,7 +287,7 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
     // every workgroup of a k_stream grid that runs hub chains must be resident: ask the runtime how many
     // fit on a CU (LDS, registers) rather than estimating it
     int per_cu = 0;
-    ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<false>, WAVE * WAVES_PER_WG, 0));
+    ZT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_stream<0>, WAVE * WAVES_PER_WG, 0));
     h->wg_per_cu = per_cu;
     h->epoch = 0;
     h->share = 1;
@@ -423,7 +429,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.sub_B = sub_B;
     // two chain positions per critical section (tppr_pair.hpp): bit-exact, 79 % of C5's chain positions pair up -- and slower
     // (the section 4.0-4.4 k clocks against 2 x 2.3 k, its preparation 25 k per pair: DESIGN.md section 5): on request only
-    sa.pairs = zt::kernel_choice(ZT_CHOICE_TPPR_CHAIN) == ZT_CHAIN_PAIRED ? 1 : 0;
+    const int chain_choice = zt::kernel_choice(ZT_CHOICE_TPPR_CHAIN);
+    sa.pairs = chain_choice == ZT_CHAIN_PAIRED ? 1 : 0;
     sa.chain_waves = WAVES_PER_WG;             // (4 / 6 / 8 waves per chain: 1874 / 1557 / 1432 us per four-batch C5 launch, round 3)
 #ifdef ZT_CRIT
     static const int crit_multi_env = getenv("ZT_CRIT_MULTI") ? atoi(getenv("ZT_CRIT_MULTI")) : 0;    // (diagnostic build only)
@@ -440,8 +447,9 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     }
 #endif
     ZT_PROF_BEGIN(s, P_STREAM);
-    if (sa.pairs) k_stream<true><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
-    else k_stream<false><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    if (sa.pairs) k_stream<1><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    else if (chain_choice == ZT_CHAIN_SPINE) k_stream<2><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    else k_stream<0><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.consumed, s));
