@@ -41,13 +41,11 @@ if len(sys.argv) > 1:
     if a[:, 2].max() > 0:
         t0 = a[:, 1].min()
         st, en, cyc = (a[:, 1] - t0) * 0.01, (a[:, 2] - t0) * 0.01, a[:, 0]
-        msg = ("  waves: start %.1f..%.1f us, end %.1f..%.1f (median %.1f) us, run median %.1f max %.1f us, %.2f GHz; by XCC end max: %s"
+        fill = (a[:, 1] - a[:, 3]) * 0.01
+        msg = ("  waves: start %.1f..%.1f us, end %.1f..%.1f (median %.1f) us, run median %.1f max %.1f us, %.2f GHz; weight fill (entry -> first tile) median %.1f max %.1f us, first entry %.1f us before the first start"
                % (st.min(), st.max(), en.min(), en.max(), np.median(en), np.median(en - st), (en - st).max(),
-                  np.median(cyc / ((en - st) * 1e-6)) / 1e9,
-                  [round(float(en[(a[:, 3].astype(int) & 15) == x].max()), 1) for x in range(8)]))
+                  np.median(cyc / ((en - st) * 1e-6)) / 1e9, np.median(fill), fill.max(), (t0 - a[:, 3].min()) * 0.01))
     print("%s: fc1_agg %.1f us%s" % (sys.argv[1], 1e3 * ms.value / max(1, cnt.value), msg))
 else:
-    for name, env in (("reg", {}), ("reg no cos", {"ZT_AGG_DBG": "1"}), ("reg bare epilogue", {"ZT_AGG_DBG": "2"}),
-                      ("reg bare epilogue, no P", {"ZT_AGG_DBG": "6"}),
-                      ("reg mfma + bare epilogue only", {"ZT_AGG_DBG": "7"})):
+    for name, env in (("reg", {}), ("reg timed (all parts)", {"ZT_AGG_DBG": "8"}), ("reg mfma + bare epilogue only", {"ZT_AGG_DBG": "7"})):
         subprocess.run([sys.executable, __file__, name], env=dict(os.environ, **env), check=True)

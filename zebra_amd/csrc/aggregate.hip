@@ -695,12 +695,24 @@ __device__ unsigned long long g_regclk[4 * 1024];   // diagnostic builds (-DZT_D
 #endif
 constexpr int REG_NS = 26;       // MFMA k-steps: F + T <= 104
 constexpr int REG_NB = 7;        // N-tiles of the hidden layer (D = 100 -> 112 columns)
+constexpr int REG_FRAG_GROUPS = (REG_NB * REG_NS + 3) / 4;      // the weights in fragment order: groups of four values per lane
+
+// fc1's [ef | time] block ([112][K2p], zero padded) in the order the lanes of k_fc1_agg_reg hold it: value q = 26 b + st
+// of lane (r16, g4) is W[16 b + r16][4 st + g4]; image[q / 4][lane][q % 4]
+__global__ void k_pack_reg_frag(const float *__restrict__ W1t, int K2p, float *__restrict__ image)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= REG_FRAG_GROUPS * 64 * 4) return;
+    const int e = i & 3, lane = (i >> 2) & 63, G = i >> 8;
+    const int q = 4 * G + e, b = q / REG_NS, st = q % REG_NS;
+    image[i] = q < REG_NB * REG_NS ? W1t[(16 * b + (lane & 15)) * K2p + 4 * st + (lane >> 4)] : 0.f;
+}
 
 template <int KK, int DBG = 0>     // DBG != 0: only instantiated in diagnostic builds (-DZT_DIAG + ZT_AGG_DBG; WRONG results: 1 no cosine, 2 bare epilogue, 4 no projected rows)
 __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
     const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
     long long num_edges, int F, long long N, int M, const int *__restrict__ nbr, const int *__restrict__ eix,
-    const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ W1t, int K2p,
+    const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ Wfrag,
     const float *__restrict__ b1, float *__restrict__ H, float *__restrict__ S, int *status)
 {
     constexpr int D = 100, T = 100, DP = 112, ROWS = 80, RQ = ROWS / KK;
@@ -714,25 +726,41 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
     const int r16 = lane & 15, g4 = lane >> 4;
     int *nb_s = s_nb[wave];
     float *dt_s = s_dt[wave], *w_s = s_w[wave], *sum_s = s_sum[wave], *ef_s = s_ef[wave];
+#ifdef ZT_DIAG
+    const unsigned long long wall_in = DBG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
 
     // ---- once per launch: this lane's slice of the weights, the time frequencies and the biases ----
-    // (the [112][K2p] matrix comes in through LDS, coalesced; 182 strided loads per lane straight from memory took 35 us)
-    __shared__ __attribute__((aligned(16))) float s_wt[DP * 112];      // [DP][K2p = 112], dead after this block (static: 57 KB in
-                                                                       // all, below the 64 KB a launch gets without an attribute)
-    for (int i = threadIdx.x; i < DP * K2p / 4; i += AGG_THREADS)
-        reinterpret_cast<f32x4 *>(s_wt)[i] = reinterpret_cast<const f32x4 *>(W1t)[i];
-    __syncthreads();
+    // The 182 values a lane needs come from an image in FRAGMENT order (k_pack_reg_frag: [46 groups][64 lanes][4]): 46
+    // coalesced 16-byte loads per lane, every wave of the launch reading the same 47 KB from L2.  (Round 3 staged the
+    // [112][112] matrix through LDS and picked the values with 182 four-byte reads at a stride that puts sixteen lanes on
+    // two banks: 10.6 us from kernel entry to the first tile -- 12 % of the kernel at C4's batch.)
     float Breg[REG_NB][REG_NS];
+    {
+        const f32x4 *Wf = reinterpret_cast<const f32x4 *>(Wfrag) + lane;
+        static_assert(REG_FRAG_GROUPS % 2 == 0, "two batches");
+        constexpr int HB = REG_FRAG_GROUPS / 2;
 #pragma unroll
-    for (int b = 0; b < REG_NB; ++b)
+        for (int half = 0; half < 2; ++half) {
+            // (all loads of a batch in flight before the first register write: the accumulator-register writes are volatile
+            //  asm, and left alone the compiler issues load, wait, four writes, load, wait ... -- 46 L2 round trips in a row)
+            f32x4 v[HB];
 #pragma unroll
-        for (int st = 0; st < REG_NS; ++st) {
-            // defined by an accumulator-register write: the value then LIVES in the accumulator half of the register
-            // file (an MFMA takes its B operand from either half); left to itself the allocator keeps all 182 in
-            // vector registers, runs out of them and spills
-            const float wv = s_wt[(16 * b + r16) * K2p + 4 * st + g4];
-            asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Breg[b][st]) : "v"(wv));
+            for (int i = 0; i < HB; ++i) v[i] = Wf[(half * HB + i) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < HB; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = 4 * (half * HB + i) + e;
+                    // defined by an accumulator-register write: the value then LIVES in the accumulator half of the register
+                    // file (an MFMA takes its B operand from either half); left to itself the allocator keeps all 182 in
+                    // vector registers, runs out of them and spills
+                    if (q < REG_NB * REG_NS) asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(Breg[q / REG_NS][q % REG_NS]) : "v"(v[i][e]));
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
     float freq[REG_NS];
 #pragma unroll
     for (int st = 0; st < REG_NS; ++st) {
@@ -798,9 +826,14 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
         }
         wave_sync();
         if (lane < RQ) {                                               // sum(w) in entry order, like torch.sum(dim=1)
+            // (KK / 4 sixteen-byte reads, all in flight, then the adds in entry order: twenty dependent four-byte reads cost
+            //  ~1 500 cycles per tile with nothing beside them)
+            f32x4 wv[KK / 4];
+#pragma unroll
+            for (int j = 0; j < KK / 4; ++j) wv[j] = *reinterpret_cast<const f32x4 *>(w_s + lane * KK + 4 * j);
             float sm = 0.f;
 #pragma unroll
-            for (int j = 0; j < KK; ++j) sm += w_s[lane * KK + j];
+            for (int j = 0; j < KK; ++j) sm += wv[j / 4][j % 4];
             sum_s[lane] = sm;
             if (lane < nq) S[(size_t)m * N + q0 + lane] = (sm == 0.f) ? 0.f : 1.f;
         }
@@ -950,7 +983,7 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
     if (DBG && lane == 0 && blockIdx.x * AGG_WAVES + wave < 1024) {
         unsigned long long *o = g_regclk + 4 * (blockIdx.x * AGG_WAVES + wave);
         o[0] = __builtin_amdgcn_s_memtime() - clk0; o[1] = wall0; o[2] = __builtin_amdgcn_s_memrealtime();
-        o[3] = __builtin_amdgcn_s_getreg(((5 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+        o[3] = wall_in;                                                         // (100 MHz) at kernel entry: the weight fill is wall0 - this
     }
 #endif
 }
@@ -1516,7 +1549,7 @@ struct EmbedPlan {
     // table path (k_fc1_agg<true>): the tile holds only [ef | cos]
     int K2p, lda2, mt2, rq2;
     size_t lds2;
-    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, off_wl, total;
+    size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, off_wl, off_wfrag, total;
     int hg;                                     // partial-sum groups per query row in H (k_fc1_agg_wide: k / 4; else 1)
 };
 
@@ -1561,6 +1594,7 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     p.off_wm = take((size_t)p.Dp * p.Dp * 4);
     p.hg = fc1_agg_wide_supported(D, F, T, k) ? k / 4 : 1;
     p.off_wl = take(p.hg > 1 ? fc1_agg_wide_weight_bytes() : 0);
+    p.off_wfrag = take((size_t)REG_FRAG_GROUPS * 64 * 4 * 4);      // k_fc1_agg_reg's weights in fragment order (K2p = 112 shapes)
     p.off_H = take((size_t)M * N * D * 4 * p.hg);
     p.off_S = take((size_t)M * N * 4);
     p.total = o;
@@ -1610,6 +1644,9 @@ static void embed_prepare(const zt_embed_weights *wt, int D, int F, int T, const
     pad(wt->fc1_w, K1, D, F + T, p.off_w1t, p.K2p);       // the [ef | time] columns of fc1 (table path)
     pad(wt->fc1_w, K1, 0, D, p.off_wm, p.Dp);             // W_m: the memory columns of fc1 (k_project_rows)
     if (p.hg > 1) fc1_agg_wide_pack(wt->fc1_w, wt->time_w, wt->fc1_b, reinterpret_cast<float *>(ws + p.off_wl), s);   // LDS image (aggregate_wide.hip)
+    if (p.K2p == 112 && p.Dp == 112)
+        k_pack_reg_frag<<<(REG_FRAG_GROUPS * 64 * 4 + 255) / 256, 256, 0, s>>>(reinterpret_cast<const float *>(ws + p.off_w1t), p.K2p,
+                                                                          reinterpret_cast<float *>(ws + p.off_wfrag));
 }
 
 const float *zt::embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k)
@@ -1677,6 +1714,7 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     char *ws = reinterpret_cast<char *>(workspace_dev);
     float *W1p = reinterpret_cast<float *>(ws + p.off_w1p);
     float *W1t = reinterpret_cast<float *>(ws + p.off_w1t);
+    const float *Wfrag = reinterpret_cast<const float *>(ws + p.off_wfrag);
     float *H = reinterpret_cast<float *>(ws + p.off_H);
     float *S = reinterpret_cast<float *>(ws + p.off_S);
     float *fc2t = reinterpret_cast<float *>(ws + p.off_fc2t);
@@ -1728,20 +1766,21 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
 #ifdef ZT_DIAG
         static const int dbg = getenv("ZT_AGG_DBG") ? atoi(getenv("ZT_AGG_DBG")) : 0;       // diagnostic (wrong results)
 #define ZT_REG_DBG(DB) k_fc1_agg_reg<20, DB><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, \
-            num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev)
+            num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev)
         if (k == 20 && dbg == 1) ZT_REG_DBG(1);
         else if (k == 20 && dbg == 2) ZT_REG_DBG(2);
         else if (k == 20 && dbg == 6) ZT_REG_DBG(6);
         else if (k == 20 && dbg == 7) ZT_REG_DBG(7);
+        else if (k == 20 && dbg == 8) ZT_REG_DBG(8);       // (all parts, with the per-wave clocks)
 #undef ZT_REG_DBG
         else
 #endif
         if (k == 20)
             k_fc1_agg_reg<20><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
-                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev);
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev);
         else
             k_fc1_agg_reg<40><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
-                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, W1t, p.K2p, wt->fc1_b, H, S, status_dev);
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev);
     } else if (d100) {
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
 #define ZT_D100(KK) k_fc1_agg_d100<KK><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes,     \
