@@ -196,12 +196,18 @@ constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
 
-// Zero-padded gate-major copy: W[3D][K] -> Wp[3][Dp][Kp]
+// Zero-padded gate-major copy in FRAGMENT order: W[3D][K] -> Wp[3][Dp / 16][Kp / 16][64 lanes][4]: the 16 x 16 block (N-tile
+// nt, k-chunk kc) of a gate as the MFMA's lanes hold it -- lane (r16, g4) has W[16 nt + r16][16 kc + 4 g4 .. + 3] -- so that a
+// wave's fragment load is ONE contiguous kilobyte.  (Row-major, the same load touched sixteen 128-byte lines and used half
+// of each: k_gru streams all 559 KB of gate weights per 16-row tile from L2, 286 MB per launch at C5's batch.)
 __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *__restrict__ Wp, int Dp, int Kp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * Dp * Kp) return;
-    const int g = i / (Dp * Kp), r = (i / Kp) % Dp, c = i % Kp;
+    const int e = i & 3, lane = (i >> 2) & 63, rest = i >> 8;
+    const int KC = Kp / 16, NT = Dp / 16;
+    const int kc = rest % KC, nt = (rest / KC) % NT, g = rest / (KC * NT);
+    const int r = 16 * nt + (lane & 15), c = 16 * kc + 4 * (lane >> 4) + e;
     Wp[i] = (r < D && c < K) ? W[((size_t)g * D + r) * K + c] : 0.f;
 }
 
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
 #pragma unroll
                 for (int b = 0; b < GRU_NTW; ++b) {
                     const bool on = live[b] && kc0 + c < KC;
-                    const size_t o = (size_t)colrow[b] * Kp + 16 * (on ? kc0 + c : 0) + 4 * g4;
+                    const size_t o = (((size_t)(colrow[b] >> 4) * KC + (on ? kc0 + c : 0)) * 64 + lane) * 4;       // (fragment order: k_pack_gates)
                     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
                     wr[c][b] = on ? *reinterpret_cast<const f32x4 *>(Wp + o) : zero;
                     wz[c][b] = on ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)Dp * Kp + o) : zero;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
         const bool on = c < KC, hid = c >= KCx;
         const float *W = hid ? Whh_p : Wih_p;
         const int Kp = hid ? Hp : Xp, cc = hid ? c - KCx : c;
-        const size_t o = (size_t)col * Kp + 16 * (on ? cc : 0) + 4 * g4;
+        const size_t o = (((size_t)nt * (Kp / 16) + (on ? cc : 0)) * 64 + lane) * 4;                           // (fragment order: k_pack_gates)
         wr[q] = on ? *reinterpret_cast<const f32x4 *>(W + o) : zero4;
         wz[q] = on ? *reinterpret_cast<const f32x4 *>(W + (size_t)Hp * Kp + o) : zero4;
         wn[q] = on ? *reinterpret_cast<const f32x4 *>(W + (size_t)2 * Hp * Kp + o) : zero4;
