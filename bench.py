@@ -356,6 +356,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         #  can be put to library + offset afterwards: tools/symbolise.py)
         with open("/proc/self/maps") as fi, open(os.environ["ZT_DUMP_MAPS"], "w") as fo:
             fo.write(fi.read())
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_PREPASS, _capi.PREPASS_COOP if a.prepass_coop else 0)
     _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED if a.chain_pairs else (a.chain_mode or 0))
     run(0, prefill)
     tgn.embedding_module.tppr_finder.check_status() if wl["strategy"] == "streaming" else None
@@ -667,6 +668,7 @@ def main():
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
     ap.add_argument("--chain-mode", type=int, default=0,
                     help="hub chains of the T-PPR update: 0 the library's pick, 1 single hops through the mailbox, 3 spine (zt_set_kernel_choice)")
+    ap.add_argument("--prepass-coop", action="store_true", help="the dependency prepass of big launches as ONE cooperative kernel (A/B against the eleven launches)")
     ap.add_argument("--chain-pairs", action="store_true",
                     help="hub chains take TWO positions per critical section where they can (csrc/tppr_pair.hpp; zt_set_kernel_choice: "
                          "bit-exact, measured slower -- DESIGN.md section 5 --, off by default)")

@@ -63,7 +63,9 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_MESSAGES 3    /* zt_store_messages: ZT_MSG_ONE, ZT_MSG_TWO (batch positions per wavefront) */
 #define ZT_CHOICE_TPPR_CHAIN 4  /* hub chains of zt_tppr_stream: ZT_CHAIN_SINGLE (one position per critical section: the
                                  * library's pick), ZT_CHAIN_PAIRED (two where the preconditions hold, csrc/tppr_pair.hpp), ZT_CHAIN_SPINE (below) */
-#define ZT_CHOICE_COUNT 5
+#define ZT_CHOICE_TPPR_PREPASS 5 /* dependency prepass of a launch of more than 4 096 accesses: ZT_PREPASS_LAUNCHES (one kernel per step,
+                                 * eleven launches: the library's pick), ZT_PREPASS_COOP (one cooperative kernel with grid barriers) */
+#define ZT_CHOICE_COUNT 6
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
 #define ZT_OUT_LATENCY 2
@@ -73,6 +75,8 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHAIN_SINGLE 1
 #define ZT_CHAIN_PAIRED 2
 #define ZT_CHAIN_SPINE 3   /* one wave per chain runs every critical section with the hub's row in registers (csrc/tppr_chain.hpp) */
+#define ZT_PREPASS_LAUNCHES 1
+#define ZT_PREPASS_COOP 2
 #define ZT_MSG_ONE 1
 #define ZT_MSG_TWO 2
 int zt_set_kernel_choice(int32_t which, int32_t value);

@@ -19,17 +19,13 @@
 //               (three D x D layers, also f32 MFMA) and the concat into out[N, D*(M+1)].
 // Arithmetic is float32 throughout (parity tolerance for embeddings: 1e-4).
 #include "common.hpp"
+#include "embed_out_body.hpp"     // f32x4, AGG_THREADS / AGG_WAVES / NTW, small_gemm, the output layers' body (shared with memory_update.hip)
 
 using namespace zt;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int AGG_THREADS = 256;
-constexpr int AGG_WAVES = 4;
 constexpr int MAX_MT = 5;          // M-tiles (16 gathered rows each) per workgroup
-constexpr int NTW = 2;             // N-tiles per wave -> D <= 128
 constexpr int LDS_BUDGET = 150 * 1024;
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -989,181 +985,6 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
 }
 
 // ---------------------------------------------------------------------------
-// out[n] = [ fc2s(relu(fc1s(memory[nodes[n]]))) | fc2(H_0[n]) + b2*S_0[n] | ... ]
-// Three small D x D layers on f32 MFMA.  One workgroup per 32 rows; the input
-// rows sit in LDS, weights ([Dp][Dp], zero padded) stream from L2 as b128
-// fragments; wave w owns output N-tiles {w, w+4}.
-// ---------------------------------------------------------------------------
-constexpr int OUT_ROWS = 32;
-constexpr int OUT_MT = OUT_ROWS / 16;
-constexpr int SG_CH = 8;             // k-steps of weight fragments in flight (small_gemm)
-constexpr int EO_GU = 8;             // staged elements in flight per thread (k_embed_out)
-
-// acc[a][b] = X[a-th 16 rows] * W[b-th owned N-tile]^T   (X in LDS [32][ldx], W padded [Dp][Dp])
-__device__ __forceinline__ void small_gemm(const float *X, int ldx, const float *__restrict__ Wp, int Dp, int NT,
-                                           int wave, int lane, f32x4 (&acc)[OUT_MT][NTW])
-{
-    const int r16 = lane & 15, g4 = lane >> 4;
-#pragma unroll
-    for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // The weight fragments of SG_CH k-steps are fetched together, before the first MFMA that needs one: a
-    // workgroup has one tile of 32 rows, so nothing else hides the L2 round trip of a load issued per k-step.
-    const int KC = Dp / 16;
-    for (int kc0 = 0; kc0 < KC; kc0 += SG_CH) {
-        f32x4 bv[SG_CH][NTW];
-#pragma unroll
-        for (int c = 0; c < SG_CH; ++c)
-#pragma unroll
-            for (int b = 0; b < NTW; ++b) {
-                const int nt = wave + b * AGG_WAVES;
-                bv[c][b] = (kc0 + c < KC && nt < NT)
-                               ? *reinterpret_cast<const f32x4 *>(Wp + (size_t)(nt * 16 + r16) * Dp + 16 * (kc0 + c) + 4 * g4)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-        for (int c = 0; c < SG_CH; ++c) {
-            if (kc0 + c >= KC) break;
-            f32x4 av[OUT_MT];
-#pragma unroll
-            for (int a = 0; a < OUT_MT; ++a)
-                av[a] = *reinterpret_cast<const f32x4 *>(X + (size_t)(a * 16 + r16) * ldx + 16 * (kc0 + c) + 4 * g4);
-#pragma unroll
-            for (int b = 0; b < NTW; ++b) {
-                if (wave + b * AGG_WAVES >= NT) continue;
-#pragma unroll
-                for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][j], bv[c][b][j], acc[a][b], 0, 0, 0);
-            }
-        }
-    }
-}
-
-template <int HG>                    // partial-sum groups per query row in H (k_fc1_agg_wide: k / 4; else 1)
-__global__ __launch_bounds__(AGG_THREADS) void k_embed_out(
-    const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
-    const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
-    const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
-    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int Dp = (D + 15) / 16 * 16, ldx = Dp + 4, NT = Dp / 16;
-    float *X = reinterpret_cast<float *>(smem);          // [32][ldx] layer input
-    float *Y = X + OUT_ROWS * ldx;                       // [32][ldx] hidden rows of the source path
-    int *rid = reinterpret_cast<int *>(Y + OUT_ROWS * ldx);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, g4 = lane >> 4;
-    const long long r0 = (long long)blockIdx.x * OUT_ROWS;
-    const int nr = (int)((N - r0) < OUT_ROWS ? (N - r0) : OUT_ROWS);
-    const int OW = D * (M + 1);
-    const unsigned mL = fastdiv_magic((unsigned)ldx);
-    f32x4 acc[OUT_MT][NTW];
-
-    // blockIdx.y = 0: the source path (two dependent layers); 1 + m: fc2 of model m.  The paths are independent,
-    // and the kernel's time is the latency of ONE workgroup (there are fewer workgroups than the chip holds).
-    const int path = blockIdx.y;
-    if (path == 0) {
-        if (tid < OUT_ROWS) {
-            int nd = 0;
-            if (tid < nr) {
-                nd = nodes[r0 + tid];
-                if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
-            }
-            rid[tid] = nd;
-        }
-        __syncthreads();
-        // ---- source path: memory[nodes] -> fc1s -> relu -> fc2s ----
-        // (EO_GU loads in flight per thread before the first LDS store: a load per iteration was a memory round trip
-        //  per iteration, 15 of them in a row)
-        for (int f0 = tid; f0 < OUT_ROWS * ldx; f0 += AGG_THREADS * EO_GU) {
-            float v[EO_GU];
-#pragma unroll
-            for (int u = 0; u < EO_GU; ++u) {
-                const int f = f0 + u * AGG_THREADS, g = fastdiv(f, mL), c = f - g * ldx;
-                v[u] = (f < OUT_ROWS * ldx && g < nr && c < D) ? memory[(size_t)rid[g] * D + c] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < EO_GU; ++u)
-                if (f0 + u * AGG_THREADS < OUT_ROWS * ldx) X[f0 + u * AGG_THREADS] = v[u];
-        }
-        __syncthreads();
-        small_gemm(X, ldx, fc1s_p, Dp, NT, wave, lane, acc);
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) {
-            const int col = (wave + b * AGG_WAVES) * 16 + r16;
-            if (col >= Dp) continue;
-            const float bias = col < D ? fc1s_b[col] : 0.f;
-#pragma unroll
-            for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc[a][b][j] + bias;
-                    Y[(size_t)(a * 16 + g4 * 4 + j) * ldx + col] = (col < D && v > 0.f) ? v : 0.f;
-                }
-        }
-        __syncthreads();
-        small_gemm(Y, ldx, fc2s_p, Dp, NT, wave, lane, acc);
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) {
-            const int col = (wave + b * AGG_WAVES) * 16 + r16;
-            if (col >= D) continue;
-            const float bias = fc2s_b[col];
-#pragma unroll
-            for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int g = a * 16 + g4 * 4 + j;
-                    if (g < nr) out[(size_t)(r0 + g) * OW + col] = acc[a][b][j] + bias;
-                }
-        }
-        return;
-    }
-    // ---- neighbour path: fc2 on the reduced rows of model m ----
-    {
-        const int m = path - 1;
-        for (int f0 = tid; f0 < OUT_ROWS * ldx; f0 += AGG_THREADS * EO_GU) {
-            float v[EO_GU];
-#pragma unroll
-            for (int u = 0; u < EO_GU; ++u) {
-                const int f = f0 + u * AGG_THREADS, g = fastdiv(f, mL), c = f - g * ldx;
-                v[u] = 0.f;
-                if (f < OUT_ROWS * ldx && g < nr && c < D) {
-                    // hg > 1 (k_fc1_agg_wide): H holds the partial sums of every group of four neighbour rows; a query row's
-                    // groups are added first to last, whichever tile or shard computed them
-                    const float *hp = H + (((size_t)m * N + r0 + g) * HG) * D + c;
-                    v[u] = hp[0];
-#pragma unroll
-                    for (int q = 1; q < HG; ++q) v[u] += hp[(size_t)q * D];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < EO_GU; ++u)
-                if (f0 + u * AGG_THREADS < OUT_ROWS * ldx) X[f0 + u * AGG_THREADS] = v[u];
-        }
-        __syncthreads();
-        small_gemm(X, ldx, fc2_p, Dp, NT, wave, lane, acc);
-#pragma unroll
-        for (int b = 0; b < NTW; ++b) {
-            const int col = (wave + b * AGG_WAVES) * 16 + r16;
-            if (col >= D) continue;
-            const float bias = fc2_b[col];
-#pragma unroll
-            for (int a = 0; a < OUT_MT; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int g = a * 16 + g4 * 4 + j;
-                    if (g < nr)
-                        out[(size_t)(r0 + g) * OW + (size_t)D * (m + 1) + col] =
-                            acc[a][b][j] + bias * S[(size_t)m * N + r0 + g];
-                }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // k_embed_out2: the same three layers, organised for LATENCY (round 4).  k_embed_out's time was never its arithmetic:
 // at C2's batch (600 rows) it ran 27 us for 40 MFLOP -- a chain of dependent memory round trips per workgroup (ids ->
 // row staging through LDS in a loop the compiler cannot unroll, one round trip per iteration -> weight fragments per
@@ -1693,8 +1514,10 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
                       int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
                       const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                       const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
-                      const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait)
+                      const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
+                      zt::embed_out_deferred *defer = nullptr)
 {
+    if (defer) defer->valid = false;
     if (!memory_dev || !efeat_dev || !wt || !status_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) {
         set_error("zt_embed: bad argument");
         return ZT_ERR_ARG;
@@ -1800,7 +1623,6 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     }
     ZT_PROF_END(s, P_FC1_AGG);
     if (mid_wait != nullptr) ZT_HIP(hipStreamWaitEvent(s, mid_wait, 0));
-    ZT_PROF_BEGIN(s, P_EMBED_OUT);
     const int hg = widek ? p.hg : 1;
     // small batches: the latency-organised kernel (one wave per tile, path and N-tile; 1 - 2 memory round trips); large ones:
     // the persistent one (weights resident in LDS, a wave per 16 rows x all N-tiles); other widths: the tiled one (weights
@@ -1817,6 +1639,8 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     //  stream's kernels: C4 (3 000 rows, no CU masks, k_pruned_topk running beside) 36 us against the tiled kernel's 20; C5
     //  (12 288 rows, the main stream's CUs to itself) 29 against 38.  So: from 8 192 rows on.
     const bool use3 = can3 && !use2 && (oc == ZT_OUT_PERSIST || (oc == 0 && N >= 8192));
+    const bool held_back = defer != nullptr && !use2 && !use3;          // (launched by the caller, beside the GRU update)
+    if (!held_back) ZT_PROF_BEGIN(s, P_EMBED_OUT);
     if (use2) {
         // one wave per (16 rows, path, N-tile), striding over the row tiles with its weights in registers
         const long long tiles = (N + 15) / 16;
@@ -1850,12 +1674,22 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         if (hg == 1) ZT_EO3(1); else if (hg == 5) ZT_EO3(5); else ZT_EO3(10);
 #undef ZT_EO3
     } else {
-        const size_t lds2 = (size_t)2 * OUT_ROWS * (p.Dp + 4) * 4 + OUT_ROWS * 4;
-#define ZT_EO(HGV) k_embed_out<HGV><<<dim3((unsigned)((N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(M + 1)), AGG_THREADS, lds2, s>>>( \
-            memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, fc1st, wt->fc1s_b, fc2st, wt->fc2s_b, out_dev, status_dev)
-        if (hg == 1) ZT_EO(1); else if (hg == 5) ZT_EO(5); else if (hg == 10) ZT_EO(10);
-        else { set_error("zt_embed: %d partial-sum groups per row", hg); return ZT_ERR_UNSUPPORTED; }
-#undef ZT_EO
+        if (hg != 1 && hg != 5 && hg != 10) { set_error("zt_embed: %d partial-sum groups per row", hg); return ZT_ERR_UNSUPPORTED; }
+        zt::embed_out_deferred od;
+        od.valid = true;
+        od.memory = memory_dev; od.num_nodes = num_nodes; od.nodes = nodes_dev; od.N = N; od.D = D; od.M = M; od.hg = hg;
+        od.H = H; od.S = S; od.fc2_p = fc2t; od.fc2_b = wt->fc2_b; od.fc1s_p = fc1st; od.fc1s_b = wt->fc1s_b; od.fc2s_p = fc2st;
+        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.src_base = 0;
+        if (defer != nullptr) {
+            // the caller launches them beside the GRU update (gru_update_ex) -- or by embed_out_launch
+            const unsigned keep = defer->src_base;
+            *defer = od;
+            defer->src_base = keep;
+            ZT_LAUNCH_CHECK();
+            return ZT_OK;
+        }
+        const int rc = zt::embed_out_launch(od, s);
+        if (rc != ZT_OK) return rc;
     }
     ZT_PROF_END(s, P_EMBED_OUT);
     ZT_LAUNCH_CHECK();
@@ -1872,14 +1706,33 @@ extern "C" int zt_embed(const float *memory_dev, const float *efeat_dev, int64_t
                       wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, nullptr);
 }
 
+int zt::embed_out_launch(const zt::embed_out_deferred &d, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int Dp = round_up(d.D, 16);
+    const size_t lds2 = (size_t)2 * OUT_ROWS * (Dp + 4) * 4 + OUT_ROWS * 4;
+    EmbedOutArgs E;
+    E.memory = d.memory; E.num_nodes = d.num_nodes; E.nodes = d.nodes; E.N = d.N; E.D = d.D; E.M = d.M; E.H = d.H; E.S = d.S;
+    E.fc2_p = d.fc2_p; E.fc2_b = d.fc2_b; E.fc1s_p = d.fc1s_p; E.fc1s_b = d.fc1s_b; E.fc2s_p = d.fc2s_p; E.fc2s_b = d.fc2s_b;
+    E.out = d.out; E.status = d.status;
+    const dim3 grid((unsigned)((d.N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(d.M + 1));
+    if (d.hg == 1) k_embed_out<1><<<grid, AGG_THREADS, lds2, s>>>(E);
+    else if (d.hg == 5) k_embed_out<5><<<grid, AGG_THREADS, lds2, s>>>(E);
+    else if (d.hg == 10) k_embed_out<10><<<grid, AGG_THREADS, lds2, s>>>(E);
+    else { set_error("zt_embed: %d partial-sum groups per row", d.hg); return ZT_ERR_UNSUPPORTED; }
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
 int zt::embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges,
                  int32_t D, int32_t F, int32_t T, const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k,
                  const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                  const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
-                 const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait)
+                 const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
+                 zt::embed_out_deferred *defer)
 {
     return embed_impl(memory_dev, efeat_dev, num_nodes, num_edges, D, F, T, nodes_dev, N, M, k, nbr_dev, eix_dev, dt_dev, w_dev,
-                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, mid_wait);
+                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, mid_wait, defer);
 }
 
 // Training forward of the neighbour half (backward: aggregate_bwd.hip):

@@ -29,10 +29,28 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
 // zt_gru_update with the projected-table refresh folded into the GRU kernel (memory_update.hip); wm_p from embed_wm_ptr.
 // counter_zeroed: the row counter (first word of the workspace) is zero already; select_done: the row list and the counter
 // are filled (pipeline.hip: the message kernel hands its list of winners over), no compaction of flagged ids
+// The output layers of an embed call, held back (embed_ex: `defer`) so that gru_update_ex can launch them in ONE kernel with the
+// GRU update (k_out_gru, memory_update.hip): the two are independent apart from the memory rows the source path reads --
+// the GRU half waits for those reads before it writes (a counter in its workspace that only grows: src_base = its value
+// before this launch, tracked by the caller and 0 for a workspace whose weights are not packed yet).
+struct embed_out_deferred {
+    bool valid;
+    const float *memory;
+    long long num_nodes;
+    const int *nodes;
+    long long N;
+    int D, M, hg;
+    const float *H, *S, *fc2_p, *fc2_b, *fc1s_p, *fc1s_b, *fc2s_p, *fc2s_b;
+    float *out;
+    int *status;
+    unsigned src_base;
+};
+int embed_out_launch(const embed_out_deferred &d, void *stream);           // aggregate.hip: the held-back layers as a kernel of their own
 int gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                   uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                   const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, bool select_done = false);
+                  const float *wm_p, float *proj_table, void *stream, bool counter_zeroed = false, bool select_done = false,
+                  embed_out_deferred *fuse = nullptr);
 // zt_store_messages_range that also zeroes one int (the GRU update's row counter: first word of its workspace)
 int store_messages_ex(const float *memory_dev, const float *last_update_dev, const float *efeat_dev, const float *time_w_dev,
                       int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T, const int32_t *src_dev,
@@ -46,7 +64,8 @@ int store_messages_ex(const float *memory_dev, const float *last_update_dev, con
 int embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_nodes, int64_t num_edges, int32_t D, int32_t F, int32_t T,
              const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev, const int32_t *eix_dev,
              const float *dt_dev, const float *w_dev, const zt_embed_weights *wt, float *out_dev, void *workspace_dev,
-             int32_t *status_dev, const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait);
+             int32_t *status_dev, const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
+             embed_out_deferred *defer = nullptr);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
 // the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)
@@ -56,6 +75,10 @@ void fc1_agg_wide_pack(const float *fc1_w_dev, const float *time_w_dev, const fl
 int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w, long long num_nodes, long long num_edges,
                         long long N, int M, int k, const int *nbr, const int *eix, const float *dt, const float *w,
                         const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s);
+int pruned_topk_multi_fill(const zt_csr *c, const int32_t *q_nodes_dev, const double *q_ts_dev, int64_t nq, int32_t width,
+                           int32_t depth, int32_t n_models, const double *alpha_host, const double *beta_host, int32_t k,
+                           int32_t *out_nodes_dev, int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
+                           int32_t *status_dev, void *stream);     // tppr_prune.hip: empty rows written as zeros (no memset before)
 void tppr_hint_cus(zt_tppr *h, hipStream_t s);      // tppr_prepass.hip: plan for the compute units of stream s
 // exchange.hip: the row exchange of one step of a multi-GPU run on `stream` (pack -> all-gather -> scatter); the ids of
 // the rows written (-1: padding) come back for the projected-row refresh

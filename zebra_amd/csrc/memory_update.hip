@@ -12,12 +12,13 @@
 // the winner, flags are a device u8 array.  The GRU runs on exact-f32 MFMA
 // with the gathered [message | memory] rows staged in LDS.
 #include "common.hpp"
+#include "embed_out_body.hpp"     // the output layers of the embedding as a device function (k_out_gru below)
 
 using namespace zt;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+// (f32x4, AGG_THREADS and the output layers' body: embed_out_body.hpp, included above)
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -195,6 +196,7 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
+constexpr int GRU_SRC_WORD = 32; // word of the workspace's counter block that counts source-path workgroups (k_out_gru)
 
 // Zero-padded gate-major copy in FRAGMENT order: W[3D][K] -> Wp[3][Dp / 16][Kp / 16][64 lanes][4]: the 16 x 16 block (N-tile
 // nt, k-chunk kc) of a gate as the MFMA's lanes hold it -- lane (r16, g4) has W[16 nt + r16][16 kc + 4 g4 .. + 3] -- so that a
@@ -211,18 +213,31 @@ __global__ void k_pack_gates(const float *__restrict__ W, int D, int K, float *_
     Wp[i] = (r < D && c < K) ? W[((size_t)g * D + r) * K + c] : 0.f;
 }
 
+struct GruArgs {
+    float *memory, *last_update;
+    const float *messages, *msg_ts;
+    const int *rows, *n_rows;
+    int D, msg_dim, Xp, Hp, lda;
+    const float *Wih_p, *Whh_p, *b_ih, *b_hh, *Wm_p;
+    float *P;
+    int cap;
+};
+
+// bid = the workgroup's 16 MT-row tile.  src_read != nullptr (k_out_gru): before a row of the memory table is written, the
+// counter there must have reached src_target -- every source-path workgroup of the output layers has its rows in LDS.
 template <int MT>
-__global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *last_update, const float *__restrict__ messages,
-                                             const float *__restrict__ msg_ts, const int *__restrict__ rows,
-                                             const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp,
-                                             int lda, const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
-                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh,
-                                             const float *__restrict__ Wm_p, float *__restrict__ P, int cap)
+__device__ __forceinline__ void gru_body(const GruArgs &G, char *smem, int bid, const int *src_read, unsigned src_target)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *memory = G.memory, *last_update = G.last_update;
+    const float *__restrict__ messages = G.messages, *__restrict__ msg_ts = G.msg_ts;
+    const int *__restrict__ rows = G.rows, *__restrict__ n_rows = G.n_rows;
+    const int D = G.D, msg_dim = G.msg_dim, Xp = G.Xp, Hp = G.Hp, lda = G.lda, cap = G.cap;
+    const float *__restrict__ Wih_p = G.Wih_p, *__restrict__ Whh_p = G.Whh_p, *__restrict__ b_ih = G.b_ih, *__restrict__ b_hh = G.b_hh;
+    const float *__restrict__ Wm_p = G.Wm_p;
+    float *__restrict__ P = G.P;
     float *A = reinterpret_cast<float *>(smem);      // [32][lda]: [message (Xp) | memory (Hp)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = blockIdx.x * (MT * 16);
+    const int r0 = bid * (MT * 16);
     // the tile's node ids are requested TOGETHER with the row count, not after it (one dependent round trip less; an
     // entry beyond the count is a stale id that nobody dereferences: every gather below is masked by g < nr)
     const int id_spec = tid < MT * 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
@@ -332,7 +347,10 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
     part(Whh_p, Hp, Xp, true);      // memory part:  gh = W_hh h
     // (the new rows go back into the tile for the projection below: every wave must be done READING the old ones -- the
     //  memory columns are the K operand of everybody's W_hh product)
-    if (P != nullptr) __syncthreads();
+    if (src_read != nullptr) {
+        if (tid == 0) while ((int)((unsigned)ld_agent(src_read) - src_target) < 0) __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+    } else if (P != nullptr) __syncthreads();
     // gates (torch.nn.GRUCell): r,z = sigmoid(gi+gh); n = tanh(gi_n + r*gh_n); h' = (1-z)*n + z*h
 #pragma unroll
     for (int b = 0; b < GRU_NTW; ++b) {
@@ -389,6 +407,33 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(float *memory, float *la
             }
         }
     }
+}
+
+template <int MT>
+__global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(GruArgs G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gru_body<MT>(G, smem, blockIdx.x, nullptr, 0u);
+}
+
+// The output layers and the GRU update in ONE launch (round 5).  The two kernels are independent but for the memory rows the
+// output layers' source path reads, each is bound by one workgroup's chain of memory round trips and fills a fraction of the
+// chip: one after the other they cost the step both latencies and a launch gap.  Workgroup order: [0, out_tiles) the source
+// path of k_embed_out's body (they are dispatched first, so the GRU half's wait for their reads can never be a wait for a
+// workgroup that has no compute unit), then the GRU tiles (the longest chains: not behind 200 short workgroups' dispatch),
+// then the neighbour paths.
+template <int HG>
+__global__ __launch_bounds__(64 * GRU_WAVES) void k_out_gru(EmbedOutArgs E, int out_tiles, int gru_wgs, GruArgs G, int *src_read, unsigned src_target)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid >= out_tiles && bid < out_tiles + gru_wgs) {
+        gru_body<1>(G, smem, bid - out_tiles, src_read, src_target);
+        return;
+    }
+    if (threadIdx.x >= AGG_THREADS) return;                // (the body is written for four waves; a finished wave leaves the barriers)
+    const int q = bid < out_tiles ? bid : bid - gru_wgs;     // tile + out_tiles * path
+    embed_out_body<HG>(E, smem, q % out_tiles, q / out_tiles, src_read);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -766,8 +811,14 @@ extern "C" int zt_gru_update(float *memory_dev, float *last_update_dev, const fl
 int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,
                       uint8_t *flags_dev, int64_t num_nodes, int32_t D, int32_t msg_dim, const int32_t *ids_dev, int64_t n_ids,
                       const int32_t *n_ids_dev, const zt_gru_weights *wt, void *workspace_dev, int32_t weights_ready,
-                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, bool select_done)
+                      const float *wm_p, float *proj_table, void *stream, bool counter_zeroed, bool select_done,
+                      zt::embed_out_deferred *fuse)
 {
+    // (output layers held back by embed_ex: launched here whatever happens -- beside the GRU kernel where the shapes allow)
+    struct PendingOut {
+        zt::embed_out_deferred *d; void *s;
+        ~PendingOut() { if (d && d->valid) { (void)zt::embed_out_launch(*d, s); d->valid = false; } }
+    } pending{fuse, stream};
     if (!memory_dev || !last_update_dev || !messages_dev || !msg_ts_dev || !flags_dev || !wt || !workspace_dev ||
         D <= 0 || msg_dim <= 0 || n_ids < 0) {
         set_error("zt_gru_update: bad argument");
@@ -793,6 +844,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
         ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GP_TILE_COUNTERS * 4, s));
+        ZT_HIP(hipMemsetAsync(cnt + GRU_SRC_WORD, 0, sizeof(int), s));       // k_out_gru's "source rows read" counter (only ever grows)
     }
     // Two organisations of the same update (zt_set_kernel_choice(ZT_CHOICE_GRU, ..) pins one; tests hold them against each
     // other and torch's GRUCell):
@@ -803,6 +855,8 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                       16 * p.Hp <= 7 * 256;
     const bool split = fits && (choice == ZT_GRU_SPLIT || (choice == 0 && max_rows <= 512));
     if (split) {
+        // (held-back output layers first: their source path reads the rows this kernel rewrites)
+        if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }
         const size_t lds2 = ((size_t)16 * p.lda + (size_t)GS_WAVES * 4 * 64 * 4) * 4 + 32 * 4;
         static size_t attr2 = 0;
         if (lds2 > 48 * 1024 && lds2 > attr2) {
@@ -820,9 +874,41 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
             ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_lds = lds;
         }
-        k_gru<1><<<(unsigned)((max_rows + 15) / 16), 64 * GRU_WAVES, lds, s>>>(memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt,
-                                                                         D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih, wt->b_hh,
-                                                                         wm_p, proj_table, (int)max_rows);
+        GruArgs G;
+        G.memory = memory_dev; G.last_update = last_update_dev; G.messages = messages_dev; G.msg_ts = msg_ts_dev; G.rows = rows; G.n_rows = cnt;
+        G.D = D; G.msg_dim = msg_dim; G.Xp = p.Xp; G.Hp = p.Hp; G.lda = p.lda; G.Wih_p = wih; G.Whh_p = whh; G.b_ih = wt->b_ih; G.b_hh = wt->b_hh;
+        G.Wm_p = wm_p; G.P = proj_table; G.cap = (int)max_rows;
+        const unsigned gru_wgs = (unsigned)((max_rows + 15) / 16);
+        if (fuse != nullptr && fuse->valid && fuse->memory == memory_dev && (fuse->hg == 1 || fuse->hg == 5 || fuse->hg == 10)) {
+            const zt::embed_out_deferred &d = *fuse;
+            EmbedOutArgs E;
+            E.memory = d.memory; E.num_nodes = d.num_nodes; E.nodes = d.nodes; E.N = d.N; E.D = d.D; E.M = d.M; E.H = d.H; E.S = d.S;
+            E.fc2_p = d.fc2_p; E.fc2_b = d.fc2_b; E.fc1s_p = d.fc1s_p; E.fc1s_b = d.fc1s_b; E.fc2s_p = d.fc2s_p; E.fc2s_b = d.fc2s_b;
+            E.out = d.out; E.status = d.status;
+            const int out_tiles = (int)((d.N + OUT_ROWS - 1) / OUT_ROWS), n_out = out_tiles * (d.M + 1);
+            const int Dp = (d.D + 15) / 16 * 16;
+            size_t lds_f = (size_t)2 * OUT_ROWS * (Dp + 4) * 4 + OUT_ROWS * 4;
+            if (lds_f < lds) lds_f = lds;
+            const void *fn = d.hg == 1 ? reinterpret_cast<const void *>(k_out_gru<1>)
+                                       : (d.hg == 5 ? reinterpret_cast<const void *>(k_out_gru<5>) : reinterpret_cast<const void *>(k_out_gru<10>));
+            static size_t attr_f[3] = {0, 0, 0};
+            const int hi = d.hg == 1 ? 0 : (d.hg == 5 ? 1 : 2);
+            if (lds_f > 48 * 1024 && lds_f > attr_f[hi]) {
+                ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+                attr_f[hi] = lds_f;
+            }
+            int *src_read = cnt + GRU_SRC_WORD;
+            const unsigned target = d.src_base + (unsigned)out_tiles;
+            const unsigned grid = (unsigned)n_out + gru_wgs;
+            if (d.hg == 1) k_out_gru<1><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
+            else if (d.hg == 5) k_out_gru<5><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
+            else k_out_gru<10><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
+            fuse->src_base = target;
+            fuse->valid = false;                       // (launched)
+        } else {
+            if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }
+            k_gru<1><<<gru_wgs, 64 * GRU_WAVES, lds, s>>>(G);
+        }
     }
     ZT_PROF_END(s, P_GRU);
     ZT_LAUNCH_CHECK();

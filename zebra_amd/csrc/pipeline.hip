@@ -30,6 +30,7 @@ constexpr int MAX_GROUP = 4;
 struct zt_pipeline {
     zt_pipeline_desc d;
     hipStream_t side, main_s, plan_s;
+    zt::embed_out_deferred out_gru;     // the output layers of the step at hand, held back for k_out_gru (memory_update.hip)
     hipStream_t msg_s;         // the message build of the current batch, beside its aggregation (reads the memory tables only)
     hipEvent_t step_begin, msgs_done;
     int group;                 // batches per T-PPR launch (streaming)
@@ -219,7 +220,8 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
 int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t row_hi)
 {
     const zt_pipeline_desc &d = p->d;
-    ZT_HIP(hipStreamWaitEvent(p->side, s.filled, 0));
+    // (a group staged steps ago: no wait packet in front of the query -- ~5 us of command-processor time each)
+    if (hipEventQuery(s.filled) != hipSuccess) { (void)hipGetLastError(); ZT_HIP(hipStreamWaitEvent(p->side, s.filled, 0)); }
     s.ready_ev = s.ready;
     if (d.tppr != nullptr) {
         // `filled` was recorded behind the prepass (when there is one): no second wait; the event the update kernel
@@ -230,19 +232,11 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
         if (rc != ZT_OK) return rc;
         if (done != nullptr) { s.ready_ev = done; s.launched = true; s.waited = false; return ZT_OK; }
     } else {
-        // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): start from zeros
+        // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): the kernel writes them as zeros
+        // (a memset in front of every query was a packet on this stream -- ~6 us of every C4 step, which this stream bounds)
         const int64_t n = row_hi - row_lo;
-        const size_t per = (size_t)d.M * n * d.k;
-        if (n == 3 * s.Btot) {
-            ZT_HIP(hipMemsetAsync(s.on, 0, 4 * per * 4, p->side));          // the four arrays follow each other (make_group)
-        } else {
-            ZT_HIP(hipMemsetAsync(s.on, 0, per * 4, p->side));
-            ZT_HIP(hipMemsetAsync(s.oe, 0, per * 4, p->side));
-            ZT_HIP(hipMemsetAsync(s.od, 0, per * 4, p->side));
-            ZT_HIP(hipMemsetAsync(s.ow, 0, per * 4, p->side));
-        }
-        int rc = zt_pruned_topk_multi(d.csr, s.nodes_m + row_lo, s.ts + row_lo, n, d.width, d.depth, d.M, d.alpha, d.beta, d.k,
-                                      s.on, s.oe, s.od, s.ow, d.status, p->side);      // every model in one walk
+        int rc = zt::pruned_topk_multi_fill(d.csr, s.nodes_m + row_lo, s.ts + row_lo, n, d.width, d.depth, d.M, d.alpha, d.beta, d.k,
+                                            s.on, s.oe, s.od, s.ow, d.status, p->side);      // every model in one walk
         if (rc != ZT_OK) return rc;
     }
     ZT_HIP(hipEventRecord(s.ready, p->side));
@@ -438,8 +432,11 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // planned then).  The other members' steps skip it, and the wait for an update the main stream has already been
     // told to wait for: two packets less between the GRU of one batch and the aggregation of the next (~5 us of
     // command-processor time each; round 4).  A call that stages a group after all records it late (make_group).
-    p->entry_recorded = false;
-    if (s == nullptr || j == 0) { ZT_HIP(hipEventRecord(p->entry, p->main_s)); p->entry_recorded = true; }
+    // (round 5: every step records it -- the message kernels wait for it too, where they used to wait for an event of their
+    //  own recorded BEHIND the wait for the T-PPR update: one packet less per step on the main stream, and the message build
+    //  no longer waits for an update it does not read)
+    ZT_HIP(hipEventRecord(p->entry, p->main_s));
+    p->entry_recorded = true;
     // (a batch nobody has queried ahead is queried ALONE: the aggregation waits for this launch, and a group would
     //  make it wait for the followers' updates as well; they form the next group, which runs beside this batch)
     if (s == nullptr) { rc = make_group(p, cur, ahead, n_ahead, 1, p->side, &s, true); if (rc != ZT_OK) return rc; j = 0; }
@@ -506,8 +503,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // ---- P3 (first half), on a stream of its own: the last messages of the endpoints at positions [pos_lo, pos_hi).  They
     // read the memory tables as everything enqueued on the main stream so far leaves them (the previous batch's GRU, a
     // caller's row exchange) and nothing the aggregation writes; the GRU below waits for them.
-    ZT_HIP(hipEventRecord(p->step_begin, p->main_s));
-    ZT_HIP(hipStreamWaitEvent(p->msg_s, p->step_begin, 0));
+    ZT_HIP(hipStreamWaitEvent(p->msg_s, p->entry, 0));
     // Every endpoint of the batch gets a message here and is updated by the GRU below: in this protocol (eval steps, entered
     // with no flag pending -- step_device flushes first) "flagged among the batch's endpoints after the store" IS the list of
     // winners the message kernel already makes.  So the kernel hands its list to the GRU directly (the GRU workspace's row
@@ -531,29 +527,33 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         // (the wait for the message build sits between the aggregation and the output layer -- the messages are ready long
         //  before the aggregation ends -- so that the GRU follows the output layer without a packet in between)
         msgs_waited = true;
+        // (the output layers are held back: gru_update_ex below launches them in ONE kernel with the GRU update where both take
+        //  their tiled forms -- k_out_gru --, otherwise in front of it)
+        if (!p->gru_ready) p->out_gru.src_base = 0;          // (the workspace's counters are zeroed with its first weight pack)
         rc = zt::embed_ex(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                           od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s,
-                          msgs_waited ? p->msgs_done : nullptr);
+                          msgs_waited ? p->msgs_done : nullptr, &p->out_gru);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
-        if (p->aff_on && whole) {                // compute_edge_probabilities' scorer (model/tgn_model.py:185-188) on the rows just written
-            const int par = p->score_n & 1;
-            rc = zt_affinity(out_emb_dev, B, d.D * (d.M + 1), &p->aff, p->prob + (size_t)par * 2 * d.max_B, p->aff_ws, d.max_B,
-                             p->aff_ready ? 1 : 0, p->main_s);
-            if (rc != ZT_OK) return rc;
-            ZT_HIP(hipEventRecord(p->scored[par], p->main_s));
-            p->aff_ready = true;
-            p->score_n++;
-            p->score_B = B;
-        }
     }
     // ---- P3: the GRU update over the messages built beside the aggregation; the refresh of the projected rows rides
     // inside the GRU kernel once the padded W_m is in the embed workspace ----
     if (!msgs_waited) ZT_HIP(hipStreamWaitEvent(p->main_s, p->msgs_done, 0));
     rc = zt::gru_update_ex(d.memory, d.last_update, d.messages, d.msg_ts, d.flags, d.num_nodes, d.D, msg_dim, nodes_cur, 2 * B,
-                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, true);
+                           nullptr, &d.gw, d.gru_ws, p->gru_ready ? 1 : 0, wm_p, wm_p ? d.proj_table : nullptr, p->main_s, true, true,
+                           n_rows > 0 ? &p->out_gru : nullptr);
     if (rc != ZT_OK) return rc;
     p->gru_ready = true;
+    if (n_rows > 0 && p->aff_on && whole) {      // compute_edge_probabilities' scorer (model/tgn_model.py:185-188) on the rows just written
+        const int par = p->score_n & 1;
+        rc = zt_affinity(out_emb_dev, B, d.D * (d.M + 1), &p->aff, p->prob + (size_t)par * 2 * d.max_B, p->aff_ws, d.max_B,
+                         p->aff_ready ? 1 : 0, p->main_s);
+        if (rc != ZT_OK) return rc;
+        ZT_HIP(hipEventRecord(p->scored[par], p->main_s));
+        p->aff_ready = true;
+        p->score_n++;
+        p->score_B = B;
+    }
     if (d.proj_table != nullptr && wm_p == nullptr) {
         char *gw = reinterpret_cast<char *>(d.gru_ws);
         rc = zt_project_memory(d.memory, d.num_nodes, d.D, d.F, d.T, &d.ew, 1,

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
     const double *__restrict__ ats, long long num_nodes, const int *__restrict__ q_nodes,
     const double *__restrict__ q_ts, long long nq, int width, int depth, PruneModels pm, int k,
     int *out_nodes, int *out_eidx, float *out_dt, float *out_w, long long out_stride, int *status, int cap_c, int cap_f,
-    int dbg_stop)
+    int dbg_stop, int zero_empty)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = pm.M;
@@ -221,7 +221,16 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
         nf = n_new;
         n_cand += n_new;
     }
-    if (n_cand == 0) return;                                        // :241-242, row untouched
+    if (n_cand == 0) {                                              // :241-242, row untouched
+        // (zero_empty: the caller's output arrays are not cleared beforehand -- pipeline.hip: a memset in front of every
+        //  query is a packet on the T-PPR stream, ~6 us of every C4 step -- so an empty row is written here, as zeros)
+        if (zero_empty && lane < k)
+            for (int m = 0; m < M; ++m) {
+                const long long ob = (long long)m * out_stride + qi * k;
+                out_nodes[ob + lane] = 0; out_eidx[ob + lane] = 0; out_w[ob + lane] = 0.f; out_dt[ob + lane] = 0.f;
+            }
+        return;
+    }
     if (dbg_stop == 1) { if (lane == 0) out_nodes[qi * k] = n_cand; return; }      // (diagnostic: ZT_PRUNE_STOP)
 
     // ---- merge duplicate states: dict[state] += weight in occurrence order (:222-225) ----
@@ -453,7 +462,7 @@ extern "C" int zt_csr_find_before(const zt_csr *c, int32_t v, double t, int64_t 
 // one launch for up to PR_MAX_MODELS models; out arrays are [M][nq][k]
 static int pruned_launch(const zt_csr *c, const int32_t *q_nodes_dev, const double *q_ts_dev, int64_t nq, int32_t width,
                          int32_t depth, int M, const double *alpha, const double *beta, int32_t k, int32_t *on, int32_t *oe,
-                         float *od, float *ow, int32_t *status_dev, hipStream_t s)
+                         float *od, float *ow, int32_t *status_dev, hipStream_t s, bool zero_empty = false)
 {
     long long cap = 0, lvl = 1, front = 1;
     for (int d = 0; d < depth; ++d) { front = lvl; lvl *= width; cap += lvl; if (cap > MAX_CAND) break; }
@@ -487,7 +496,7 @@ static int pruned_launch(const zt_csr *c, const int32_t *q_nodes_dev, const doub
         ZT_PROF_BEGIN(s, P_PRUNE);
         k_pruned_topk<<<grid, WAVE * PR_WAVES, lds, s>>>(c->indptr, c->nbr, c->eid, c->ts, c->N, q_nodes_dev, q_ts_dev, nq,
                                                          width, depth, pm, k, on + o, oe + o, od + o, ow + o,
-                                                         (long long)nq * k, status_dev, cap_c, cap_f, dbg_stop);
+                                                         (long long)nq * k, status_dev, cap_c, cap_f, dbg_stop, zero_empty ? 1 : 0);
         ZT_PROF_END(s, P_PRUNE);
         ZT_LAUNCH_CHECK();
         m0 += mm;
@@ -507,6 +516,21 @@ extern "C" int zt_pruned_topk(const zt_csr *c, const int32_t *q_nodes_dev, const
     if (nq == 0) return ZT_OK;
     return pruned_launch(c, q_nodes_dev, q_ts_dev, nq, width, depth, 1, &alpha, &beta, k, out_nodes_dev, out_eidx_dev,
                          out_dt_dev, out_w_dev, status_dev, (hipStream_t)stream);
+}
+
+// zt_pruned_topk_multi into output arrays that were NOT cleared: rows with an empty dictionary are written as zeros by the kernel
+int zt::pruned_topk_multi_fill(const zt_csr *c, const int32_t *q_nodes_dev, const double *q_ts_dev, int64_t nq, int32_t width,
+                               int32_t depth, int32_t n_models, const double *alpha_host, const double *beta_host, int32_t k,
+                               int32_t *out_nodes_dev, int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
+                               int32_t *status_dev, void *stream)
+{
+    if (!c || nq < 0 || width <= 0 || depth <= 0 || k <= 0 || !status_dev || n_models <= 0 || !alpha_host || !beta_host) {
+        set_error("zt_pruned_topk_multi: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (nq == 0) return ZT_OK;
+    return pruned_launch(c, q_nodes_dev, q_ts_dev, nq, width, depth, n_models, alpha_host, beta_host, k, out_nodes_dev,
+                         out_eidx_dev, out_dt_dev, out_w_dev, status_dev, (hipStream_t)stream, true);
 }
 
 extern "C" int zt_pruned_topk_multi(const zt_csr *c, const int32_t *q_nodes_dev, const double *q_ts_dev, int64_t nq,

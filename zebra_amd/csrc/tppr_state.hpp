@@ -100,6 +100,7 @@ struct zt_tppr {
         const int32_t *nodes;
         int B, n_roles, model, grid, max_chains;
         unsigned long long token;
+        unsigned bar_base;                 // k_prepass_coop: value of the set's barrier word (ctl[11], never reset) before the next launch
     } set[2];
     int next_set;
     // last launch (diagnostics)
