@@ -984,132 +984,6 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// k_embed_out2: the same three layers, organised for LATENCY (round 4).  k_embed_out's time was never its arithmetic:
-// at C2's batch (600 rows) it ran 27 us for 40 MFLOP -- a chain of dependent memory round trips per workgroup (ids ->
-// row staging through LDS in a loop the compiler cannot unroll, one round trip per iteration -> weight fragments per
-// k-chunk -> second layer -> ...) on 57 workgroups.  Here one WAVE owns (16 rows, path, one N-tile of the output):
-//   * its weight fragments -- fc2's [16 x Dp] slice, for the source path also ALL of fc1s -- are requested first,
-//     before anything is looked at, and stay in registers while the wave strides over row tiles;
-//   * the A operand comes straight from memory into the MFMA lanes (lane (row r, k-slot g) loads float4 at columns
-//     16 c + 4 g -- the k order the padded weights already have), no LDS staging; partial-sum groups (k_fc1_agg_wide)
-//     are added first to last as they arrive;
-//   * the source path's hidden layer is computed by each of the NT waves of a row tile (0.4 MFLOP, redundant on purpose:
-//     sharing it would cost a barrier and a round trip through LDS or memory) and turned from the MFMA's output layout
-//     into its input layout through 7 KB of the wave's own LDS.
-// One memory round trip for the neighbour paths, two for the source path (ids, then rows).  D % 4 == 0.
-// ---------------------------------------------------------------------------
-template <int NT, int HG>
-__global__ __launch_bounds__(64) void k_embed_out2(
-    const float *__restrict__ memory, long long num_nodes, const int *__restrict__ nodes, long long N, int D, int M,
-    const float *__restrict__ H, const float *__restrict__ S, const float *__restrict__ fc2_p,
-    const float *__restrict__ fc2_b, const float *__restrict__ fc1s_p, const float *__restrict__ fc1s_b,
-    const float *__restrict__ fc2s_p, const float *__restrict__ fc2s_b, float *__restrict__ out, int *status)
-{
-    constexpr int Dp = NT * 16, KC = NT, ldy = Dp + 4;
-    __shared__ __attribute__((aligned(16))) float Y[16 * ldy];
-    const int lane = threadIdx.x, r16 = lane & 15, g4 = lane >> 4;
-    const int path = blockIdx.y, b = blockIdx.z;
-    const int col = 16 * b + r16, OW = D * (M + 1);
-    const long long tiles = (N + 15) / 16;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    // columns this lane's float4 of chunk c covers: all four inside the row, or none (D % 4 == 0)
-    bool cin[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) cin[c] = 16 * c + 4 * g4 < D;
-
-    if (path == 0) {
-        f32x4 w1[NT][KC], w2[KC];
-#pragma unroll
-        for (int bb = 0; bb < NT; ++bb)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) w1[bb][c] = *reinterpret_cast<const f32x4 *>(fc1s_p + (size_t)(16 * bb + r16) * Dp + 16 * c + 4 * g4);
-#pragma unroll
-        for (int c = 0; c < KC; ++c) w2[c] = *reinterpret_cast<const f32x4 *>(fc2s_p + (size_t)col * Dp + 16 * c + 4 * g4);
-        float b1v[NT];
-#pragma unroll
-        for (int bb = 0; bb < NT; ++bb) b1v[bb] = 16 * bb + r16 < D ? fc1s_b[16 * bb + r16] : 0.f;
-        const float b2v = col < D ? fc2s_b[col] : 0.f;
-        long long t = blockIdx.x;
-        int nd = (t < tiles && t * 16 + r16 < N) ? nodes[t * 16 + r16] : 0;
-        for (; t < tiles; t += gridDim.x) {
-            const long long r0 = t * 16;
-            if (nd < 0 || nd >= num_nodes) { atomicExch(status, ZT_ERR_RANGE); nd = 0; }
-            const bool rin = r0 + r16 < N;
-            f32x4 a[KC];
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-                a[c] = (rin && cin[c]) ? *reinterpret_cast<const f32x4 *>(memory + (size_t)nd * D + 16 * c + 4 * g4) : zero4;
-            const long long tn = t + gridDim.x;
-            nd = (tn < tiles && tn * 16 + r16 < N) ? nodes[tn * 16 + r16] : 0;      // the next tile's ids, a tile ahead
-            f32x4 acc1[NT];
-#pragma unroll
-            for (int bb = 0; bb < NT; ++bb) acc1[bb] = zero4;
-#pragma unroll
-            for (int c = 0; c < KC; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int bb = 0; bb < NT; ++bb)
-                        acc1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], w1[bb][c][j], acc1[bb], 0, 0, 0);
-#pragma unroll
-            for (int bb = 0; bb < NT; ++bb)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = acc1[bb][j] + b1v[bb];
-                    Y[(4 * g4 + j) * ldy + 16 * bb + r16] = (16 * bb + r16 < D && v > 0.f) ? v : 0.f;
-                }
-            wave_sync();
-            f32x4 acc = zero4;
-#pragma unroll
-            for (int c = 0; c < KC; ++c) {
-                const f32x4 y = *reinterpret_cast<const f32x4 *>(Y + r16 * ldy + 16 * c + 4 * g4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(y[j], w2[c][j], acc, 0, 0, 0);
-            }
-            if (col < D) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + col] = acc[j] + b2v;
-            }
-            wave_sync();                                                   // Y is free for the next tile
-        }
-        return;
-    }
-    // ---- neighbour path: fc2 on the reduced rows of model m ----
-    const int m = path - 1;
-    f32x4 w2[KC];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) w2[c] = *reinterpret_cast<const f32x4 *>(fc2_p + (size_t)col * Dp + 16 * c + 4 * g4);
-    const float b2v = col < D ? fc2_b[col] : 0.f;
-    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const long long r0 = t * 16;
-        const bool rin = r0 + r16 < N;
-        const float *hp = H + (((size_t)m * N + (rin ? r0 + r16 : 0)) * HG) * D + 4 * g4;
-        f32x4 g[HG][KC];
-#pragma unroll
-        for (int q = 0; q < HG; ++q)
-#pragma unroll
-            for (int c = 0; c < KC; ++c) g[q][c] = (rin && cin[c]) ? *reinterpret_cast<const f32x4 *>(hp + (size_t)q * D + 16 * c) : zero4;
-        float sv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sv[j] = r0 + 4 * g4 + j < N ? S[(size_t)m * N + r0 + 4 * g4 + j] : 0.f;
-        f32x4 acc = zero4;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            f32x4 a = g[0][c];
-#pragma unroll
-            for (int q = 1; q < HG; ++q) a += g[q][c];                     // a query row's groups, first to last
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w2[c][j], acc, 0, 0, 0);
-        }
-        if (col < D) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (r0 + 4 * g4 + j < N) out[(size_t)(r0 + 4 * g4 + j) * OW + (size_t)D * (m + 1) + col] = acc[j] + b2v * sv[j];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // k_embed_out3 (round 5): the same three layers, PERSISTENT, for batches beyond k_embed_out2's reach.  k_embed_out's time
@@ -1639,17 +1513,25 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     //  stream's kernels: C4 (3 000 rows, no CU masks, k_pruned_topk running beside) 36 us against the tiled kernel's 20; C5
     //  (12 288 rows, the main stream's CUs to itself) 29 against 38.  So: from 8 192 rows on.
     const bool use3 = can3 && !use2 && (oc == ZT_OUT_PERSIST || (oc == 0 && N >= 8192));
-    const bool held_back = defer != nullptr && !use2 && !use3;          // (launched by the caller, beside the GRU update)
+    const bool held_back = defer != nullptr && !use3;                    // (launched by the caller, beside the GRU update)
     if (!held_back) ZT_PROF_BEGIN(s, P_EMBED_OUT);
     if (use2) {
         // one wave per (16 rows, path, N-tile), striding over the row tiles with its weights in registers
         const long long tiles = (N + 15) / 16;
-        const dim3 grid((unsigned)(tiles < 256 ? tiles : 256), (unsigned)(M + 1), (unsigned)(p.Dp / 16));
-#define ZT_EO2(NTV, HGV) k_embed_out2<NTV, HGV><<<grid, 64, 0, s>>>(memory_dev, num_nodes, nodes_dev, N, D, M, H, S, fc2t, wt->fc2_b, \
-            fc1st, wt->fc1s_b, fc2st, wt->fc2s_b, out_dev, status_dev)
-        if (p.Dp == 112) { if (hg == 1) ZT_EO2(7, 1); else if (hg == 5) ZT_EO2(7, 5); else ZT_EO2(7, 10); }
-        else             { if (hg == 1) ZT_EO2(8, 1); else if (hg == 5) ZT_EO2(8, 5); else ZT_EO2(8, 10); }
-#undef ZT_EO2
+        zt::embed_out_deferred od;
+        od.valid = true; od.form = 2; od.gx = (int)(tiles < 256 ? tiles : 256);
+        od.memory = memory_dev; od.num_nodes = num_nodes; od.nodes = nodes_dev; od.N = N; od.D = D; od.M = M; od.hg = hg;
+        od.H = H; od.S = S; od.fc2_p = fc2t; od.fc2_b = wt->fc2_b; od.fc1s_p = fc1st; od.fc1s_b = wt->fc1s_b; od.fc2s_p = fc2st;
+        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.src_base = 0;
+        if (defer != nullptr) {
+            const unsigned keep = defer->src_base;
+            *defer = od;
+            defer->src_base = keep;
+            ZT_LAUNCH_CHECK();
+            return ZT_OK;
+        }
+        const int rc = zt::embed_out_launch(od, s);
+        if (rc != ZT_OK) return rc;
     } else if (use3) {
         // one workgroup per CU of the stream; the source path's two layers are as many MFMAs per row as M models' fc2
         const long long tiles = (N + 15) / 16;
@@ -1676,7 +1558,7 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     } else {
         if (hg != 1 && hg != 5 && hg != 10) { set_error("zt_embed: %d partial-sum groups per row", hg); return ZT_ERR_UNSUPPORTED; }
         zt::embed_out_deferred od;
-        od.valid = true;
+        od.valid = true; od.form = 1; od.gx = 0;
         od.memory = memory_dev; od.num_nodes = num_nodes; od.nodes = nodes_dev; od.N = N; od.D = D; od.M = M; od.hg = hg;
         od.H = H; od.S = S; od.fc2_p = fc2t; od.fc2_b = wt->fc2_b; od.fc1s_p = fc1st; od.fc1s_b = wt->fc1s_b; od.fc2s_p = fc2st;
         od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.src_base = 0;
@@ -1715,6 +1597,15 @@ int zt::embed_out_launch(const zt::embed_out_deferred &d, void *stream)
     E.memory = d.memory; E.num_nodes = d.num_nodes; E.nodes = d.nodes; E.N = d.N; E.D = d.D; E.M = d.M; E.H = d.H; E.S = d.S;
     E.fc2_p = d.fc2_p; E.fc2_b = d.fc2_b; E.fc1s_p = d.fc1s_p; E.fc1s_b = d.fc1s_b; E.fc2s_p = d.fc2s_p; E.fc2s_b = d.fc2s_b;
     E.out = d.out; E.status = d.status;
+    if (d.form == 2) {
+        const dim3 grid2((unsigned)d.gx, (unsigned)(d.M + 1), (unsigned)(Dp / 16));
+#define ZT_EO2(NTV, HGV) k_embed_out2<NTV, HGV><<<grid2, 64, 0, s>>>(E)
+        if (Dp == 112) { if (d.hg == 1) ZT_EO2(7, 1); else if (d.hg == 5) ZT_EO2(7, 5); else ZT_EO2(7, 10); }
+        else           { if (d.hg == 1) ZT_EO2(8, 1); else if (d.hg == 5) ZT_EO2(8, 5); else ZT_EO2(8, 10); }
+#undef ZT_EO2
+        ZT_LAUNCH_CHECK();
+        return ZT_OK;
+    }
     const dim3 grid((unsigned)((d.N + OUT_ROWS - 1) / OUT_ROWS), (unsigned)(d.M + 1));
     if (d.hg == 1) k_embed_out<1><<<grid, AGG_THREADS, lds2, s>>>(E);
     else if (d.hg == 5) k_embed_out<5><<<grid, AGG_THREADS, lds2, s>>>(E);

@@ -40,6 +40,7 @@ struct embed_out_deferred {
     const int *nodes;
     long long N;
     int D, M, hg;
+    int form, gx;          // 1: the tiled kernel (k_embed_out); 2: the latency-organised one (k_embed_out2), gx tiles' worth of waves per path and N-tile
     const float *H, *S, *fc2_p, *fc2_b, *fc1s_p, *fc1s_b, *fc2s_p, *fc2s_b;
     float *out;
     int *status;

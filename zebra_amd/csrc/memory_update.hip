@@ -462,21 +462,32 @@ constexpr int GS_STAGE = 37;         // staged elements per thread: 16 (msg + D)
 constexpr int GS_TILE_COUNTERS = 512;
 constexpr int GS_MAX_ROWS = GS_TILE_COUNTERS * 16;
 
-__global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, float *last_update, const float *__restrict__ messages,
-                                                             const float *__restrict__ msg_ts, const int *__restrict__ rows,
-                                                             const int *__restrict__ n_rows, int D, int msg_dim, int Xp, int Hp, int lda,
-                                                             const float *__restrict__ Wih_p, const float *__restrict__ Whh_p,
-                                                             const float *__restrict__ b_ih, const float *__restrict__ b_hh,
-                                                             const float *__restrict__ Wm_p, float *__restrict__ P, int *tile_cnt,
-                                                             float *hnew, int cap)
+struct GruSplitArgs {
+    GruArgs g;
+    int *tile_cnt;
+    float *hnew;
+};
+
+// (bx, by) = (16-row tile, N-tile).  src_read != nullptr (k_out_gru2): the tile's last workgroup waits for the counter there
+// to reach src_target before it commits the rows to the memory table.
+__device__ __forceinline__ void gru_split_body(const GruSplitArgs &GS, char *smem, int bx, int by, const int *src_read, unsigned src_target)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GruArgs &G = GS.g;
+    float *memory = G.memory, *last_update = G.last_update;
+    const float *__restrict__ messages = G.messages, *__restrict__ msg_ts = G.msg_ts;
+    const int *__restrict__ rows = G.rows, *__restrict__ n_rows = G.n_rows;
+    const int D = G.D, msg_dim = G.msg_dim, Xp = G.Xp, Hp = G.Hp, lda = G.lda, cap = G.cap;
+    const float *__restrict__ Wih_p = G.Wih_p, *__restrict__ Whh_p = G.Whh_p, *__restrict__ b_ih = G.b_ih, *__restrict__ b_hh = G.b_hh;
+    const float *__restrict__ Wm_p = G.Wm_p;
+    float *__restrict__ P = G.P;
+    int *tile_cnt = GS.tile_cnt;
+    float *hnew = GS.hnew;
     float *A = reinterpret_cast<float *>(smem);                          // [16][lda]: [message (Xp) | memory (Hp)], zero padded
     float *red = A + 16 * lda;                                           // [4 waves][4 sums][64 lanes][4]
     int *rid = reinterpret_cast<int *>(red + GS_WAVES * 4 * 64 * 4);     // [16] node ids; [16] = "this workgroup is the tile's last"
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g4 = lane >> 4;
     GSTAMP(0);
-    const int r0 = blockIdx.x * 16, nt = blockIdx.y, NT = Hp / 16;
+    const int r0 = bx * 16, nt = by, NT = Hp / 16;
     // (ids requested together with the row count: see k_gru)
     const int id_spec = tid < 16 ? __builtin_nontemporal_load(rows + (r0 + tid < cap ? r0 + tid : cap - 1)) : 0;
     const int total = *n_rows;
@@ -570,13 +581,17 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
         // ---- arrive: the tile's last workgroup commits (sc1 stores drained, no fence: see k_gru_persist) ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int done = 0;
-        if (lane == 0) done = atomicAdd(&tile_cnt[blockIdx.x], 1);
+        if (lane == 0) done = atomicAdd(&tile_cnt[bx], 1);
         done = __builtin_amdgcn_readfirstlane(done);
-        if (lane == 0) { rid[16] = done == NT - 1 ? 1 : 0; if (done == NT - 1) atomicExch(&tile_cnt[blockIdx.x], 0); }
+        if (lane == 0) { rid[16] = done == NT - 1 ? 1 : 0; if (done == NT - 1) atomicExch(&tile_cnt[bx], 0); }
     }
     __syncthreads();
     GSTAMP(6);
     if (rid[16] == 0) return;
+    if (src_read != nullptr) {                                           // (k_out_gru2: the output layers' source path has read its rows)
+        if (tid == 0) while ((int)((unsigned)ld_agent(src_read) - src_target) < 0) __builtin_amdgcn_s_sleep(2);
+        __syncthreads();
+    }
     // ---- every N-tile of these 16 rows has been computed from the OLD rows: new rows -> memory table, -> projected table
     // (read with sc1 loads: served by L2, where the other workgroups' drained sc1 stores are) ----
     {
@@ -616,6 +631,38 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(float *memory, floa
             const int g = 4 * g4 + j;
             if (g < nr) P[(size_t)rid[g] * Hp + 16 * b + r16] = acc[j];
         }
+    }
+}
+
+__global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(GruSplitArgs GS)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gru_split_body(GS, smem, blockIdx.x, blockIdx.y, nullptr, 0u);
+}
+
+// k_out_gru for SMALL batches: the latency-organised output layers (k_embed_out2: one wave per (tiles, path, N-tile), four of
+// them to a workgroup here) beside k_gru_split.  Workgroup order as in k_out_gru: the source-path waves first (n_src_wgs
+// workgroups), the GRU's (tile, N-tile) workgroups, the neighbour paths.
+template <int NT, int HG>
+__global__ __launch_bounds__(64 * GS_WAVES) void k_out_gru2(EmbedOutArgs E, int gx, int n_src_wgs, int gru_tiles, GruSplitArgs GS, int *src_read,
+                                                            unsigned src_target)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gru_wgs = gru_tiles * NT;
+    if (bid >= n_src_wgs && bid < n_src_wgs + gru_wgs) {
+        const int g = bid - n_src_wgs;
+        gru_split_body(GS, smem, g % gru_tiles, g / gru_tiles, src_read, src_target);
+        return;
+    }
+    float *Y = reinterpret_cast<float *>(smem) + wave * (16 * (NT * 16 + 4));
+    const int per_path = gx * NT;                          // waves per path: (tile stride gx) x (N-tile)
+    if (bid < n_src_wgs) {
+        const int v = 4 * bid + wave;
+        if (v < per_path) embed_out2_body<NT, HG>(E, Y, lane, v % gx, gx, 0, v / gx, src_read);
+    } else {
+        const int v = 4 * (bid - n_src_wgs - gru_wgs) + wave;
+        if (v < per_path * E.M) { const int r = v % per_path; embed_out2_body<NT, HG>(E, Y, lane, r % gx, gx, 1 + v / per_path, r / gx, nullptr); }
     }
 }
 
@@ -855,18 +902,51 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                       16 * p.Hp <= 7 * 256;
     const bool split = fits && (choice == ZT_GRU_SPLIT || (choice == 0 && max_rows <= 512));
     if (split) {
-        // (held-back output layers first: their source path reads the rows this kernel rewrites)
-        if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }
         const size_t lds2 = ((size_t)16 * p.lda + (size_t)GS_WAVES * 4 * 64 * 4) * 4 + 32 * 4;
         static size_t attr2 = 0;
         if (lds2 > 48 * 1024 && lds2 > attr2) {
             ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             attr2 = lds2;
         }
-        k_gru_split<<<dim3((unsigned)((max_rows + 15) / 16), (unsigned)(p.Hp / 16)), 64 * GS_WAVES, lds2, s>>>(
-            memory_dev, last_update_dev, messages_dev, msg_ts_dev, rows, cnt, D, msg_dim, p.Xp, p.Hp, p.lda, wih, whh, wt->b_ih,
-            wt->b_hh, wm_p, proj_table, reinterpret_cast<int *>(ws + p.off_tiles), reinterpret_cast<float *>(ws + p.off_hnew),
-            (int)max_rows);
+        GruSplitArgs GS;
+        GS.g.memory = memory_dev; GS.g.last_update = last_update_dev; GS.g.messages = messages_dev; GS.g.msg_ts = msg_ts_dev; GS.g.rows = rows;
+        GS.g.n_rows = cnt; GS.g.D = D; GS.g.msg_dim = msg_dim; GS.g.Xp = p.Xp; GS.g.Hp = p.Hp; GS.g.lda = p.lda; GS.g.Wih_p = wih; GS.g.Whh_p = whh;
+        GS.g.b_ih = wt->b_ih; GS.g.b_hh = wt->b_hh; GS.g.Wm_p = wm_p; GS.g.P = proj_table; GS.g.cap = (int)max_rows;
+        GS.tile_cnt = reinterpret_cast<int *>(ws + p.off_tiles); GS.hnew = reinterpret_cast<float *>(ws + p.off_hnew);
+        const int gru_tiles = (int)((max_rows + 15) / 16), NTg = p.Hp / 16;
+        const bool can_fuse2 = fuse != nullptr && fuse->valid && fuse->form == 2 && fuse->memory == memory_dev &&
+                               (fuse->D + 15) / 16 == NTg && (NTg == 7 || NTg == 8) && (fuse->hg == 1 || fuse->hg == 5 || fuse->hg == 10);
+        if (can_fuse2) {
+            const zt::embed_out_deferred &d = *fuse;
+            EmbedOutArgs E;
+            E.memory = d.memory; E.num_nodes = d.num_nodes; E.nodes = d.nodes; E.N = d.N; E.D = d.D; E.M = d.M; E.H = d.H; E.S = d.S;
+            E.fc2_p = d.fc2_p; E.fc2_b = d.fc2_b; E.fc1s_p = d.fc1s_p; E.fc1s_b = d.fc1s_b; E.fc2s_p = d.fc2s_p; E.fc2s_b = d.fc2s_b;
+            E.out = d.out; E.status = d.status;
+            const int per_path = d.gx * NTg, n_src_wgs = (per_path + 3) / 4, n_nb_wgs = (per_path * d.M + 3) / 4;
+            size_t lds_f = (size_t)4 * 16 * (NTg * 16 + 4) * 4;
+            if (lds_f < lds2) lds_f = lds2;
+            int *src_read = cnt + GRU_SRC_WORD;
+            const unsigned target = d.src_base + (unsigned)per_path;
+            const unsigned grid = (unsigned)(n_src_wgs + gru_tiles * NTg + n_nb_wgs);
+#define ZT_OG2(NTV, HGV) do {                                                                                                   \
+                static size_t attr_og2 = 0;                                                                                     \
+                if (lds_f > 48 * 1024 && lds_f > attr_og2) {                                                                    \
+                    ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_out_gru2<NTV, HGV>),                            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                       \
+                    attr_og2 = lds_f;                                                                                           \
+                }                                                                                                               \
+                k_out_gru2<NTV, HGV><<<grid, 64 * GS_WAVES, lds_f, s>>>(E, d.gx, n_src_wgs, gru_tiles, GS, src_read, target);    \
+            } while (0)
+            if (NTg == 7) { if (d.hg == 1) ZT_OG2(7, 1); else if (d.hg == 5) ZT_OG2(7, 5); else ZT_OG2(7, 10); }
+            else          { if (d.hg == 1) ZT_OG2(8, 1); else if (d.hg == 5) ZT_OG2(8, 5); else ZT_OG2(8, 10); }
+#undef ZT_OG2
+            fuse->src_base = target;
+            fuse->valid = false;
+        } else {
+            // (held-back output layers first: their source path reads the rows this kernel rewrites)
+            if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }
+            k_gru_split<<<dim3((unsigned)gru_tiles, (unsigned)NTg), 64 * GS_WAVES, lds2, s>>>(GS);
+        }
     } else {
         const size_t lds = (size_t)16 * p.lda * 4 + 16 * 4;
         static size_t attr_lds = 0;
@@ -879,7 +959,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         G.D = D; G.msg_dim = msg_dim; G.Xp = p.Xp; G.Hp = p.Hp; G.lda = p.lda; G.Wih_p = wih; G.Whh_p = whh; G.b_ih = wt->b_ih; G.b_hh = wt->b_hh;
         G.Wm_p = wm_p; G.P = proj_table; G.cap = (int)max_rows;
         const unsigned gru_wgs = (unsigned)((max_rows + 15) / 16);
-        if (fuse != nullptr && fuse->valid && fuse->memory == memory_dev && (fuse->hg == 1 || fuse->hg == 5 || fuse->hg == 10)) {
+        if (fuse != nullptr && fuse->valid && fuse->form == 1 && fuse->memory == memory_dev && (fuse->hg == 1 || fuse->hg == 5 || fuse->hg == 10)) {
             const zt::embed_out_deferred &d = *fuse;
             EmbedOutArgs E;
             E.memory = d.memory; E.num_nodes = d.num_nodes; E.nodes = d.nodes; E.N = d.N; E.D = d.D; E.M = d.M; E.H = d.H; E.S = d.S;
