@@ -43,7 +43,7 @@ def main():
     # kernel-name prefix -> bench.py's name (template arguments vary with the workload)
     prefixes = [("k_stream", "tppr_stream"), ("k_fc1_agg_reg", "fc1_agg"), ("k_fc1_agg_wide", "fc1_agg"), ("k_fc1_agg_d100", "fc1_agg"),
                 ("k_fc1_agg<true>", "fc1_agg_generic"), ("k_fc1_agg<false>", "fc1_agg_full"), ("k_embed_out", "embed_out"),
-                ("k_gru_split", "gru_update"), ("k_gru", "gru_update"), ("k_build_messages", "store_messages"), ("k_pruned_topk", "pruned_topk"),
+                ("k_out_gru", "gru_update"), ("k_gru_split", "gru_update"), ("k_gru", "gru_update"), ("k_build_messages", "store_messages"), ("k_pruned_topk", "pruned_topk"),
                 ("k_deps", "tppr_prepass"), ("k_prepass_fused", "tppr_prepass"), ("k_project_rows", "project_rows"),
                 ("k_affinity", "score")]
     for pre, n in prefixes:                        # (the first prefix in the list that names a kernel of this run wins its slot)

@@ -20,7 +20,7 @@ def main():
     out = {"workload": workload, "launches_averaged": last, "kernels": {}}
     # every kernel of the timed step that the pass instrumented, matched by PREFIX (template arguments and kernel
     # generations change from round to round: a whitelist of exact names silently dropped the round-4 kernels)
-    prefixes = ("k_stream", "k_fc1_agg", "k_embed_out", "k_gru", "k_build_messages", "k_last_pos", "k_pruned_topk",
+    prefixes = ("k_stream", "k_fc1_agg", "k_embed_out", "k_out_gru", "k_gru", "k_build_messages", "k_last_pos", "k_pruned_topk",
                 "k_project_rows", "k_affinity", "k_deps", "k_own", "k_reserve", "k_hot_select", "k_plan", "k_prepass")
     for k in sorted(agg):
         if not k.startswith(prefixes):
