@@ -117,12 +117,13 @@ def _run(oracle, name, first_batch, fill, nb, steps_for_group, group=-1, tppr_cu
 def test_wikipedia_configs_vs_oracle(oracle, name, steps):
     """C1 (one T-PPR model, alpha 0.1 / beta 0.9: train.py:57) and C2 (two models) at Wikipedia's shape: 9 228 node
     ids, bipartite 8 227 + 1 000, F = 172, bs = 200, k = 20; bench.py's prefill (10 % of the stream = 78 batches), then
-    32 checked batches; launch groups as the 200-step bench run (4) and as the driver's 20-step run (2) choose them."""
+    32 checked batches; launch groups as the 200-step bench run (8 batches per launch) and as the driver's 20-step run (2)
+    choose them."""
     from zebra_amd import synth
     wl = synth.WORKLOADS[name]
     fill = (wl["n_edges"] // 10) // wl["bs"]
     worst, cus, grp = _run(oracle, name, 0, fill, 32, steps)
-    assert cus == 64 and grp == (4 if steps >= 40 else 2)
+    assert cus == 64 and grp == (8 if steps >= 80 else 2)
 
 
 @pytest.mark.parametrize("steps", [200, 20])
@@ -134,7 +135,7 @@ def test_reddit_config_vs_oracle(oracle, steps):
     wl = synth.WORKLOADS["c3"]
     fill = (wl["n_edges"] // 10) // wl["bs"]
     worst, cus, grp = _run(oracle, "c3", 0, fill, 30, steps)
-    assert cus == 64 and grp == (4 if steps >= 40 else 2)
+    assert cus == 64 and grp == (8 if steps >= 80 else 2)
 
 
 def test_superuser_config_vs_oracle(oracle):

@@ -25,7 +25,10 @@
 
 using namespace zt;
 
-constexpr int MAX_GROUP = 4;
+#ifndef ZT_MAX_GROUP
+#define ZT_MAX_GROUP 8
+#endif
+constexpr int MAX_GROUP = ZT_MAX_GROUP;
 
 struct zt_pipeline {
     zt_pipeline_desc d;
