@@ -174,6 +174,40 @@ def test_pipelined_step_matches_sequential(tppr_cus, strategy):
             assert np.array_equal(outs["seq"][2][kk], outs[mode][2][kk])
 
 
+@pytest.mark.parametrize("F,bs", [(1, 400), (172, 400), (1, 150)])
+def test_fused_output_and_gru_launch_matches_separate_kernels(F, bs):
+    """k_out_gru / k_out_gru2 (the output layers beside the GRU update in ONE launch, csrc/memory_update.hip): a pipelined
+    step against the sequential path -- which launches k_embed_out / k_embed_out2 and k_gru / k_gru_split one after the
+    other -- bit for bit: embeddings of every batch, the memory table, last_update.  bs = 400: 1 200 rows, the tiled output
+    kernel + k_gru<1> (partial-sum groups with F = 172: k_out_gru<5>); bs = 150: 450 rows, the latency-organised forms."""
+    N, D, T, k, al, be, seed = 3000, 100, 100, 20, [0.1, 0.1], [0.5, 0.95], 91
+    nbt = 5
+    E = nbt * bs
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    outs = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode == "pipe":
+            tgn.enable_pipeline(tppr_cus=0, max_batch=bs)
+        embs = []
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            for b in range(nbt):
+                cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
+                nxt = tuple(x[(b + 1) * bs:(b + 2) * bs] for x in t) if (mode == "pipe" and b + 1 < nbt) else None
+                embs.append(tgn.step_device(*cur, prefetch=nxt).clone())
+        torch.cuda.synchronize()
+        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(), tgn.memory.last_update.cpu().numpy())
+        tgn.enable_pipeline(False)
+    for q in range(3):
+        assert np.array_equal(outs["seq"][q], outs["pipe"][q])
+    assert np.abs(outs["seq"][0]).max() > 0
+
+
 @pytest.mark.parametrize("group,look,ragged", [(2, 5, False), (3, 8, True), (4, 11, False), (2, 2, False), (3, 1, True)])
 def test_grouped_tppr_launches_match_sequential(group, look, ragged):
     """zt_pipeline_set_group: the streaming T-PPR update of `group` consecutive batches as ONE launch (edges in
