@@ -75,6 +75,7 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHAIN_SINGLE 1
 #define ZT_CHAIN_PAIRED 2
 #define ZT_CHAIN_SPINE 3   /* one wave per chain runs every critical section with the hub's row in registers (csrc/tppr_chain.hpp) */
+#define ZT_CHAIN_DUO 4     /* spine mode with the weights' recurrence (network + lane shift) on a wave of its own, ahead of the spine */
 #define ZT_PREPASS_LAUNCHES 1
 #define ZT_PREPASS_COOP 2
 #define ZT_MSG_ONE 1

@@ -66,6 +66,18 @@ def test_streaming_golden_paired_hops(zt, name):
 
 
 @pytest.mark.parametrize("name", list(I.STREAM_CASES))
+def test_streaming_golden_duo(zt, name):
+    """... and in duo mode (ZT_CHAIN_DUO: the weights' recurrence on a wave of its own, running ahead of the spine on the
+    assumption that every test of the lean section passes; the spine voids its records whenever one does not)."""
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
+    try:
+        test_streaming_golden(zt, name)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
+
+
+@pytest.mark.parametrize("name", list(I.STREAM_CASES))
 def test_streaming_golden_spine(zt, name):
     """The same goldens with hub chains in spine mode (csrc/tppr_chain.hpp: one wave per chain runs every critical section
     with the hub's row in registers, the others prepare and finish; ZT_CHAIN_SPINE): bit for bit the reference's."""

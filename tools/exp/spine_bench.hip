@@ -1,5 +1,5 @@
 // The spine's loop (chain_spine, zebra_amd/csrc/tppr_chain.hpp) ALONE: one workgroup, wave 0 = the spine, wave 1 = a
-// feeder that plays all seven helpers (posts a prepared side per position ahead of the spine, frees ring slots, runs the
+// feeder (wave 2) that plays all the helpers (posts a prepared side per position ahead of the spine, frees ring slots, runs the
 // hops the spine leaves to "the helper" by publishing a fresh row), waves 2..7 idle or -- noise = 1 -- busy with LDS and
 // vector work.  Prints core clocks per hop: what the spine's instruction stream costs with nothing in its way.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -o tools/out/spine_bench tools/exp/spine_bench.hip && tools/out/spine_bench [hops] [noise]
@@ -18,18 +18,27 @@ __global__ __launch_bounds__(512) void k_bench(zt_tppr h, int len, long long *ou
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < MAIL_R) { mail.slot[threadIdx.x].seq_set = 0; mail.slot[threadIdx.x].seq_ord = 0; mail.slot[threadIdx.x].seq_free = 0; }
     if (threadIdx.x < PREP_R) { mail.prep[threadIdx.x].seq = 0; mail.prep[threadIdx.x].res = 0; }
-    if (threadIdx.x == 0) { mail.head = 0; done = 0; }
+    if (threadIdx.x == 0) { mail.head = 0; done = 0; mail.a_gen = 0; mail.a_restart = 0; }
+    if (threadIdx.x < PREP_R) mail.prep[threadIdx.x].a_seq = 0;
     for (int q = threadIdx.x; q < WAVES_PER_WG * HTAB; q += blockDim.x) lds[q / HTAB].htab[q % HTAB] = -1;
     __syncthreads();
     const int k = h.k;
     const double beta = h.beta[0];
     if (wave == 0) {
         const long long t0 = (long long)__builtin_readcyclecounter();
-        chain_spine(h, lds, lane, &mail, len);
+#ifdef SB_DUO
+        chain_spine<true>(h, lds, lane, &mail, len);
+#else
+        chain_spine<false>(h, lds, lane, &mail, len);
+#endif
         const long long t1 = (long long)__builtin_readcyclecounter();
         if (lane == 0) { out[0] = t1 - t0; __hip_atomic_store(&done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#ifdef SB_DUO
     } else if (wave == 1) {
-        WaveLds &L = lds[1];
+        chain_weights(h, lds, lane, &mail, len);
+#endif
+    } else if (wave == 2) {
+        WaveLds &L = lds[2];
         const int nb = k + 1;
         const double inf = __longlong_as_double(0x7ff0000000000000ll);
         // the partner's side, the same at every position: nb candidates with weights 0.011 .. descending in sorted lanes
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(512) void k_bench(zt_tppr h, int len, long long *ou
                     __hip_atomic_store(&P->res, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     P->norm = pn_post; P->scale_s1 = 0.93; P->norm_next = nn; P->tnow = 100.0 + posted;      // (no division: the feeder must be faster than the spine)
                     P->nkey = 0x100000000ull * (900000 + posted) + 3;
-                    P->meta = posted == 0 ? 0u : ((unsigned)nb | ((unsigned)k << 8) | (1u << 16) | (1u << 20) | (1u << 24));
+                    P->meta = posted == 0 ? 0u : ((unsigned)nb | ((unsigned)k << 8) | (1u << 16) | (2u << 20) | (1u << 24));
                     asm volatile("" ::: "memory");
                     __hip_atomic_store(&P->seq, posted + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(512) void k_bench(zt_tppr h, int len, long long *ou
             ++seen;
         }
         if (lane == 0) out[1] = left;
-    } else if (noise) {
+    } else if (noise && wave >= 3) {
         WaveLds &L = lds[wave];
         double acc = lane;
         while (__hip_atomic_load(&done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {

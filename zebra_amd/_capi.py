@@ -35,7 +35,7 @@ SYMBOLS = [
 # zt_set_kernel_choice selectors / values (include/zebra_amd.h)
 CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES, CHOICE_TPPR_CHAIN, CHOICE_TPPR_PREPASS = 0, 1, 2, 3, 4, 5
 PREPASS_LAUNCHES, PREPASS_COOP = 1, 2
-CHAIN_SINGLE, CHAIN_PAIRED, CHAIN_SPINE = 1, 2, 3
+CHAIN_SINGLE, CHAIN_PAIRED, CHAIN_SPINE, CHAIN_DUO = 1, 2, 3, 4
 AGG_GENERIC = 1
 OUT_TILED, OUT_LATENCY, OUT_PERSIST = 1, 2, 3
 GRU_TILE, GRU_SPLIT = 1, 2

@@ -150,8 +150,10 @@ __device__ __forceinline__ void sp_lanes_load(const WaveLds &Lw, int idx, SpSide
 // fetched while this one's network runs (header) and right behind it (per-lane part); (d) the loop is unrolled by two so
 // that "this side" and "the next" need no moves.  A hop that fails a test has clobbered the weights: the spine picks the row
 // up from the mailbox after the helper's hop anyway.
+template <bool DUO>
 __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr &h, WaveLds *lds, int lane, Mail *mail, int len)
 {
+    int duo_gen = 0;                                                            // (DUO) generation of the weights wave's records that are valid
     const int k = h.k;
     const unsigned kmask = (1u << k) - 1u;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -222,6 +224,25 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
             }
             // is a key of the hub's row in the partner's row?  Read now, looked at after the network
             const int cand = (table && in1) ? Lw.htab[(int)((((unsigned)ckey * ma) ^ ((unsigned)(ckey >> 32) * mb)) >> 22)] : -1;
+            int sp;
+            u64 S;
+            if (DUO) {
+                // the weights wave (chain_weights) has run the network on the row's weights: sorted positions + run starts from
+                // its record -- valid iff it carries this generation (nothing since its last pick-up of the row was left to a helper).
+                // (A position that has failed a test already is not waited for: the weights wave may never produce it.)
+                sp = 0; S = 1ull;
+                if (!fail) {
+                    const int want = (duo_gen << 12) | (t + 1);
+                    unsigned spins = 0;
+                    while (lds_load_seq(&P->a_seq) != want) {
+                        if ((++spins & 8191u) == 0 && launch_failed(status)) return false;
+                    }
+                    asm volatile("" ::: "memory");
+                    sp = Lw.sort.r[lane];
+                    const u64 sv = P->S;
+                    S = ((u64)(unsigned)ZT_U((unsigned)(sv >> 32)) << 32) | (unsigned)ZT_U((unsigned)sv);
+                }
+            } else {
             merge_stage<32>(sw, sid);
             merge_stage<16>(sw, sid);
             merge_stage<8>(sw, sid);
@@ -236,11 +257,12 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
                 const unsigned wh = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(swb >> 32));
                 hw = __longlong_as_double((long long)(((u64)wh << 32) | wl));
             }
-            const int sp = push_i32(lane, sid);                  // sorted position to the candidate's lane
+            sp = push_i32(lane, sid);                            // sorted position to the candidate's lane
             const long long swb = __double_as_longlong(sw);
             const int llo = __builtin_amdgcn_mov_dpp((int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, true);   // wave_shr:1
             const int lhi = __builtin_amdgcn_mov_dpp((int)(swb >> 32), 0x138, 0xf, 0xf, true);
-            const u64 S = __ballot(__longlong_as_double(((long long)lhi << 32) | (unsigned)llo) != sw) | 1ull;     // run starts
+            S = __ballot(__longlong_as_double(((long long)lhi << 32) | (unsigned)llo) != sw) | 1ull;     // run starts
+            }
             // ---- the next position's per-lane part (its header has arrived behind the network) ----
             if (ZT_U(Hn.seq) == t + 2) {
                 const unsigned mn = (unsigned)ZT_U(Hn.meta);
@@ -284,6 +306,7 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
             if (__builtin_expect(go, 1)) {
                 // ---- keys and time stamps of the new row: the candidate kept at provisional slot ps moves to lane ps ----
                 const int dest = kept ? ps : 63;
+                if (DUO) hw = __longlong_as_double((long long)push_u64((u64)__double_as_longlong(cw), dest));   // (no network here: the weights move like the keys)
                 hkey = push_u64(ckey, dest);
                 hts = __longlong_as_double((long long)push_u64((u64)__double_as_longlong(cts), dest));
                 // ---- the mailbox slot, as a lean hop writes it: the helpers' off-chain halves and the fallback read it ----
@@ -291,14 +314,14 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
                 if (!full && sp >= rsG && sp < drop) out_slot->alt_key[sp - rsG] = ckey;
                 if (fin && kept) out_slot->pos[ps] = ps;
                 // ---- ... and what this position's helper needs for the rest of the hop ----
-                Lw.sort.r[lane] = sp;
+                if (!DUO) Lw.sort.r[lane] = sp;
                 if (lane == 0) {
                     mail_v4u v;
                     v.x = Hc.b.x; v.y = Hc.b.y;
                     v.z = (unsigned)k | ((unsigned)mo_ << 8) | ((unsigned)na_ << 16) | (1u << 24);
                     v.w = uo;
                     *reinterpret_cast<mail_v4u *>(&out_slot->norm) = v;
-                    P->S = S;
+                    if (!DUO) P->S = S;
                     asm volatile("" ::: "memory");
                     __hip_atomic_store(&out_slot->seq_set, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (fin) __hip_atomic_store(&out_slot->seq_ord, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -312,6 +335,15 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
         if (__builtin_expect(!go, 0)) {
             if (lane == 0) __hip_atomic_store(&P->res, -(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             have = false;
+            if (DUO) {
+                // the weights wave's records from here on are void: it picks the row up where this wave will
+                ++duo_gen;
+                if (lane == 0) {
+                    __hip_atomic_store(&mail->a_restart, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_store(&mail->a_gen, duo_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
         return true;
     };
@@ -320,8 +352,125 @@ __device__ __attribute__((always_inline)) inline void chain_spine(const zt_tppr 
         if (!hop(t, HA, HB)) break;
         if (t + 1 < len && !hop(t + 1, HB, HA)) break;
     }
+    if (DUO && lane == 0) __hip_atomic_store(&mail->a_restart, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // the weights wave may go
     chain_stat(h.ctl, lane, ST_PAIR_DONE, n_ran);
     chain_stat(h.ctl, lane, ST_PAIR_BAIL_CRIT, len - n_ran);
+#undef ZT_U
+}
+
+// Duo mode: the WEIGHTS wave.  What makes hop t + 1 wait for hop t is the hub row's weights alone -- scaled, merged with the
+// partner's sorted side by the network, the kept ones shifted down -- ~175 of the hop's ~440 instructions; keys, time stamps, the
+// tests and the publication can trail.  This wave runs that recurrence and nothing else, AHEAD of the spine: it assumes every
+// test of the lean section will pass, leaves the sorted positions (in the helper's WaveLds) and the mask of run starts (in the
+// position's prep record) under its generation number, and moves on.  The spine (chain_spine<true>) takes them instead of
+// running the network itself; whenever it leaves a position to its helper it bumps the generation and names the position to
+// restart from -- this wave drops what it has, waits for that position's slot like the spine does, and picks the weights up
+// there.  A position whose side is not prepared, or whose shape the recurrence does not cover, makes it wait for exactly that.
+__device__ __attribute__((always_inline)) inline void chain_weights(const zt_tppr &h, WaveLds *lds, int lane, Mail *mail, int len)
+{
+    const int k = h.k;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const bool low = __builtin_amdgcn_inverse_ballot_w64(0xffffffffull);
+    const int idx = lane & 31;
+    int *status = h.ctl + 2;
+#define ZT_U(x) __builtin_amdgcn_readfirstlane((int)(x))
+    double hw = 0.0;
+    int n1 = 0, gen = 0, t = 0;
+    bool have = false;
+    __builtin_amdgcn_s_setprio(3);
+    // wait until the spine says where to (re)start: a_gen != gen
+    auto wait_restart = [&]() -> bool {
+        unsigned spins = 0;
+        for (;;) {
+            const int g = lds_load_seq(&mail->a_gen);
+            if (g != gen) {
+                asm volatile("" ::: "memory");
+                gen = g;
+                t = ZT_U(lds_load_seq(&mail->a_restart));
+                have = false;
+                return t >= 0;                                    // (< 0: the spine has finished meanwhile)
+            }
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 4095u) == 0 && launch_failed(status)) return false;
+            // the chain is over once its head has passed the end and the spine is gone: the spine always bumps the generation
+            // for position 0, so a chain of length >= 1 gets here at least once; a finished chain: see below
+            if (lds_load_seq(&mail->a_restart) < 0) return false;
+        }
+    };
+    if (!wait_restart()) return;                                  // (position 0 is always the helper's)
+    for (;;) {
+        // past the chain's end: the spine may still send this wave back, or finish (a_restart < 0)
+        if (t >= len || ZT_U(lds_load_seq(&mail->a_gen)) != gen) { if (!wait_restart()) return; continue; }
+        PrepHdr *P = &mail->prep[t % PREP_R];
+        if (!have) {
+            MailSlot *in_slot = &mail->slot[(t + MAIL_R - 1) % MAIL_R];
+            // the row as position t - 1 was published (by its helper: that is why we are here)
+            unsigned spins = 0;
+            bool again = false;
+            while (lds_load_seq(&in_slot->seq_set) != t) {
+                __builtin_amdgcn_s_sleep(1);
+                if (lds_load_seq(&mail->a_gen) != gen) { again = true; break; }
+                if ((++spins & 4095u) == 0 && launch_failed(status)) return;
+            }
+            if (again) continue;
+            asm volatile("" ::: "memory");
+            double hn; int a0, a1, a2, a3; unsigned a4;
+            mail_hdr_read(in_slot, hn, a0, a4, a1, a2, a3);
+            hw = in_slot->w[idx];
+            n1 = ZT_U(a0);
+            have = true;
+        }
+        {   // the prepared side of position t
+            unsigned spins = 0;
+            bool again = false;
+            while (lds_load_seq(&P->seq) != t + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if (lds_load_seq(&mail->a_gen) != gen) { again = true; break; }
+                if ((++spins & 4095u) == 0 && launch_failed(status)) return;
+            }
+            if (again) continue;
+            asm volatile("" ::: "memory");
+        }
+        const unsigned meta = (unsigned)ZT_U(P->meta);
+        const int nb = (int)(meta & 0xffu);
+        const int n = n1 + nb, drop = n - k;
+        if (((meta >> 24) & 1u) == 0u || n1 <= 0 || drop <= 0 || n > 63) {
+            // not a position of the lean kind: the spine will leave it to its helper and say where to go on
+            if (!wait_restart()) return;
+            continue;
+        }
+        WaveLds &Lw = lds[(meta >> 20) & 0xfu];
+        const double scale_s1 = P->scale_s1;
+        double sw = __longlong_as_double((long long)Lw.key[64 + idx]);
+        int sid = Lw.sel[idx];
+        const bool in1 = lane < n1;
+        if (low) { const double cw = hw * scale_s1; sw = in1 ? cw : inf; sid = lane; }
+        merge_stage<32>(sw, sid);
+        merge_stage<16>(sw, sid);
+        merge_stage<8>(sw, sid);
+        merge_stage<4>(sw, sid);
+        merge_stage<2>(sw, sid);
+        merge_stage<1>(sw, sid);
+        const long long swb = __double_as_longlong(sw);
+        {   // the next row's weights: sorted lane j + drop -> lane j
+            const int from = (lane + drop) << 2;
+            const unsigned wl = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(unsigned)(swb & 0xffffffffll));
+            const unsigned wh = (unsigned)__builtin_amdgcn_ds_bpermute(from, (int)(swb >> 32));
+            hw = __longlong_as_double((long long)(((u64)wh << 32) | wl));
+        }
+        const int sp = push_i32(lane, sid);
+        const int llo = __builtin_amdgcn_mov_dpp((int)(unsigned)(swb & 0xffffffffll), 0x138, 0xf, 0xf, true);   // wave_shr:1
+        const int lhi = __builtin_amdgcn_mov_dpp((int)(swb >> 32), 0x138, 0xf, 0xf, true);
+        const u64 S = __ballot(__longlong_as_double(((long long)lhi << 32) | (unsigned)llo) != sw) | 1ull;
+        Lw.sort.r[lane] = sp;
+        if (lane == 0) {
+            P->S = S;
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&P->a_seq, (gen << 12) | (t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        n1 = k;
+        ++t;
+    }
 #undef ZT_U
 }
 

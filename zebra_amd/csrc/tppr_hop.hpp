@@ -79,7 +79,7 @@ struct PrepHdr {
     int seq;                   // position + 1 once posted (written last)
     u64 S;                     // spine -> helper: the mask of run starts
     int res;                   // spine -> helper: position + 1 = "the spine ran the section"; -(position + 1) = "yours" (written last)
-    int pad;
+    int a_seq;                 // duo mode: generation << 12 | position + 1 once the weights wave has left S and the sorted positions (written last)
 };
 struct Mail {
 #ifdef ZT_CRIT
@@ -88,6 +88,8 @@ struct Mail {
     MailSlot slot[MAIL_R];
     PrepHdr prep[PREP_R];
     int head;          // next position of the chain's edge list
+    int a_restart, a_gen;   // duo mode, spine -> weights wave: "everything you have for positions >= a_restart - 1 is void; pick the row up
+                            // from the slot position a_restart - 1 publishes" (a_gen written last; it only grows)
 };
 
 struct StreamArgs {

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
     if (threadIdx.x < MAIL_R) { mail.slot[threadIdx.x].seq_set = 0; mail.slot[threadIdx.x].seq_ord = 0; mail.slot[threadIdx.x].seq_free = 0; }
     if (threadIdx.x == 0) mail.head = 0;
-    if (MODE == 2 && threadIdx.x < PREP_R) { mail.prep[threadIdx.x].seq = 0; mail.prep[threadIdx.x].res = 0; }
+    if (MODE >= 2 && threadIdx.x < PREP_R) { mail.prep[threadIdx.x].seq = 0; mail.prep[threadIdx.x].res = 0; mail.prep[threadIdx.x].a_seq = 0; }
+    if (MODE >= 2 && threadIdx.x == 0) { mail.a_gen = 0; mail.a_restart = 0; }
 #ifdef ZT_CRIT
     if (threadIdx.x == 0) mail.t_start = (long long)__builtin_readcyclecounter();
 #endif
@@ -125,8 +126,9 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
         // partner's update, the emission -- runs elsewhere (process_chain_partner), but a hop's preparation and its
         // off-chain half (replay, order, stores) still add up to ~5 hop periods of one wave's time.
         if ((int)(threadIdx.x / WAVE) >= A.chain_waves) return;
-        const bool spine_on = MODE == 2 && h.k <= REG_K_MAX && len > 0;
-        if (spine_on && threadIdx.x < WAVE) { chain_spine(h, lds, lane, &mail, len); return; }
+        const bool spine_on = MODE >= 2 && h.k <= REG_K_MAX && len > 0;
+        if (spine_on && threadIdx.x < WAVE) { chain_spine<MODE == 3>(h, lds, lane, &mail, len); return; }
+        if (spine_on && MODE == 3 && threadIdx.x < 2 * WAVE) { chain_weights(h, lds, lane, &mail, len); return; }
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
         // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
@@ -449,6 +451,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     ZT_PROF_BEGIN(s, P_STREAM);
     if (sa.pairs) k_stream<1><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     else if (chain_choice == ZT_CHAIN_SPINE) k_stream<2><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    else if (chain_choice == ZT_CHAIN_DUO) k_stream<3><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     else k_stream<0><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
