@@ -89,6 +89,22 @@ def test_streaming_golden_spine(zt, name):
         _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
 
 
+def test_duo_dense_hub_and_soak(zt, oracle):
+    """Duo mode on the dense-hub graphs and a slice of the randomised soak (restarts of the weights wave: every position the
+    spine leaves to a helper voids its records)."""
+    from zebra_amd import _capi
+    import soak_tppr
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
+    try:
+        for seed in (1, 2):
+            test_dense_hub_graph_vs_oracle(zt, oracle, seed)
+        for seed in range(54000, 54040):
+            err = soak_tppr.one(seed, zt, oracle)
+            assert err is None, err
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, 0)
+
+
 def test_spine_dense_hub_and_soak(zt, oracle):
     """Spine mode on the dense-hub graphs (long chains, hub-hub edges, exact ties), a slice of the randomised soak and a hub
     stream long enough for chains, against the oracle; the chain statistics show the spine running the sections."""
