@@ -113,7 +113,8 @@ int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes);
 /* Statistics of the hub chains since the last call (synchronises `stream`, clears the counters): out5[0] pairs of
  * consecutive chain positions claimed by one wavefront, [1] pairs applied in ONE critical section, [2] / [3] pairs left
  * to the single hop before / inside the section (a precondition failed), [4] positions taken singly.
- * (csrc/tppr_pair.hpp; the reference applies the edges one by one, utils/util.py:495-574.) */
+ * ZT_CHAIN_SPINE / ZT_CHAIN_DUO: [1] = sections the spine ran, [3] = positions it left to their helpers.
+ * (csrc/tppr_pair.hpp, csrc/tppr_chain.hpp; the reference applies the edges one by one, utils/util.py:495-574.) */
 int zt_tppr_chain_stats(zt_tppr *h, int64_t *out5, void *stream);
 
 /* tppr_finder.reset_tppr (utils/util.py:419-434). */
