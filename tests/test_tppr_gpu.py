@@ -802,6 +802,21 @@ def test_dependency_plan_matches_restatement(zt, name, batch):
     f.stream_device(nd, torch.from_numpy(ts[s0:s1].astype(np.float64)).cuda(), ed, 3, True, -1, plan_token=tok)
 
 
+@pytest.mark.parametrize("shape", ["many_big_groups", "one_huge_group", "big_list_overflow"])
+def test_dependency_plan_cooperative_kernel(zt, oracle, shape):
+    """The same plans from k_prepass_coop (ZT_PREPASS_COOP: the ten steps in ONE kernel of 24 workgroups, grid barriers
+    without fences -- the steps hand their arrays over through write-through stores and sc1 loads), and the goldens' state
+    after streaming with it."""
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_TPPR_PREPASS, _capi.PREPASS_COOP)
+    try:
+        test_dependency_plan_of_large_launches(zt, shape)
+        if shape == "many_big_groups":
+            test_large_single_call_and_epoch_wrap(zt, oracle)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_TPPR_PREPASS, 0)
+
+
 @pytest.mark.parametrize("shape", ["many_big_groups", "one_huge_group", "big_list_overflow", "small_fused"])
 def test_dependency_plan_of_large_launches(zt, shape):
     """Writer ordinals and reader flags of launches that take every branch of the prepass' dependency step

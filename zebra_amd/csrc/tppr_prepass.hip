@@ -17,6 +17,14 @@ namespace {
 // K0: a set is planned afresh: the status of the launch it last served is history (the handle's latch keeps it)
 __global__ void k_plan_begin(int *ctl) { if (threadIdx.x == 0) { ctl[2] = 0; ctl[13] = 0; } }
 
+// Accesses to the arrays one prepass step leaves for the next.  SC = false: plain (the steps are kernels of their own, or
+// one workgroup).  SC = true (k_prepass_coop): relaxed agent-scope accesses -- write-through stores, loads that do not
+// trust this compute unit's L1 or a remote XCD's copy -- so that a grid barrier needs no fence: a thread's stores have
+// been acknowledged when it arrives (s_waitcnt vmcnt(0)), and what it loads afterwards comes from where they went.
+template <bool SC> __device__ __forceinline__ int pre_ld(const int *p) { return SC ? ld_agent(p) : *p; }
+template <bool SC> __device__ __forceinline__ void pre_st(int *p, int v) { if (SC) st_agent(p, v); else *p = v; }
+
+template <bool SC = false>
 __device__ __forceinline__ void d_count(int a, const int *__restrict__ nodes, const long long *__restrict__ eidx,
                                         long long role_stride, int B, int n_roles, long long N, int *cnt, int *slot,
                                         int *ctl, int *latch)
@@ -32,14 +40,14 @@ __device__ __forceinline__ void d_count(int a, const int *__restrict__ nodes, co
     if (!ok) {
         atomicExch(&ctl[2], ZT_ERR_RANGE);
         latch_failure(latch, ZT_ERR_RANGE);
-        slot[a] = -1;
+        pre_st<SC>(slot + a, -1);
         return;
     }
     bool shadow = false;
     if (r >= 1) shadow = nodes[i] == x;                                    // same as the source
     if (r == 2) shadow = shadow || nodes[role_stride + i] == x;           // same as the destination
-    if (shadow) { slot[a] = -2; return; }
-    slot[a] = atomicAdd(&cnt[x], 1);
+    if (shadow) { pre_st<SC>(slot + a, -2); return; }
+    pre_st<SC>(slot + a, atomicAdd(&cnt[x], 1));
 }
 
 __global__ void k_count(const int *__restrict__ nodes, const long long *__restrict__ eidx, long long role_stride,
@@ -49,22 +57,23 @@ __global__ void k_count(const int *__restrict__ nodes, const long long *__restri
 }
 
 // K2: the first access of each node reserves a contiguous range of `list`.
+template <bool SC = false>
 __device__ __forceinline__ void d_reserve(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                           const int *cnt, int *off, const int *slot, int *ctl, int *hot_node, int *hot_cnt,
                                           int big_min)
 {
     if (a >= B * n_roles) return;
-    if (slot[a] == 0) {
+    if (pre_ld<SC>(slot + a) == 0) {
         const int x = nodes[(long long)(a / B) * role_stride + a % B];
-        const int c = cnt[x];
-        off[x] = atomicAdd(&ctl[0], c);
+        const int c = pre_ld<SC>(cnt + x);
+        pre_st<SC>(off + x, atomicAdd(&ctl[0], c));
         if (c >= big_min && c <= DEPS_SORT_MAX) {  // a big group: its dependencies come from a sort (d_deps_group)
             const int bi = atomicAdd(&ctl[5], 1);
-            if (bi < MAX_BIG) hot_node[MAX_HOT + bi] = x;
+            if (bi < MAX_BIG) pre_st<SC>(hot_node + MAX_HOT + bi, x);
         }
         if (c >= HOT_MIN) {                        // hub candidate
             const int hi = atomicAdd(&ctl[3], 1);
-            if (hi < MAX_HOT) { hot_node[hi] = x; hot_cnt[hi] = c; }
+            if (hi < MAX_HOT) { pre_st<SC>(hot_node + hi, x); pre_st<SC>(hot_cnt + hi, c); }
         }
     }
 }
@@ -92,29 +101,30 @@ __device__ __forceinline__ int d_chain_budget(int top, int grid, int tasks, int 
 }
 
 // K2b (one wavefront pair): keep the MAX_CHAINS most-touched candidates as chains.
+template <bool SC = false>
 __device__ __forceinline__ void d_hot_select(int t, int *ctl, const int *hot_node, const int *hot_cnt, int *chain_of,
                                              int *chain_node, int *chain_len, int max_chains, int grid, int tasks, int n_models)
 {
     if (t >= MAX_HOT) return;                      // MAX_HOT threads take part
-    int nh = ctl[3];
+    int nh = pre_ld<SC>(ctl + 3);
     nh = nh < MAX_HOT ? nh : MAX_HOT;
     {   // the chain budget of this launch (every thread works it out alike: at most MAX_HOT reads)
         int top = 0;
-        for (int q = 0; q < nh; ++q) top = hot_cnt[q] > top ? hot_cnt[q] : top;
+        for (int q = 0; q < nh; ++q) { const int cq = pre_ld<SC>(hot_cnt + q); top = cq > top ? cq : top; }
         max_chains = d_chain_budget(top, grid, tasks, n_models, max_chains);
     }
-    if (t < MAX_CHAINS) chain_len[t] = 0;
-    if (ctl[2] == ZT_ERR_RANGE) { if (t == 0) ctl[4] = 0; return; }
+    if (t < MAX_CHAINS) pre_st<SC>(chain_len + t, 0);
+    if (pre_ld<SC>(ctl + 2) == ZT_ERR_RANGE) { if (t == 0) pre_st<SC>(ctl + 4, 0); return; }
     int rank = 0;
     if (t < nh) {
-        const int c = hot_cnt[t], x = hot_node[t];
+        const int c = pre_ld<SC>(hot_cnt + t), x = pre_ld<SC>(hot_node + t);
         for (int q = 0; q < nh; ++q) {
-            const int cq = hot_cnt[q];
-            rank += (cq > c || (cq == c && hot_node[q] < x)) ? 1 : 0;
+            const int cq = pre_ld<SC>(hot_cnt + q);
+            rank += (cq > c || (cq == c && pre_ld<SC>(hot_node + q) < x)) ? 1 : 0;
         }
-        if (rank < max_chains) { chain_of[x] = rank; chain_node[rank] = x; }
+        if (rank < max_chains) { pre_st<SC>(chain_of + x, rank); pre_st<SC>(chain_node + rank, x); }
     }
-    if (t == 0) ctl[4] = nh < max_chains ? nh : max_chains;
+    if (t == 0) pre_st<SC>(ctl + 4, nh < max_chains ? nh : max_chains);
 }
 
 
@@ -130,20 +140,21 @@ __global__ void k_hot_select(int *ctl, const int *hot_node, const int *hot_cnt, 
 // chains -- each chain applies its own hub's update and takes the other hub's row from the other chain's versions; the
 // chain of the more-touched hub is the edge's OWNER: its partner task in the general queue emits the edge's rows.
 // A chain holds CH_MAX edges; a hub's later edges go through the general queue and the row in `rows`.
+template <bool SC = false>
 __device__ __forceinline__ void d_own(int i, const int *__restrict__ nodes, long long role_stride, int B, const int *cnt,
                                       const int *slot, const int *wo, const int *chain_of, int *chain_len, int *chain_edges,
                                       int *owner_of)
 {
     if (i >= B) return;
     int owner = -1;
-    if (slot[i] >= 0 && slot[B + i] != -1) {        // valid edge
+    if (pre_ld<SC>(slot + i) >= 0 && pre_ld<SC>(slot + B + i) != -1) {        // valid edge
         const int u = nodes[i], v = nodes[role_stride + i];
-        const int cu = chain_of[u], cv = v != u ? chain_of[v] : -1;
-        const int pu = wo[i], pv = wo[B + i];
+        const int cu = pre_ld<SC>(chain_of + u), cv = v != u ? pre_ld<SC>(chain_of + v) : -1;
+        const int pu = pre_ld<SC>(wo + i), pv = pre_ld<SC>(wo + B + i);
         const bool in_u = cu >= 0 && pu < CH_MAX, in_v = cv >= 0 && pv < CH_MAX;
         if (in_u) { chain_edges[cu * CH_MAX + pu] = i; atomicMax(&chain_len[cu], pu + 1); }
         if (in_v) { chain_edges[cv * CH_MAX + pv] = i; atomicMax(&chain_len[cv], pv + 1); }
-        if (in_u && (!in_v || cnt[u] >= cnt[v])) owner = cu;
+        if (in_u && (!in_v || pre_ld<SC>(cnt + u) >= pre_ld<SC>(cnt + v))) owner = cu;
         else if (in_v) owner = cv;
     }
     owner_of[i] = owner;
@@ -157,16 +168,17 @@ __global__ void k_own(const int *__restrict__ nodes, long long role_stride, int 
 
 // K2d: per access, the chain that holds the node's row by version (zt_tppr::hv): a writer access that is a chain position,
 // a reader access (negative sample) up to the chain's last version.  (After K2c: chain_len is final.)
+template <bool SC = false>
 __device__ __forceinline__ void d_hubacc(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                          const int *slot, const int *wo, const int *chain_of, const int *chain_len, int *hv)
 {
     if (a >= B * n_roles) return;
     int c = -1;
-    if (slot[a] >= 0) {
+    if (pre_ld<SC>(slot + a) >= 0) {
         const int r = a / B;
-        const int cc = chain_of[nodes[(long long)r * role_stride + a % B]];
+        const int cc = pre_ld<SC>(chain_of + nodes[(long long)r * role_stride + a % B]);
         if (cc >= 0) {
-            const int len = chain_len[cc], w = wo[a];
+            const int len = pre_ld<SC>(chain_len + cc), w = pre_ld<SC>(wo + a);
             if (len > 0 && (r < 2 ? w < CH_MAX : w <= len)) c = cc;
         }
     }
@@ -180,13 +192,14 @@ __global__ void k_hubacc(const int *__restrict__ nodes, long long role_stride, i
 }
 
 // K3: scatter accesses into their node's range, encoded (edge << 2) | role.
+template <bool SC = false>
 __device__ __forceinline__ void d_fill(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                        const int *off, const int *slot, int *list)
 {
     if (a >= B * n_roles) return;
-    const int s = slot[a];
+    const int s = pre_ld<SC>(slot + a);
     if (s < 0) return;
-    list[off[nodes[(long long)(a / B) * role_stride + a % B]] + s] = ((a % B) << 2) | (a / B);   // (edge << 2) | role
+    pre_st<SC>(list + pre_ld<SC>(off + nodes[(long long)(a / B) * role_stride + a % B]) + s, ((a % B) << 2) | (a / B));   // (edge << 2) | role
 }
 
 __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *off,
@@ -199,14 +212,15 @@ __global__ void k_fill(const int *__restrict__ nodes, long long role_stride, int
 //   wo    = number of writer accesses by earlier edges  (= ordinal of the last earlier writer)
 //   pflag = the latest earlier edge touching the node, if that access was a reader, else -1
 //   nxt   = how many later edges touch the node (the length of the chain waiting for this access)
+template <bool SC = false>
 __device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                        const int *cnt, const int *off, const int *slot, const int *list, int *wo,
                                        int *pflag, int *nxt, int n_big, int big_min)
 {
     if (a >= B * n_roles) return;
-    if (slot[a] < 0) { wo[a] = 0; pflag[a] = -1; nxt[a] = 0; return; }
+    if (pre_ld<SC>(slot + a) < 0) { pre_st<SC>(wo + a, 0); pre_st<SC>(pflag + a, -1); pre_st<SC>(nxt + a, 0); return; }
     const int x = nodes[(long long)(a / B) * role_stride + a % B];
-    const int o = off[x], c = cnt[x];
+    const int o = pre_ld<SC>(off + x), c = pre_ld<SC>(cnt + x);
     if (c >= big_min && c <= DEPS_SORT_MAX && n_big <= MAX_BIG) return;    // d_deps_group's (every big group is on the list)
     const int me = a % B;
     int best = -1, best_role = 0, writers = 0, nx = 0;
@@ -215,7 +229,7 @@ __device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, lon
     for (int p0 = 0; p0 < c; p0 += 16) {
         int b[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) b[t] = list[o + ((p0 + t) < c ? (p0 + t) : (c - 1))];
+        for (int t = 0; t < 16; ++t) b[t] = pre_ld<SC>(list + o + ((p0 + t) < c ? (p0 + t) : (c - 1)));
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             if (p0 + t >= c) break;
@@ -228,9 +242,9 @@ __device__ __forceinline__ void d_deps(int a, const int *__restrict__ nodes, lon
             }
         }
     }
-    wo[a] = writers;
-    nxt[a] = nx;
-    pflag[a] = (best >= 0 && best_role == 2) ? best : -1;
+    pre_st<SC>(wo + a, writers);
+    pre_st<SC>(nxt + a, nx);
+    pre_st<SC>(pflag + a, (best >= 0 && best_role == 2) ? best : -1);
 }
 
 __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *cnt,
@@ -247,13 +261,14 @@ __global__ void k_deps(const int *__restrict__ nodes, long long role_stride, int
 // after a sort by value the member at position p has exactly p earlier edges: wo = writers among [0, p) (a prefix
 // count), the latest earlier access is the member at p - 1, nxt = c - 1 - p.  One workgroup sorts the group in LDS
 // (bitonic, padded to a power of two) and scans the writer flags.  `s` holds DEPS_SORT_MAX ints, `t` two per thread.
+template <bool SC = false>
 __device__ __forceinline__ void d_deps_group(int tid, int nthr, int x, int B, const int *cnt, const int *off, const int *list,
                                              int *wo, int *pflag, int *nxt, int *s, int *t)
 {
-    const int c = cnt[x], o = off[x];
+    const int c = pre_ld<SC>(cnt + x), o = pre_ld<SC>(off + x);
     int P = 64;
     while (P < c) P <<= 1;
-    for (int i = tid; i < P; i += nthr) s[i] = i < c ? list[o + i] : 0x7fffffff;
+    for (int i = tid; i < P; i += nthr) s[i] = i < c ? pre_ld<SC>(list + o + i) : 0x7fffffff;
     __syncthreads();
     for (int k2 = 2; k2 <= P; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -284,10 +299,10 @@ __device__ __forceinline__ void d_deps_group(int tid, int nthr, int x, int B, co
         const int p = b0 + q;
         if (p >= c) break;
         const int v = s[p], e = v >> 2, r = v & 3, a = r * B + e;
-        wo[a] = run;
+        pre_st<SC>(wo + a, run);
         run += r < 2 ? 1 : 0;
-        nxt[a] = c - 1 - p;
-        pflag[a] = (p > 0 && (s[p - 1] & 3) == 2) ? (s[p - 1] >> 2) : -1;
+        pre_st<SC>(nxt + a, c - 1 - p);
+        pre_st<SC>(pflag + a, (p > 0 && (s[p - 1] & 3) == 2) ? (s[p - 1] >> 2) : -1);
     }
     __syncthreads();                                   // (the arrays are reused for the next group)
 }
@@ -304,12 +319,13 @@ __global__ __launch_bounds__(DEPS_BIG_THREADS) void k_deps_big(int B, const int 
 }
 
 // K5: restore the per-node counters and the control words for the next call.
+template <bool SC = false>
 __device__ __forceinline__ void d_cleanup(int a, const int *__restrict__ nodes, long long role_stride, int B, int n_roles,
                                           const int *slot, int *cnt, int *ctl, const int *hot_node, int *chain_of)
 {
-    if (a < MAX_HOT && a < ctl[3]) chain_of[hot_node[a]] = -1;
+    if (a < MAX_HOT && a < pre_ld<SC>(ctl + 3)) pre_st<SC>(chain_of + pre_ld<SC>(hot_node + a), -1);
     if (a >= B * n_roles) return;
-    if (slot[a] == 0) cnt[nodes[(long long)(a / B) * role_stride + a % B]] = 0;
+    if (pre_ld<SC>(slot + a) == 0) pre_st<SC>(cnt + nodes[(long long)(a / B) * role_stride + a % B], 0);
 }
 
 __global__ void k_cleanup(const int *__restrict__ nodes, long long role_stride, int B, int n_roles, const int *slot,
@@ -373,12 +389,13 @@ constexpr int COOP_WGS = 24, COOP_THREADS = 512, COOP_BARRIERS = 8;
 constexpr int CTL_BAR = 11;
 __device__ __forceinline__ void coop_barrier(int *bar, unsigned target)
 {
-    __syncthreads();                                   // (every thread's stores have been issued and acknowledged: s_waitcnt + barrier)
+    // no fence: what the steps hand each other travels as write-through stores and sc1 loads (pre_st / pre_ld <true>) or as
+    // device-scope atomics; a thread's stores have been acknowledged before it arrives
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                               // ... and are visible beyond this compute unit's L2
         atomicAdd(bar, 1);
-        while ((int)((unsigned)ld_agent(bar) - target) < 0) __builtin_amdgcn_s_sleep(4);
-        __threadfence();                               // (acquire: the compute unit's L1 is shared by the workgroup)
+        while ((int)((unsigned)ld_agent(bar) - target) < 0) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
 }
@@ -394,13 +411,13 @@ __global__ __launch_bounds__(COOP_THREADS) void k_prepass_coop(
     const int gtid = blockIdx.x * COOP_THREADS + tid, gthr = G * COOP_THREADS;
     int *bar = ctl + CTL_BAR;
     unsigned target = bar_base;
-    if (gtid == 0) { ctl[2] = 0; ctl[13] = 0; }                                  // k_plan_begin
+    if (gtid == 0) { st_agent(ctl + 2, 0); st_agent(ctl + 13, 0); }                                  // k_plan_begin
     coop_barrier(bar, target += G);
-    for (int a = gtid; a < A; a += gthr) d_count(a, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
+    for (int a = gtid; a < A; a += gthr) d_count<true>(a, nodes, eidx, role_stride, B, n_roles, N, cnt, slot, ctl, latch);
     coop_barrier(bar, target += G);
-    for (int a = gtid; a < A; a += gthr) d_reserve(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt, big_min);
+    for (int a = gtid; a < A; a += gthr) d_reserve<true>(a, nodes, role_stride, B, n_roles, cnt, off, slot, ctl, hot_node, hot_cnt, big_min);
     coop_barrier(bar, target += G);
-    for (int a = gtid; a < A; a += gthr) d_fill(a, nodes, role_stride, B, n_roles, off, slot, list);
+    for (int a = gtid; a < A; a += gthr) d_fill<true>(a, nodes, role_stride, B, n_roles, off, slot, list);
     coop_barrier(bar, target += G);
     {
         const int n_big = ld_agent(&ctl[5]);
@@ -408,25 +425,24 @@ __global__ __launch_bounds__(COOP_THREADS) void k_prepass_coop(
         // walk of everybody else; the last workgroup picks the chains meanwhile (it needs the candidates only)
         if (n_big <= MAX_BIG)
             for (int g = blockIdx.x; g < n_big; g += G)
-                d_deps_group(tid, COOP_THREADS, hot_node[MAX_HOT + g], B, cnt, off, list, wo, pflag, nxt, sort_s, sort_t);
-        for (int a = gtid; a < A; a += gthr) d_deps(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt, n_big, big_min);
-        if ((int)blockIdx.x == G - 1) d_hot_select(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains, grid, B * n_models, n_models);
+                d_deps_group<true>(tid, COOP_THREADS, ld_agent(hot_node + MAX_HOT + g), B, cnt, off, list, wo, pflag, nxt, sort_s, sort_t);
+        for (int a = gtid; a < A; a += gthr) d_deps<true>(a, nodes, role_stride, B, n_roles, cnt, off, slot, list, wo, pflag, nxt, n_big, big_min);
+        if ((int)blockIdx.x == G - 1) d_hot_select<true>(tid, ctl, hot_node, hot_cnt, chain_of, chain_node, chain_len, max_chains, grid, B * n_models, n_models);
     }
     coop_barrier(bar, target += G);
-    for (int i = gtid; i < B; i += gthr) d_own(i, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
+    for (int i = gtid; i < B; i += gthr) d_own<true>(i, nodes, role_stride, B, cnt, slot, wo, chain_of, chain_len, chain_edges, owner_of);
     coop_barrier(bar, target += G);
-    for (int a = gtid; a < A; a += gthr) d_hubacc(a, nodes, role_stride, B, n_roles, slot, wo, chain_of, chain_len, hv);
+    for (int a = gtid; a < A; a += gthr) d_hubacc<true>(a, nodes, role_stride, B, n_roles, slot, wo, chain_of, chain_len, hv);
     coop_barrier(bar, target += G);
     for (int a = gtid; a < (A > MAX_HOT ? A : MAX_HOT); a += gthr)
-        d_cleanup(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
+        d_cleanup<true>(a, nodes, role_stride, B, n_roles, slot, cnt, ctl, hot_node, chain_of);
     // the last workgroup through resets the control words (k_reset_ctl: after every cleanup thread has read ctl[3])
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
         target += G;
         if ((unsigned)atomicAdd(bar, 1) + 1u == target) {
-            __threadfence();
-            for (int q = 0; q < 6; ++q) if (q != 2 && q != 4) ctl[q] = 0;
+            for (int q = 0; q < 6; ++q) if (q != 2 && q != 4) st_agent(ctl + q, 0);
         }
     }
 }
