@@ -31,8 +31,8 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
 // are filled (pipeline.hip: the message kernel hands its list of winners over), no compaction of flagged ids
 // The output layers of an embed call, held back (embed_ex: `defer`) so that gru_update_ex can launch them in ONE kernel with the
 // GRU update (k_out_gru, memory_update.hip): the two are independent apart from the memory rows the source path reads --
-// the GRU half waits for those reads before it writes (a counter in its workspace that only grows: src_base = its value
-// before this launch, tracked by the caller and 0 for a workspace whose weights are not packed yet).
+// the GRU half waits for those reads before it writes (two counters in its workspace that take turns: a launch counts in one
+// from zero and clears the other for the next; src_base = which one, toggled by gru_update_ex).
 struct embed_out_deferred {
     bool valid;
     const float *memory;

@@ -196,7 +196,7 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
-constexpr int GRU_SRC_WORD = 32; // word of the workspace's counter block that counts source-path workgroups (k_out_gru)
+constexpr int GRU_SRC_WORD = 32; // words 32, 33 of the workspace's counter block count source-path workgroups (k_out_gru), launch by launch in turn
 
 // Zero-padded gate-major copy in FRAGMENT order: W[3D][K] -> Wp[3][Dp / 16][Kp / 16][64 lanes][4]: the 16 x 16 block (N-tile
 // nt, k-chunk kc) of a gate as the MFMA's lanes hold it -- lane (r16, g4) has W[16 nt + r16][16 kc + 4 g4 .. + 3] -- so that a
@@ -423,10 +423,14 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(GruArgs G)
 // workgroup that has no compute unit), then the GRU tiles (the longest chains: not behind 200 short workgroups' dispatch),
 // then the neighbour paths.
 template <int HG>
-__global__ __launch_bounds__(64 * GRU_WAVES) void k_out_gru(EmbedOutArgs E, int out_tiles, int gru_wgs, GruArgs G, int *src_read, unsigned src_target)
+__global__ __launch_bounds__(64 * GRU_WAVES) void k_out_gru(EmbedOutArgs E, int out_tiles, int gru_wgs, GruArgs G, int *src_read, unsigned src_target,
+                                                           int *src_next)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
+    // (two counters take turns from launch to launch: this launch counts in *src_read from 0 and zeroes the other one for the
+    //  next -- the previous launch, the last to look at it, is over; no value has to be carried on the host)
+    if (bid == 0 && threadIdx.x == 0) st_agent(src_next, 0);
     if (bid >= out_tiles && bid < out_tiles + gru_wgs) {
         gru_body<1>(G, smem, bid - out_tiles, src_read, src_target);
         return;
@@ -645,10 +649,11 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(GruSplitArgs GS)
 // workgroups), the GRU's (tile, N-tile) workgroups, the neighbour paths.
 template <int NT, int HG>
 __global__ __launch_bounds__(64 * GS_WAVES) void k_out_gru2(EmbedOutArgs E, int gx, int n_src_wgs, int gru_tiles, GruSplitArgs GS, int *src_read,
-                                                            unsigned src_target)
+                                                            unsigned src_target, int *src_next)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (bid == 0 && threadIdx.x == 0) st_agent(src_next, 0);          // (see k_out_gru)
     const int gru_wgs = gru_tiles * NT;
     if (bid >= n_src_wgs && bid < n_src_wgs + gru_wgs) {
         const int g = bid - n_src_wgs;
@@ -891,7 +896,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
         ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GP_TILE_COUNTERS * 4, s));
-        ZT_HIP(hipMemsetAsync(cnt + GRU_SRC_WORD, 0, sizeof(int), s));       // k_out_gru's "source rows read" counter (only ever grows)
+        ZT_HIP(hipMemsetAsync(cnt + GRU_SRC_WORD, 0, 2 * sizeof(int), s));   // k_out_gru's two "source rows read" counters
     }
     // Two organisations of the same update (zt_set_kernel_choice(ZT_CHOICE_GRU, ..) pins one; tests hold them against each
     // other and torch's GRUCell):
@@ -925,8 +930,9 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
             const int per_path = d.gx * NTg, n_src_wgs = (per_path + 3) / 4, n_nb_wgs = (per_path * d.M + 3) / 4;
             size_t lds_f = (size_t)4 * 16 * (NTg * 16 + 4) * 4;
             if (lds_f < lds2) lds_f = lds2;
-            int *src_read = cnt + GRU_SRC_WORD;
-            const unsigned target = d.src_base + (unsigned)per_path;
+            const int par = (int)(d.src_base & 1u);                      // (the counter of this launch; the kernel zeroes the other)
+            int *src_read = cnt + GRU_SRC_WORD + par, *src_next = cnt + GRU_SRC_WORD + (par ^ 1);
+            const unsigned target = (unsigned)per_path;
             const unsigned grid = (unsigned)(n_src_wgs + gru_tiles * NTg + n_nb_wgs);
 #define ZT_OG2(NTV, HGV) do {                                                                                                   \
                 static size_t attr_og2 = 0;                                                                                     \
@@ -935,12 +941,12 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                       \
                     attr_og2 = lds_f;                                                                                           \
                 }                                                                                                               \
-                k_out_gru2<NTV, HGV><<<grid, 64 * GS_WAVES, lds_f, s>>>(E, d.gx, n_src_wgs, gru_tiles, GS, src_read, target);    \
+                k_out_gru2<NTV, HGV><<<grid, 64 * GS_WAVES, lds_f, s>>>(E, d.gx, n_src_wgs, gru_tiles, GS, src_read, target, src_next); \
             } while (0)
             if (NTg == 7) { if (d.hg == 1) ZT_OG2(7, 1); else if (d.hg == 5) ZT_OG2(7, 5); else ZT_OG2(7, 10); }
             else          { if (d.hg == 1) ZT_OG2(8, 1); else if (d.hg == 5) ZT_OG2(8, 5); else ZT_OG2(8, 10); }
 #undef ZT_OG2
-            fuse->src_base = target;
+            fuse->src_base = (unsigned)(par ^ 1);
             fuse->valid = false;
         } else {
             // (held-back output layers first: their source path reads the rows this kernel rewrites)
@@ -977,13 +983,14 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                 ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
                 attr_f[hi] = lds_f;
             }
-            int *src_read = cnt + GRU_SRC_WORD;
-            const unsigned target = d.src_base + (unsigned)out_tiles;
+            const int par = (int)(d.src_base & 1u);                      // (the counter of this launch; the kernel zeroes the other)
+            int *src_read = cnt + GRU_SRC_WORD + par, *src_next = cnt + GRU_SRC_WORD + (par ^ 1);
+            const unsigned target = (unsigned)out_tiles;
             const unsigned grid = (unsigned)n_out + gru_wgs;
-            if (d.hg == 1) k_out_gru<1><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
-            else if (d.hg == 5) k_out_gru<5><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
-            else k_out_gru<10><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target);
-            fuse->src_base = target;
+            if (d.hg == 1) k_out_gru<1><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
+            else if (d.hg == 5) k_out_gru<5><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
+            else k_out_gru<10><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
+            fuse->src_base = (unsigned)(par ^ 1);
             fuse->valid = false;                       // (launched)
         } else {
             if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }

@@ -532,7 +532,6 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         msgs_waited = true;
         // (the output layers are held back: gru_update_ex below launches them in ONE kernel with the GRU update where both take
         //  their tiled forms -- k_out_gru --, otherwise in front of it)
-        if (!p->gru_ready) p->out_gru.src_base = 0;          // (the workspace's counters are zeroed with its first weight pack)
         rc = zt::embed_ex(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                           od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s,
                           msgs_waited ? p->msgs_done : nullptr, &p->out_gru);
