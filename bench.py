@@ -140,13 +140,17 @@ def model_weights(tgn):
     return w, c(tgn.time_encoder.w.weight).ravel()
 
 
-def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
+def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads, gpu=None):
     """Oracle ("port") on the host cores: the eval-mode protocol on the first timed batches of the same
     stream, started from the GPU run's warm state.  SURVEY.md 8(d): P1 = the C restatement, single-threaded
     like the reference's Numba loop, P2 / P3 = the build's torch-CPU module (oracle/torch_cpu.py: the torch
     ops the reference runs, torch.get_num_threads() threads) -- that is `value`, first half of the sample.
     Second half, reported beside it: P1 with one thread per T-PPR model and P2 / P3 by the C port on
-    n_threads OpenMP threads."""
+    n_threads OpenMP threads.
+    ``gpu``: what the GPU run kept of the SAME batches (``emb(b)`` -> its [3B, H] embeddings of sample batch b as a numpy
+    array; ``after`` = ids + T-PPR rows + memory tables exported right behind the timed region, present when the sample
+    ends where the timed region ends): the oracle's outputs are compared with them batch by batch instead of being
+    thrown away -> ``parity_in_run`` (the oracle is the checker here, after the timed regions)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     import torch
@@ -183,6 +187,7 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
     t_all = [0.0, 0.0, 0.0]
     n_e = [0, 0, 0]
     single = p.tppr.streaming_topk if p.tppr is not None else None
+    par = dict(batches=0, timed_batches=0, max_abs_embedding_diff=0.0, tolerance=1e-4)
     for b, (src, dst, neg, ts, eidx) in enumerate(batches):
         part = 0 if b < cut1 else (1 if b < cut2 else 2)
         p.p23 = "c" if part == 1 else "torch"
@@ -196,11 +201,20 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
         nodes = np.concatenate([src, dst, neg]).astype(np.int32)
         on = p.topk(nodes, ts, eidx)
         t1 = time.perf_counter()
-        p.batch(src, dst, neg, ts, eidx, False, topk_out=on)
+        emb_ref, _ = p.batch(src, dst, neg, ts, eidx, False, topk_out=on)
         t2 = time.perf_counter()
         t_p1[part] += t1 - t0
         t_all[part] += t2 - t0
         n_e[part] += len(src)
+        if gpu is not None:
+            got = gpu["emb"](b)
+            if got is not None:
+                d_b = float(np.abs(got - np.asarray(emb_ref)).max()) if got.shape == np.asarray(emb_ref).shape else float("inf")
+                par["max_abs_embedding_diff"] = max(par["max_abs_embedding_diff"], d_b)
+                par["batches"] += 1
+                if b >= gpu["warmup"]:
+                    par["timed_batches"] += 1
+            del got
     if p.tppr is not None:
         p.tppr.streaming_topk = single
     out = dict(value=n_e[0] / t_all[0], unit="edges/s", cores=n_threads, kind="port",
@@ -224,6 +238,31 @@ def cpu_baseline(wl, snap, weights, time_w, batches, csr_arrays, n_threads):
         out["value_default_threads"] = n_e[2] / t_all[2]
         out["default_threads"] = default_threads
     torch.set_num_threads(default_threads)
+    if gpu is not None and par["batches"]:
+        after = gpu.get("after")
+        par["tppr_rows_bit_exact"] = None
+        if after is not None:
+            ids_a = after["ids"]
+            if p.tppr is not None:
+                same, n_rows = True, 0
+                for m in range(M):
+                    ref_rows = p.tppr.export_rows(m, ids_a)
+                    for kk in ref_rows:
+                        same = same and bool(np.array_equal(ref_rows[kk], after["tppr"][m][kk]))
+                    n_rows += len(ids_a)
+                par["tppr_rows_bit_exact"] = same
+                par["tppr_rows_compared"] = n_rows
+            par["max_abs_memory_diff"] = float(np.abs(p.mem.memory[ids_a] - after["memory"]).max()) if len(ids_a) else 0.0
+            par["last_update_equal"] = bool(np.array_equal(p.mem.last_update[ids_a], after["last_update"]))
+        par["ok"] = bool(par["max_abs_embedding_diff"] <= par["tolerance"] and par["tppr_rows_bit_exact"] is not False
+                         and par.get("max_abs_memory_diff", 0.0) <= par["tolerance"] and par.get("last_update_equal", True))
+        par["note"] = ("oracle (CPU restatement, pinned to the reference's fixtures) on the run's own batches from the run's own "
+                       "warm state: %d warm-up + %d timed batches, embeddings of every batch against the ones the GPU wrote in "
+                       "the warm-up / timed region%s" % (par["batches"] - par["timed_batches"], par["timed_batches"],
+                       "; T-PPR rows (len, norm, keys, time stamps, float64 weights: np.array_equal) and memory rows of every "
+                       "node those batches touched, exported right behind the timed region" if after is not None else
+                       "; state not compared (the sample ends before the timed region does)"))
+        out["parity_in_run"] = par
     return out
 
 
@@ -249,7 +288,7 @@ def launch_ranks(n, argv):
 CRIT_SECTION_NS = 970.0    # the hub chain's critical section: 2280 core clocks (median, tools/crit_profile.py)
 
 
-def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edges):
+def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edges, steady=0):
     """One workload: build the model, prefill, warm up, time `steps` steps, read the per-kernel events, run the CPU leg
     (world == 1).  Returns the dict of the JSON line (headline) or of a `workloads` entry."""
     import ctypes as C
@@ -265,7 +304,10 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     # two timed regions: the metric's step (embeddings + T-PPR and memory updates: SURVEY.md 8d) and, behind it, the same
     # step with compute_edge_probabilities' scorer at its tail (model/tgn_model.py:185-188; 5 warm-up steps in between)
     scored = world == 1 and not a.no_score and not (a.no_pipeline and headline) and not a.exchange_world1
-    n_steps_total = prefill + warmup + steps + ((5 + steps) if scored else 0)
+    # a third region (headline only, `steady` > 0): the metric's step again over `steady` batches with the launch groups such
+    # a region gets -- the figure DESIGN.md quotes as "200 steps", where the region's first and last batch no longer count
+    steady = steady if (steady > steps and not (a.no_pipeline and headline) and not a.python_loop) else 0
+    n_steps_total = prefill + warmup + steps + ((5 + steps) if scored else 0) + ((10 + steady) if steady else 0)
     n_edges = n_steps_total * bs
     if n_edges > wl["n_edges"]:
         raise SystemExit("stream of %d edges is shorter than prefill+warmup+steps" % wl["n_edges"])
@@ -324,8 +366,8 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     # views of every batch, made once: slicing tensors is host work that is not part of the path
     batches = [(src_d[b * bs:(b + 1) * bs], dst_d[b * bs:(b + 1) * bs], neg_d[b * bs:(b + 1) * bs],
                 ts_d[b * bs:(b + 1) * bs], eidx_d[b * bs:(b + 1) * bs]) for b in range(n_steps_total)]
-    look = synth.pipeline_look(group)           # batches in sight: the rest of this group, the next group, the one after
-                                                # it, and one more (a group is only full while a follower is in sight)
+    state = dict(look=synth.pipeline_look(group))   # batches in sight: the rest of this group, the next group, the one after
+                                                    # it, and one more (a group is only full while a follower is in sight)
 
     # the batch loop itself: native (zt_pipeline_run: the region's steps from one host call -- the loop of
     # evaluation/evaluation.py:19-45 in the library, the row exchange of a multi-rank run included) unless --python-loop or
@@ -337,18 +379,21 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         if native:
             prepared[(b0, nb)] = tgn.prepare_run(batches[b0:b0 + nb])
 
-    def run(b0, nb):
-        # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region)
+    def run(b0, nb, keep=None):
+        # exactly nb steps; nothing of step b0+nb is enqueued (the view ahead ends with the region).  keep: a [nb, 3 bs, H]
+        # tensor that receives every step's embeddings (parity_in_run) instead of one buffer overwritten by every step
         ctx = torch.cuda.stream(main_stream) if main_stream is not None else contextlib.nullcontext()
         with ctx:
             if native:
                 if (b0, nb) not in prepared:
                     prep(b0, nb)
-                tgn.run_device(prepared[(b0, nb)], look=look)
+                tgn.run_device(prepared[(b0, nb)], out=keep, look=state["look"])
                 return
             for b in range(b0, b0 + nb):
-                ahead = [] if no_pipeline else batches[b + 1: min(b + 1 + look, b0 + nb)]
-                step(*batches[b], ahead=ahead)
+                ahead = [] if no_pipeline else batches[b + 1: min(b + 1 + state["look"], b0 + nb)]
+                e = step(*batches[b], ahead=ahead)
+                if keep is not None:
+                    keep[b - b0].copy_(e)
 
     lib = _capi.lib()
     if os.environ.get("ZT_DUMP_MAPS") and rank == 0:
@@ -393,7 +438,14 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         del xa
         spun = True
     prep(prefill + warmup, steps)               # (the region's batch list in the library's form: made before the clock starts)
-    run(prefill, warmup)
+    # parity_in_run: the embeddings of the warm-up and the timed steps are KEPT (one [3 bs, H] block per step instead of one
+    # buffer every step overwrites) and compared with the oracle's after the timed regions, in cpu_baseline()
+    keep_w = keep_t = None
+    if cpu_nb:
+        Hd = tgn.embedding_dimension * (M + 1)
+        keep_w = torch.empty((warmup, 3 * bs, Hd), dtype=torch.float32, device=device) if warmup else None
+        keep_t = torch.empty((steps, 3 * bs, Hd), dtype=torch.float32, device=device)
+    run(prefill, warmup, keep_w)
     if not a.no_profile:
         lib.zt_profile_reset()
         # (two event records per timed launch are host calls too: every 4th launch of the main stream's kernels in the headline
@@ -405,7 +457,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(prefill + warmup, steps)
+    run(prefill + warmup, steps, keep_t)
     t_host = time.perf_counter() - t0          # host time to enqueue the timed steps
     torch.cuda.synchronize()
     if world > 1:
@@ -415,6 +467,13 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     sys.stderr.write("[bench] %s: host enqueue %.3f ms/step, wall %.3f ms/step\n" % (name, 1e3 * t_host / steps, 1e3 * dt / steps))
     chain_stats = tgn.embedding_module.tppr_finder.chain_stats() if wl["strategy"] == "streaming" else None
     lib.zt_profile_enable(0)
+    # parity_in_run: the state right behind the timed region (T-PPR rows, memory rows of every node the warm-up and timed
+    # batches touched), when the CPU sample ends exactly there
+    after = None
+    if cpu_nb == warmup + steps:
+        ea, eb = prefill * bs, (prefill + cpu_nb) * bs
+        ids_a = np.unique(np.concatenate([src[ea:eb], dst[ea:eb], neg[ea:eb]])).astype(np.int64)
+        after = snapshot_state(tgn, wl, ids_a)
     # ---- the second region: the same step + the link scorer (sharded runs score nothing: a rank holds a row shard) ----
     with_scorer = None
     if scored:
@@ -447,6 +506,39 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                 "next %d batches after 5 warm-up steps; `value` is the metric's step (embeddings + T-PPR and "
                                 "memory updates)" % steps)
         sys.stderr.write("[bench] %s: with the scorer %.3f ms/step\n" % (name, 1e3 * dt_s / steps))
+    # ---- the third region (headline): the metric's step over `steady` batches, launch groups as such a region gets them ----
+    steady_state = None
+    if steady:
+        if scored:
+            tgn.enable_scoring(False)
+        _, g_s = synth.pipeline_settings(wl, steady, -1, a.group if headline else -1)
+        if g_s != group and wl["strategy"] == "streaming":
+            _capi.check(lib.zt_pipeline_set_group(tgn._pipe, C.c_int32(g_s)), "zt_pipeline_set_group")
+            tgn._pipe_group = g_s
+        state["look"] = synth.pipeline_look(g_s)
+        b2 = prefill + warmup + steps + ((5 + steps) if scored else 0)
+        prep(b2 + 10, steady)
+        run(b2, 10)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        run(b2 + 10, steady)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ss = time.perf_counter() - t2
+        if world > 1:
+            tm2 = torch.tensor([dt_ss], dtype=torch.float64, device=device)
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+            dt_ss = float(tm2.item())
+        steady_state = dict(value=steady * bs / dt_ss, unit="edges/s", ms_per_step=1e3 * dt_ss / steady, steps=steady, warmup=10,
+                            tppr_launch_group=g_s,
+                            note="the metric's step (same workload, same settings, no per-kernel events) over %d batches behind the "
+                                 "regions above: the timed region's first batch (prepass + a single-batch T-PPR update before any "
+                                 "aggregation can start) and its last aggregation weigh 1/%d here instead of 1/%d" % (steady, steady, steps))
+        sys.stderr.write("[bench] %s: steady state %.3f ms/step over %d steps\n" % (name, 1e3 * dt_ss / steady, steady))
     if wl["strategy"] == "streaming":
         tgn.embedding_module.tppr_finder.check_status()
     if world > 1:
@@ -585,7 +677,12 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         extra = dict(src=src, dst=dst, eidx=eidx, ts=ts)
         if F != 1:
             extra["efeat"] = efeat_host
-        cpu = cpu_baseline(wl, snap, weights, time_w, cb, extra, min(16, os.cpu_count() or 1))
+        def gpu_emb(b, kw=keep_w, kt=keep_t):
+            t = kw[b] if b < warmup else (kt[b - warmup] if b - warmup < steps else None)
+            return None if t is None else t.cpu().numpy()
+        cpu = cpu_baseline(wl, snap, weights, time_w, cb, extra, min(16, os.cpu_count() or 1),
+                           gpu=dict(emb=gpu_emb, warmup=warmup, after=after))
+        del keep_w, keep_t
 
     value = edges / dt
     out = {
@@ -617,6 +714,8 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         "chain_bound_ms_per_step": (kern["tppr_stream"]["avg_us"] * kern["tppr_stream"]["launches"] / steps / 1e3)
                                    if "tppr_stream" in kern else None,
         "with_scorer": with_scorer,
+        "steady_state": steady_state,
+        "parity_in_run": (cpu or {}).pop("parity_in_run", None),
         "roofline": roof,
         "roofline_throughput_kernel": roof2,
         "cpu_baseline": cpu,
@@ -649,6 +748,9 @@ def main():
                          "line, each with its own ms_per_step / roofline / cpu_baseline: comma-separated names, 'none', or "
                          "'default' = c2,c3,c4 behind the c5 headline (nothing behind another --workload)")
     ap.add_argument("--leg-steps", type=int, default=100, help="timed steps of every leg (warm-up 10)")
+    ap.add_argument("--steady-steps", type=int, default=200,
+                    help="a further timed region of this many steps behind the headline's (printed as \"steady_state\"; skipped "
+                         "when --steps is at least as long; 0 = none)")
     ap.add_argument("--prefill-steps", type=int, default=-1,
                     help="untimed batches run before warm-up so that T-PPR rows are full (default: per workload)")
     ap.add_argument("--cpu-edges", type=int, default=-1, help="edges of the CPU-baseline sample (0 = skip)")
@@ -733,7 +835,7 @@ def main():
 
     cpu_default = {"c5": 48 * 4096, "c3": 40 * 600, "c2": 60 * 200, "c1": 60 * 200, "c4": 20 * 1000}
     ce = a.cpu_edges if a.cpu_edges >= 0 else cpu_default[a.workload]
-    out = run_workload(a, a.workload, a.steps, a.warmup, world, rank, device, True, ce)
+    out = run_workload(a, a.workload, a.steps, a.warmup, world, rank, device, True, ce, steady=a.steady_steps)
     legs = a.legs
     if legs == "default":
         legs = "c2,c3,c4" if a.workload == "c5" else "none"
@@ -743,7 +845,7 @@ def main():
         leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
         r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
         if r is not None:
-            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_hops", "chain_bound_ms_per_step", "with_scorer",
+            res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_hops", "chain_bound_ms_per_step", "with_scorer", "parity_in_run",
                                               "roofline", "roofline_throughput_kernel", "cpu_baseline", "algorithmic", "kernels")}
     if rank == 0:
         out["rccl_ranks"] = world if (world > 1 and not rehearsal) else 0

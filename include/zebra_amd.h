@@ -499,6 +499,10 @@ int zt_pipeline_set_stats(zt_pipeline *p, float *avg_topk_dev);
  * non-zero the streaming T-PPR state is AHEAD of the last step: a caller must not query or update the state
  * through zt_tppr_stream (or leave the announced order) before those batches have been stepped. */
 int zt_pipeline_outstanding(const zt_pipeline *p);
+/* Returns ZT_ERR_TIMEOUT (once) when a kernel of an EARLIER step gave up a bounded in-kernel wait -- the gate between the
+ * output layers and the GRU update in their shared launch waits at most 4 s for the source path's reads, then leaves the
+ * memory rows of its tile untouched and reports to the status word of the descriptor and to a host-mapped latch that
+ * this call looks at on entry: that step's memory update is incomplete. */
 int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const zt_batch *ahead, int32_t n_ahead,
                            int64_t row_lo, int64_t row_hi, int64_t pos_lo, int64_t pos_hi, float *out_emb_dev);
 /* n consecutive whole-batch steps from one host call (the batch loop of evaluation/evaluation.py:19-45): step b sees

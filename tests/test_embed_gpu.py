@@ -208,6 +208,104 @@ def test_fused_output_and_gru_launch_matches_separate_kernels(F, bs):
     assert np.abs(outs["seq"][0]).max() > 0
 
 
+@pytest.mark.parametrize("F,bs", [(1, 400), (1, 150)])
+def test_out_gru_gate_survives_what_happens_between_fused_steps(F, bs):
+    """The gate between the two halves of k_out_gru / k_out_gru2 keeps ALL its state in two words of the GRU workspace
+    (count of source-path units, count of participants that have left; the last one out zeroes both): nothing the host
+    does between two fused steps can leave it out of step with the kernels.  Driven through the sequences the round-5 review
+    named -- the workspace re-packed mid-pipeline (a weight changed in place: zt_pipeline_update(weights_changed = 1)), a
+    step whose GRU half has no rows (positions = (0, 0)) between fused steps, the pipeline destroyed and re-created on the
+    same workspace, a direct zt_gru_update on that workspace between two pipeline steps -- against the sequential path
+    (separate kernels), bit for bit; and the two gate words read zero after every step."""
+    N, D, T, k, al, be, seed = 3000, 100, 100, 20, [0.1, 0.1], [0.5, 0.95], 97
+    nbt = 9
+    E = nbt * bs
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    outs = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode == "pipe":
+            tgn.enable_pipeline(tppr_cus=0, max_batch=bs)
+        embs, gates = [], []
+        for b in range(nbt):
+            cur = tuple(x[b * bs:(b + 1) * bs] for x in t)
+            # (no batch is queried ahead: the pipeline may be torn down between any two steps without a T-PPR update
+            #  having been applied for a batch that is then stepped again)
+            main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+            with torch.cuda.stream(main):
+                if b == 2:                                   # a weight changes in place: the workspace is re-packed
+                    with torch.no_grad():
+                        tgn.memory_updater.memory_updater.weight_ih.mul_(1.0)
+                        tgn.embedding_module.fc2.weight.mul_(1.0)
+                if b == 6:                                   # a direct zt_gru_update on the pipeline's workspace (no row is flagged: the
+                    ids = torch.arange(1, 2 * bs + 1, dtype=torch.int32, device=dev)     # tables stay, the row list and counter do not)
+                    tgn.memory_updater.update_device(tgn.memory, ids, 2 * bs)
+                pos = (0, 0) if b == 4 else None             # this step's GRU half finds no row
+                embs.append(tgn.step_device(*cur, positions=pos).clone())
+            torch.cuda.synchronize()
+            if mode == "pipe":
+                gates.append(tgn.memory_updater._ws[:256].view(torch.int32)[32:34].cpu().numpy().copy())
+                if b == 5:                                   # the pipeline goes and comes back on the same workspace
+                    ws_before = tgn.memory_updater._ws.data_ptr()
+                    tgn.enable_pipeline(False)
+                    tgn.enable_pipeline(tppr_cus=0, max_batch=bs)
+                    assert tgn.memory_updater._ws.data_ptr() == ws_before
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        assert int(tgn.embedding_module._status.item()) == 0 if tgn.embedding_module._status is not None else True
+        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(), tgn.memory.last_update.cpu().numpy())
+        if mode == "pipe":
+            assert all((g == 0).all() for g in gates), gates
+        tgn.enable_pipeline(False)
+    for q in range(3):
+        assert np.array_equal(outs["seq"][q], outs["pipe"][q])
+    assert np.abs(outs["seq"][0]).max() > 0
+
+
+def test_out_gru_gate_gives_up_and_reports():
+    """The gate's wait is bounded (4 s of the wall clock, as every wait of k_stream): with the count of source-path units
+    poisoned so that it can never reach its target, the GRU half gives up, leaves the memory rows of its tiles untouched,
+    writes ZT_ERR_TIMEOUT to the step's status word and to the pipeline's host-mapped latch -- the NEXT step call fails
+    with it, once -- and the last participant out still zeroes the gate: the step after that runs clean."""
+    from zebra_amd import _capi
+    N, D, F, T, k, al, be, seed, bs = 3000, 100, 1, 100, 20, [0.1, 0.1], [0.5, 0.95], 98, 400
+    E = 4 * bs
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    tgn.enable_pipeline(tppr_cus=0, max_batch=bs)
+    batch = lambda b: tuple(x[b * bs:(b + 1) * bs] for x in t)
+    with torch.cuda.stream(tgn.main_stream):
+        tgn.step_device(*batch(0))
+        torch.cuda.synchronize()
+        gate = tgn.memory_updater._ws[:256].view(torch.int32)
+        assert gate[32:34].tolist() == [0, 0]
+        mem_before = tgn.memory.memory.clone()
+        gate[32] = -3                                        # three units short for ever: every GRU workgroup's wait gives up
+        torch.cuda.synchronize()
+        tgn.step_device(*batch(1))                           # (enqueued: the failure is the kernel's, seconds from now)
+        torch.cuda.synchronize()
+        assert int(tgn.embedding_module._status.item()) == _capi.ZT_ERR_TIMEOUT
+        assert torch.equal(tgn.memory.memory, mem_before)    # no tile wrote its rows
+        assert gate[32:34].tolist() == [0, 0]                # the last one out reset the gate all the same
+        with pytest.raises(_capi.ZebraError, match="status -5"):
+            tgn.step_device(*batch(2))
+        tgn.embedding_module._status.zero_()
+        tgn.step_device(*batch(2))                           # reported once; the pipeline runs on
+        tgn.step_device(*batch(3), check_status=True)
+        torch.cuda.synchronize()
+        assert gate[32:34].tolist() == [0, 0]
+        assert not torch.equal(tgn.memory.memory, mem_before)
+    tgn.enable_pipeline(False)
+
+
 @pytest.mark.parametrize("group,look,ragged", [(2, 5, False), (3, 8, True), (4, 11, False), (2, 2, False), (3, 1, True)])
 def test_grouped_tppr_launches_match_sequential(group, look, ragged):
     """zt_pipeline_set_group: the streaming T-PPR update of `group` consecutive batches as ONE launch (edges in

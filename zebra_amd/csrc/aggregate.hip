@@ -1522,11 +1522,11 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         od.valid = true; od.form = 2; od.gx = (int)(tiles < 256 ? tiles : 256);
         od.memory = memory_dev; od.num_nodes = num_nodes; od.nodes = nodes_dev; od.N = N; od.D = D; od.M = M; od.hg = hg;
         od.H = H; od.S = S; od.fc2_p = fc2t; od.fc2_b = wt->fc2_b; od.fc1s_p = fc1st; od.fc1s_b = wt->fc1s_b; od.fc2s_p = fc2st;
-        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.src_base = 0;
+        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.latch = nullptr;
         if (defer != nullptr) {
-            const unsigned keep = defer->src_base;
+            int *keep = defer->latch;
             *defer = od;
-            defer->src_base = keep;
+            defer->latch = keep;
             ZT_LAUNCH_CHECK();
             return ZT_OK;
         }
@@ -1561,12 +1561,12 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         od.valid = true; od.form = 1; od.gx = 0;
         od.memory = memory_dev; od.num_nodes = num_nodes; od.nodes = nodes_dev; od.N = N; od.D = D; od.M = M; od.hg = hg;
         od.H = H; od.S = S; od.fc2_p = fc2t; od.fc2_b = wt->fc2_b; od.fc1s_p = fc1st; od.fc1s_b = wt->fc1s_b; od.fc2s_p = fc2st;
-        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.src_base = 0;
+        od.fc2s_b = wt->fc2s_b; od.out = out_dev; od.status = status_dev; od.latch = nullptr;
         if (defer != nullptr) {
             // the caller launches them beside the GRU update (gru_update_ex) -- or by embed_out_launch
-            const unsigned keep = defer->src_base;
+            int *keep = defer->latch;
             *defer = od;
-            defer->src_base = keep;
+            defer->latch = keep;
             ZT_LAUNCH_CHECK();
             return ZT_OK;
         }

@@ -31,8 +31,9 @@ int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, c
 // are filled (pipeline.hip: the message kernel hands its list of winners over), no compaction of flagged ids
 // The output layers of an embed call, held back (embed_ex: `defer`) so that gru_update_ex can launch them in ONE kernel with the
 // GRU update (k_out_gru, memory_update.hip): the two are independent apart from the memory rows the source path reads --
-// the GRU half waits for those reads before it writes (two counters in its workspace that take turns: a launch counts in one
-// from zero and clears the other for the next; src_base = which one, toggled by gru_update_ex).
+// the GRU half waits for those reads before it writes (a gate in the GRU workspace whose whole state is device memory: a
+// count of source-path units that have their rows and a count of participants that have left; the last one out zeroes both, so
+// every launch finds them at zero whatever the host did in between; the wait is bounded and reports to `status` / `latch`).
 struct embed_out_deferred {
     bool valid;
     const float *memory;
@@ -44,7 +45,7 @@ struct embed_out_deferred {
     const float *H, *S, *fc2_p, *fc2_b, *fc1s_p, *fc1s_b, *fc2s_p, *fc2s_b;
     float *out;
     int *status;
-    unsigned src_base;
+    int *latch;            // host-mapped word a gate wait that gives up writes ZT_ERR_TIMEOUT to (or NULL); kept across embed_ex calls
 };
 int embed_out_launch(const embed_out_deferred &d, void *stream);           // aggregate.hip: the held-back layers as a kernel of their own
 int gru_update_ex(float *memory_dev, float *last_update_dev, const float *messages_dev, const float *msg_ts_dev,

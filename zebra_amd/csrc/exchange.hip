@@ -100,6 +100,9 @@ struct zt_exchange {
 
 namespace {
 
+// buffers, communicator, mapping and the handle itself (zt_exchange_destroy; every failing path of zt_exchange_create)
+void release_exchange(zt_exchange *x);
+
 // [id | row of every table] of the rows a rank's GRU update rewrote (k_pack_rows of memory_update.hip, with the ids in a
 // compact array beside the payload on the receiving side)
 __global__ __launch_bounds__(256) void k_xchg_pack(zt_row_tables T, int row_floats, const int *__restrict__ ids,
@@ -176,6 +179,12 @@ extern "C" int zt_exchange_create(zt_exchange **out, const zt_exchange_desc *d)
     }
     zt_exchange *x = new zt_exchange();
     memset(x, 0, sizeof(*x));
+    // every way out of this function but the last releases what has been made so far (round-5 advisor: the error returns
+    // behind the hipMallocs leaked the buffers and the handle)
+    struct Guard {
+        zt_exchange *x;
+        ~Guard() { if (x) release_exchange(x); }
+    } guard{x};
     x->rank = d->rank; x->world = d->world; x->kind = d->transport; x->with_messages = d->with_messages ? 1 : 0;
     x->cap = d->cap_rows;
     x->tables.n = 0;
@@ -190,25 +199,46 @@ extern "C" int zt_exchange_create(zt_exchange **out, const zt_exchange_desc *d)
     ZT_HIP(hipMalloc(&x->recv, (size_t)x->world * x->cap * rowb));
     ZT_HIP(hipMalloc(&x->ids, (size_t)x->world * x->cap * 4));
     if (x->kind == ZT_XCHG_RCCL) {
-        if (rccl() == nullptr) { set_error("zt_exchange_create: no RCCL in this process (librccl.so.1 not found)"); delete x; return ZT_ERR_UNSUPPORTED; }
+        if (rccl() == nullptr) { set_error("zt_exchange_create: no RCCL in this process (librccl.so.1 not found)"); return ZT_ERR_UNSUPPORTED; }
         ncclUniqueId id;
         memcpy(&id, d->unique_id, NCCL_UNIQUE_ID_BYTES);
         ZT_NCCL(rccl()->CommInitRank(&x->comm, x->world, id, x->rank));         // (collective: every rank calls it)
     } else {
+        // Rank 0 MAKES the segment -- an old one of that name (a killed run: only rank 0's destroy unlinks) is removed first,
+        // the new one is created exclusively and starts as zeros (ftruncate of a fresh object), so no counter of an earlier
+        // run can be mistaken for this run's steps -- and the other ranks only ever OPEN it: the caller orders them behind
+        // rank 0's create (TGN.enable_exchange: a barrier); a rank that comes early waits for the name to appear.
         snprintf(x->shm_name, sizeof(x->shm_name), "/%s", d->shm_name[0] == '/' ? d->shm_name + 1 : d->shm_name);
         x->half_bytes = (size_t)x->world * x->cap * rowb;
         x->shm_bytes = sizeof(ShmHeader) + 2 * x->half_bytes;
-        const int fd = shm_open(x->shm_name, O_CREAT | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)x->shm_bytes) != 0) {
-            if (fd >= 0) close(fd);
+        int fd = -1;
+        if (x->rank == 0) {
+            (void)shm_unlink(x->shm_name);
+            fd = shm_open(x->shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd >= 0 && ftruncate(fd, (off_t)x->shm_bytes) != 0) { close(fd); fd = -1; (void)shm_unlink(x->shm_name); }
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                fd = shm_open(x->shm_name, O_RDWR, 0600);
+                if (fd >= 0) {
+                    struct stat sb;
+                    if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= x->shm_bytes) break;      // (rank 0 has sized it)
+                    close(fd);
+                    fd = -1;
+                } else if (errno != ENOENT) break;
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) { errno = ETIMEDOUT; break; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+        }
+        if (fd < 0) {
             set_error("zt_exchange_create: shared-memory segment %s: %s", x->shm_name, strerror(errno));
-            delete x;
             return ZT_ERR_ARG;
         }
         x->shm = mmap(nullptr, x->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
-        if (x->shm == MAP_FAILED) { set_error("zt_exchange_create: mmap failed"); x->shm = nullptr; delete x; return ZT_ERR_ARG; }
+        if (x->shm == MAP_FAILED) { set_error("zt_exchange_create: mmap failed"); x->shm = nullptr; return ZT_ERR_ARG; }
     }
+    guard.x = nullptr;
     *out = x;
     return ZT_OK;
 }
@@ -222,17 +252,26 @@ extern "C" int zt_exchange_set_tables(zt_exchange *x, float *memory, float *last
     return ZT_OK;
 }
 
-extern "C" int zt_exchange_destroy(zt_exchange *x)
+namespace {
+void release_exchange(zt_exchange *x)
 {
-    if (!x) return ZT_OK;
-    (void)hipDeviceSynchronize();
     if (x->comm != nullptr && rccl() != nullptr) (void)rccl()->CommDestroy(x->comm);
     if (x->shm != nullptr) {
         (void)munmap(x->shm, x->shm_bytes);
         if (x->rank == 0) (void)shm_unlink(x->shm_name);
     }
-    (void)hipFree(x->send); (void)hipFree(x->recv); (void)hipFree(x->ids);
+    if (x->send) (void)hipFree(x->send);
+    if (x->recv) (void)hipFree(x->recv);
+    if (x->ids) (void)hipFree(x->ids);
     delete x;
+}
+}  // namespace
+
+extern "C" int zt_exchange_destroy(zt_exchange *x)
+{
+    if (!x) return ZT_OK;
+    (void)hipDeviceSynchronize();
+    release_exchange(x);
     return ZT_OK;
 }
 

@@ -196,7 +196,52 @@ __global__ void k_select_flagged(const int *__restrict__ ids, long long n_ids, c
 constexpr int GRU_NTW = 1;     // hidden N-tiles per wave; 8 waves -> D <= 128
 constexpr int GRU_WAVES = 8;
 constexpr int GRU_CH = 6;      // k-steps of weight fragments in flight
-constexpr int GRU_SRC_WORD = 32; // words 32, 33 of the workspace's counter block count source-path workgroups (k_out_gru), launch by launch in turn
+constexpr int GRU_SRC_WORD = 32; // words 32, 33 of the workspace's counter block: the gate of k_out_gru / k_out_gru2 (SrcGate)
+
+// The gate between the two halves of k_out_gru / k_out_gru2.  The output layers' source path reads memory[nodes] as the
+// previous update left it and the GRU half rewrites rows of the same nodes: a source-path unit (a workgroup of k_out_gru, a
+// wave of k_out_gru2) adds 1 to word[0] once its rows have arrived, and a GRU workgroup waits for word[0] == target before its
+// first write to the table.  ALL of the protocol's state is these two words of the GRU workspace (round-5 advisor: a parity
+// kept on the host could disagree with them -- a second pipeline or a direct zt_gru_update on the same workspace, a workspace
+// re-packed in between): every participant -- source-path unit or GRU workgroup -- adds 1 to word[1] when it is through, and
+// the last one out zeroes both words, so a launch always finds them at zero.  Launches that share a workspace must be
+// ordered by a stream, as for the row list beside these words.  The wait is bounded like every wait of k_stream
+// (tppr_rows.hpp): after GATE_TICKS it writes ZT_ERR_TIMEOUT to the caller's status word and, where the pipeline gave one,
+// to a host-mapped latch that fails the next step call -- and the workgroup leaves the table untouched.
+constexpr long long GATE_TICKS = 400000000ll;     // 4 s of the 100 MHz wall clock
+struct SrcGate {
+    int *word;
+    unsigned target, participants;
+    int *status, *latch;
+};
+
+// by ONE thread of a GRU workgroup; false: gave up (reported)
+__device__ __forceinline__ bool gate_wait(const SrcGate &g)
+{
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (ld_agent(g.word) < (int)g.target) {          // (signed: a word that is not a count of this launch's units never opens the gate)
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 2047u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > GATE_TICKS) {
+                atomicExch(g.status, ZT_ERR_TIMEOUT);
+                if (g.latch != nullptr) __hip_atomic_store(g.latch, (int)ZT_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// by the thread that added to / waited for word[0], once per participant, when its unit is through
+__device__ __forceinline__ void gate_leave(const SrcGate &g)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (this unit's add to word[0] has reached L2 before its add to word[1] can)
+    const unsigned before = (unsigned)atomicAdd(g.word + 1, 1);
+    if (before + 1u == g.participants) { st_agent(g.word, 0); st_agent(g.word + 1, 0); }
+}
 
 // Zero-padded gate-major copy in FRAGMENT order: W[3D][K] -> Wp[3][Dp / 16][Kp / 16][64 lanes][4]: the 16 x 16 block (N-tile
 // nt, k-chunk kc) of a gate as the MFMA's lanes hold it -- lane (r16, g4) has W[16 nt + r16][16 kc + 4 g4 .. + 3] -- so that a
@@ -223,10 +268,10 @@ struct GruArgs {
     int cap;
 };
 
-// bid = the workgroup's 16 MT-row tile.  src_read != nullptr (k_out_gru): before a row of the memory table is written, the
-// counter there must have reached src_target -- every source-path workgroup of the output layers has its rows in LDS.
+// bid = the workgroup's 16 MT-row tile.  gate != nullptr (k_out_gru): before a row of the memory table is written every
+// source-path workgroup of the output layers must have its rows in LDS (SrcGate; LDS: one word more behind the node ids).
 template <int MT>
-__device__ __forceinline__ void gru_body(const GruArgs &G, char *smem, int bid, const int *src_read, unsigned src_target)
+__device__ __forceinline__ void gru_body(const GruArgs &G, char *smem, int bid, const SrcGate *gate)
 {
     float *memory = G.memory, *last_update = G.last_update;
     const float *__restrict__ messages = G.messages, *__restrict__ msg_ts = G.msg_ts;
@@ -347,9 +392,10 @@ __device__ __forceinline__ void gru_body(const GruArgs &G, char *smem, int bid, 
     part(Whh_p, Hp, Xp, true);      // memory part:  gh = W_hh h
     // (the new rows go back into the tile for the projection below: every wave must be done READING the old ones -- the
     //  memory columns are the K operand of everybody's W_hh product)
-    if (src_read != nullptr) {
-        if (tid == 0) while ((int)((unsigned)ld_agent(src_read) - src_target) < 0) __builtin_amdgcn_s_sleep(2);
+    if (gate != nullptr) {
+        if (tid == 0) rid[MT * 16] = gate_wait(*gate) ? 1 : 0;
         __syncthreads();
+        if (rid[MT * 16] == 0) return;                 // (gave up: reported; the table keeps its rows)
     } else if (P != nullptr) __syncthreads();
     // gates (torch.nn.GRUCell): r,z = sigmoid(gi+gh); n = tanh(gi_n + r*gh_n); h' = (1-z)*n + z*h
 #pragma unroll
@@ -413,7 +459,7 @@ template <int MT>
 __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(GruArgs G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gru_body<MT>(G, smem, blockIdx.x, nullptr, 0u);
+    gru_body<MT>(G, smem, blockIdx.x, nullptr);
 }
 
 // The output layers and the GRU update in ONE launch (round 5).  The two kernels are independent but for the memory rows the
@@ -423,21 +469,19 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void k_gru(GruArgs G)
 // workgroup that has no compute unit), then the GRU tiles (the longest chains: not behind 200 short workgroups' dispatch),
 // then the neighbour paths.
 template <int HG>
-__global__ __launch_bounds__(64 * GRU_WAVES) void k_out_gru(EmbedOutArgs E, int out_tiles, int gru_wgs, GruArgs G, int *src_read, unsigned src_target,
-                                                           int *src_next)
+__global__ __launch_bounds__(64 * GRU_WAVES) void k_out_gru(EmbedOutArgs E, int out_tiles, int gru_wgs, GruArgs G, SrcGate gate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
-    // (two counters take turns from launch to launch: this launch counts in *src_read from 0 and zeroes the other one for the
-    //  next -- the previous launch, the last to look at it, is over; no value has to be carried on the host)
-    if (bid == 0 && threadIdx.x == 0) st_agent(src_next, 0);
     if (bid >= out_tiles && bid < out_tiles + gru_wgs) {
-        gru_body<1>(G, smem, bid - out_tiles, src_read, src_target);
+        gru_body<1>(G, smem, bid - out_tiles, &gate);
+        if (threadIdx.x == 0) gate_leave(gate);              // (thread 0 is the one that waited, if the tile had rows at all)
         return;
     }
     if (threadIdx.x >= AGG_THREADS) return;                // (the body is written for four waves; a finished wave leaves the barriers)
     const int q = bid < out_tiles ? bid : bid - gru_wgs;     // tile + out_tiles * path
-    embed_out_body<HG>(E, smem, q % out_tiles, q / out_tiles, src_read);
+    embed_out_body<HG>(E, smem, q % out_tiles, q / out_tiles, gate.word);
+    if (bid < out_tiles && threadIdx.x == 0) gate_leave(gate);   // (a source-path workgroup: thread 0 made its add to word[0])
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -472,9 +516,9 @@ struct GruSplitArgs {
     float *hnew;
 };
 
-// (bx, by) = (16-row tile, N-tile).  src_read != nullptr (k_out_gru2): the tile's last workgroup waits for the counter there
-// to reach src_target before it commits the rows to the memory table.
-__device__ __forceinline__ void gru_split_body(const GruSplitArgs &GS, char *smem, int bx, int by, const int *src_read, unsigned src_target)
+// (bx, by) = (16-row tile, N-tile).  gate != nullptr (k_out_gru2): the tile's last workgroup waits at the gate (SrcGate)
+// before it commits the rows to the memory table.
+__device__ __forceinline__ void gru_split_body(const GruSplitArgs &GS, char *smem, int bx, int by, const SrcGate *gate)
 {
     const GruArgs &G = GS.g;
     float *memory = G.memory, *last_update = G.last_update;
@@ -592,9 +636,10 @@ __device__ __forceinline__ void gru_split_body(const GruSplitArgs &GS, char *sme
     __syncthreads();
     GSTAMP(6);
     if (rid[16] == 0) return;
-    if (src_read != nullptr) {                                           // (k_out_gru2: the output layers' source path has read its rows)
-        if (tid == 0) while ((int)((unsigned)ld_agent(src_read) - src_target) < 0) __builtin_amdgcn_s_sleep(2);
+    if (gate != nullptr) {                                               // (k_out_gru2: the output layers' source path has read its rows)
+        if (tid == 0) rid[17] = gate_wait(*gate) ? 1 : 0;
         __syncthreads();
+        if (rid[17] == 0) return;                                        // (gave up: reported; the table keeps its rows)
     }
     // ---- every N-tile of these 16 rows has been computed from the OLD rows: new rows -> memory table, -> projected table
     // (read with sc1 loads: served by L2, where the other workgroups' drained sc1 stores are) ----
@@ -641,30 +686,32 @@ __device__ __forceinline__ void gru_split_body(const GruSplitArgs &GS, char *sme
 __global__ __launch_bounds__(64 * GS_WAVES) void k_gru_split(GruSplitArgs GS)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    gru_split_body(GS, smem, blockIdx.x, blockIdx.y, nullptr, 0u);
+    gru_split_body(GS, smem, blockIdx.x, blockIdx.y, nullptr);
 }
 
 // k_out_gru for SMALL batches: the latency-organised output layers (k_embed_out2: one wave per (tiles, path, N-tile), four of
 // them to a workgroup here) beside k_gru_split.  Workgroup order as in k_out_gru: the source-path waves first (n_src_wgs
 // workgroups), the GRU's (tile, N-tile) workgroups, the neighbour paths.
 template <int NT, int HG>
-__global__ __launch_bounds__(64 * GS_WAVES) void k_out_gru2(EmbedOutArgs E, int gx, int n_src_wgs, int gru_tiles, GruSplitArgs GS, int *src_read,
-                                                            unsigned src_target, int *src_next)
+__global__ __launch_bounds__(64 * GS_WAVES) void k_out_gru2(EmbedOutArgs E, int gx, int n_src_wgs, int gru_tiles, GruSplitArgs GS, SrcGate gate)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (bid == 0 && threadIdx.x == 0) st_agent(src_next, 0);          // (see k_out_gru)
     const int gru_wgs = gru_tiles * NT;
     if (bid >= n_src_wgs && bid < n_src_wgs + gru_wgs) {
         const int g = bid - n_src_wgs;
-        gru_split_body(GS, smem, g % gru_tiles, g / gru_tiles, src_read, src_target);
+        gru_split_body(GS, smem, g % gru_tiles, g / gru_tiles, &gate);
+        if (threadIdx.x == 0) gate_leave(gate);              // (every GRU workgroup is a participant, whether it waited or not)
         return;
     }
     float *Y = reinterpret_cast<float *>(smem) + wave * (16 * (NT * 16 + 4));
     const int per_path = gx * NT;                          // waves per path: (tile stride gx) x (N-tile)
     if (bid < n_src_wgs) {
         const int v = 4 * bid + wave;
-        if (v < per_path) embed_out2_body<NT, HG>(E, Y, lane, v % gx, gx, 0, v / gx, src_read);
+        if (v < per_path) {
+            embed_out2_body<NT, HG>(E, Y, lane, v % gx, gx, 0, v / gx, gate.word);
+            if (lane == 0) gate_leave(gate);                 // (a source-path wave: lane 0 made its add to word[0])
+        }
     } else {
         const int v = 4 * (bid - n_src_wgs - gru_wgs) + wave;
         if (v < per_path * E.M) { const int r = v % per_path; embed_out2_body<NT, HG>(E, Y, lane, r % gx, gx, 1 + v / per_path, r / gx, nullptr); }
@@ -896,7 +943,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
         k_pack_gates<<<(3 * p.Hp * p.Xp + 255) / 256, 256, 0, s>>>(wt->w_ih, D, msg_dim, wih, p.Hp, p.Xp);
         k_pack_gates<<<(3 * p.Hp * p.Hp + 255) / 256, 256, 0, s>>>(wt->w_hh, D, D, whh, p.Hp, p.Hp);
         ZT_HIP(hipMemsetAsync(ws + p.off_tiles, 0, (size_t)GP_TILE_COUNTERS * 4, s));
-        ZT_HIP(hipMemsetAsync(cnt + GRU_SRC_WORD, 0, 2 * sizeof(int), s));   // k_out_gru's two "source rows read" counters
+        ZT_HIP(hipMemsetAsync(cnt + GRU_SRC_WORD, 0, 2 * sizeof(int), s));   // the gate's two words (a fresh workspace; afterwards every launch leaves them at zero)
     }
     // Two organisations of the same update (zt_set_kernel_choice(ZT_CHOICE_GRU, ..) pins one; tests hold them against each
     // other and torch's GRUCell):
@@ -930,9 +977,9 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
             const int per_path = d.gx * NTg, n_src_wgs = (per_path + 3) / 4, n_nb_wgs = (per_path * d.M + 3) / 4;
             size_t lds_f = (size_t)4 * 16 * (NTg * 16 + 4) * 4;
             if (lds_f < lds2) lds_f = lds2;
-            const int par = (int)(d.src_base & 1u);                      // (the counter of this launch; the kernel zeroes the other)
-            int *src_read = cnt + GRU_SRC_WORD + par, *src_next = cnt + GRU_SRC_WORD + (par ^ 1);
-            const unsigned target = (unsigned)per_path;
+            SrcGate gate;
+            gate.word = cnt + GRU_SRC_WORD; gate.target = (unsigned)per_path; gate.participants = (unsigned)(per_path + gru_tiles * NTg);
+            gate.status = d.status; gate.latch = d.latch;
             const unsigned grid = (unsigned)(n_src_wgs + gru_tiles * NTg + n_nb_wgs);
 #define ZT_OG2(NTV, HGV) do {                                                                                                   \
                 static size_t attr_og2 = 0;                                                                                     \
@@ -941,12 +988,11 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));                       \
                     attr_og2 = lds_f;                                                                                           \
                 }                                                                                                               \
-                k_out_gru2<NTV, HGV><<<grid, 64 * GS_WAVES, lds_f, s>>>(E, d.gx, n_src_wgs, gru_tiles, GS, src_read, target, src_next); \
+                k_out_gru2<NTV, HGV><<<grid, 64 * GS_WAVES, lds_f, s>>>(E, d.gx, n_src_wgs, gru_tiles, GS, gate);                 \
             } while (0)
             if (NTg == 7) { if (d.hg == 1) ZT_OG2(7, 1); else if (d.hg == 5) ZT_OG2(7, 5); else ZT_OG2(7, 10); }
             else          { if (d.hg == 1) ZT_OG2(8, 1); else if (d.hg == 5) ZT_OG2(8, 5); else ZT_OG2(8, 10); }
 #undef ZT_OG2
-            fuse->src_base = (unsigned)(par ^ 1);
             fuse->valid = false;
         } else {
             // (held-back output layers first: their source path reads the rows this kernel rewrites)
@@ -954,7 +1000,7 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
             k_gru_split<<<dim3((unsigned)gru_tiles, (unsigned)NTg), 64 * GS_WAVES, lds2, s>>>(GS);
         }
     } else {
-        const size_t lds = (size_t)16 * p.lda * 4 + 16 * 4;
+        const size_t lds = (size_t)16 * p.lda * 4 + 32 * 4;              // A tile + node ids + the gate's verdict (k_out_gru)
         static size_t attr_lds = 0;
         if (lds > 48 * 1024 && lds > attr_lds) {
             ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gru<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -983,14 +1029,13 @@ int zt::gru_update_ex(float *memory_dev, float *last_update_dev, const float *me
                 ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
                 attr_f[hi] = lds_f;
             }
-            const int par = (int)(d.src_base & 1u);                      // (the counter of this launch; the kernel zeroes the other)
-            int *src_read = cnt + GRU_SRC_WORD + par, *src_next = cnt + GRU_SRC_WORD + (par ^ 1);
-            const unsigned target = (unsigned)out_tiles;
+            SrcGate gate;
+            gate.word = cnt + GRU_SRC_WORD; gate.target = (unsigned)out_tiles; gate.participants = (unsigned)out_tiles + gru_wgs;
+            gate.status = d.status; gate.latch = d.latch;
             const unsigned grid = (unsigned)n_out + gru_wgs;
-            if (d.hg == 1) k_out_gru<1><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
-            else if (d.hg == 5) k_out_gru<5><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
-            else k_out_gru<10><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, src_read, target, src_next);
-            fuse->src_base = (unsigned)(par ^ 1);
+            if (d.hg == 1) k_out_gru<1><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, gate);
+            else if (d.hg == 5) k_out_gru<5><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, gate);
+            else k_out_gru<10><<<grid, 64 * GRU_WAVES, lds_f, s>>>(E, out_tiles, (int)gru_wgs, G, gate);
             fuse->valid = false;                       // (launched)
         } else {
             if (fuse != nullptr && fuse->valid) { const int rc = zt::embed_out_launch(*fuse, s); fuse->valid = false; if (rc != ZT_OK) return rc; }

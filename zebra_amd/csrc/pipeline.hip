@@ -78,6 +78,10 @@ struct zt_pipeline {
     int score_n;               // scorings enqueued so far (parity = which half / which event)
     int64_t score_B;           // batch size of the last one
     zt_exchange *xchg;         // zt_pipeline_set_exchange: the row exchange of a multi-GPU run at the end of every step (or NULL)
+    // Failure latch in host-mapped memory (as zt_tppr's): a bounded in-kernel wait of the step's own kernels that gives up
+    // (the gate of k_out_gru / k_out_gru2, memory_update.hip) writes ZT_ERR_TIMEOUT here at system scope, and the NEXT step
+    // call fails with it -- no synchronisation, and a caller that never reads the status word still hears of it.
+    int *latch_host, *latch_dev;
 };
 
 namespace {
@@ -289,6 +293,10 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipStreamCreateWithFlags(&p->msg_s, hipStreamNonBlocking));
     }
     if (desc->tppr != nullptr) zt::tppr_hint_cus(desc->tppr, p->side);      // the first plans are made for THIS stream's CUs
+    ZT_HIP(hipHostMalloc(reinterpret_cast<void **>(&p->latch_host), sizeof(int), hipHostMallocMapped));
+    *p->latch_host = 0;
+    ZT_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&p->latch_dev), p->latch_host, 0));
+    p->out_gru.latch = p->latch_dev;
     ZT_HIP(hipEventCreateWithFlags(&p->step_begin, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->msgs_done, hipEventDisableTiming | zt::sync_event_flags()));
     ZT_HIP(hipEventCreateWithFlags(&p->scored[0], hipEventDisableTiming | zt::sync_event_flags()));
@@ -328,6 +336,7 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     (void)hipStreamDestroy(p->msg_s);
     (void)hipEventDestroy(p->scored[0]); (void)hipEventDestroy(p->scored[1]);
     (void)hipEventDestroy(p->entry); (void)hipEventDestroy(p->step_begin); (void)hipEventDestroy(p->msgs_done);
+    if (p->latch_host) (void)hipHostFree(p->latch_host);
     delete p;
     return ZT_OK;
 }
@@ -415,6 +424,13 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         !out_emb_dev || row_lo < 0 || row_hi > 3 * cur->B || row_lo > row_hi || pos_lo < 0 || pos_hi > 2 * cur->B || pos_lo > pos_hi) {
         set_error("zt_pipeline_step: bad argument");
         return ZT_ERR_ARG;
+    }
+    if (const int st = *reinterpret_cast<volatile int *>(p->latch_host)) {
+        // a kernel of an earlier step gave up a bounded wait: its results are void.  Reported once, then cleared.
+        *reinterpret_cast<volatile int *>(p->latch_host) = 0;
+        set_error("zt_pipeline_step: a kernel of an earlier step gave up a bounded wait (status %d: the gate between the output "
+                  "layers and the GRU update, memory_update.hip); that step's memory update is incomplete", st);
+        return st;
     }
     const zt_pipeline_desc &d = p->d;
     const int64_t B = cur->B, n_rows = row_hi - row_lo;

@@ -125,6 +125,13 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
     const double qt = q_ts[qi];
     if (qn < 0 || qn >= num_nodes) {
         if (lane == 0) atomicExch(status, ZT_ERR_RANGE);
+        // (zero_empty: nobody cleared the slot -- the row would keep the previous group's neighbours and the aggregation of
+        //  this step, whose caller may never look at the status word, would consume them: an empty row instead)
+        if (zero_empty && lane < k)
+            for (int m = 0; m < M; ++m) {
+                const long long ob = (long long)m * out_stride + qi * k;
+                out_nodes[ob + lane] = 0; out_eidx[ob + lane] = 0; out_w[ob + lane] = 0.f; out_dt[ob + lane] = 0.f;
+            }
         return;
     }
 

@@ -172,7 +172,8 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
                     }
                 }
             }
-            chain_stat(h.ctl, lane, ST_SINGLE);
+            if (MODE != 0) chain_stat(h.ctl, lane, ST_SINGLE);      // (statistics of the alternative chain modes only: the default kernel's hot path
+                                                                    //  carries no atomic to a shared word that nobody reads -- round-5 advisor)
             const int pe = t > 0 ? ZT_U(ch_edge[t - 1]) : -1, ne = t + 1 < len ? ZT_U(ch_edge[t + 1]) : -1, ce = ZT_U(ch_edge[t]);
             HopRec rec;
             rec.partner = ZT_U(ch_partner[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pchain = ZT_U(ch_pch[t]);

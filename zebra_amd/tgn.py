@@ -246,7 +246,16 @@ class TGN(torch.nn.Module):
                                                          m.timestamps.data_ptr())
         d.D, d.msg_dim = self.memory_dimension, m.messages.shape[1]
         h = C.c_void_p()
-        check(lib().zt_exchange_create(C.byref(h), C.byref(d)), "zt_exchange_create")
+        if transport == "shm" and world > 1 and dist.is_available() and dist.is_initialized():
+            # rank 0 makes the segment (an old one of that name is removed first, the new one starts as zeros); the others
+            # open it once it exists: never a segment a killed run left behind (csrc/exchange.hip)
+            if rank == 0:
+                check(lib().zt_exchange_create(C.byref(h), C.byref(d)), "zt_exchange_create")
+            dist.barrier(group=group)
+            if rank != 0:
+                check(lib().zt_exchange_create(C.byref(h), C.byref(d)), "zt_exchange_create")
+        else:
+            check(lib().zt_exchange_create(C.byref(h), C.byref(d)), "zt_exchange_create")
         self._xchg = h
         self._xchg_args = (int(rank), int(world), bool(with_messages))
         check(lib().zt_pipeline_set_exchange(self._pipe, h), "zt_pipeline_set_exchange")
@@ -489,6 +498,9 @@ class TGN(torch.nn.Module):
                 self._status.zero_()
                 if em._status is not None:
                     em._status.zero_()
+                if st == _capi.ZT_ERR_TIMEOUT:
+                    raise _capi.ZebraError("a kernel of the step gave up a bounded in-kernel wait (status %d): the step's memory "
+                                           "update is incomplete" % st)
                 raise IndexError("node / edge id out of range (status %d)" % st)
         return emb
 
