@@ -474,6 +474,14 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         ea, eb = prefill * bs, (prefill + cpu_nb) * bs
         ids_a = np.unique(np.concatenate([src[ea:eb], dst[ea:eb], neg[ea:eb]])).astype(np.int64)
         after = snapshot_state(tgn, wl, ids_a)
+        if spun:                                   # (the export idled the GPU again: same throw-away work before the next region)
+            xa = torch.randn((4096, 4096), device=device)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < 0.35:
+                for _ in range(20):
+                    xa = torch.mm(xa, xa).clamp_(-1.0, 1.0)
+                torch.cuda.synchronize()
+            del xa
     # ---- the second region: the same step + the link scorer (sharded runs score nothing: a rank holds a row shard) ----
     with_scorer = None
     if scored:
@@ -583,6 +591,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     pmc = {}
     pmc_edges = None
     pmc_source = None
+    pmc_stale = None
     if world == 1:
         for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             pj = os.path.join(ROOT, "profiles", rnd, "%s_pmc_summary.json" % name)
@@ -594,6 +603,13 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                 # size is scaled by the edges per launch (the kernel's traffic is per edge -- rows read and written, tag
                 # polls), and the roofline note says so
                 on = summ.get("measured_on") or {}
+                # the counters belong to a LIBRARY: a summary taken on other kernel sources than the ones this run was built
+                # from is quoted all the same (the launch shapes and byte counts move little) but flagged
+                try:
+                    from zebra_amd.build import csrc_sha16
+                    pmc_stale = on.get("csrc_sha16") != csrc_sha16()
+                except Exception:
+                    pmc_stale = None
                 pmc_edges = on.get("edges_per_k_stream_launch")
                 if on.get("tppr_launch_group") not in (None, group) and not pmc_edges:
                     pmc = {kk: vv for kk, vv in pmc.items() if kk != "tppr_stream"}
@@ -629,7 +645,9 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         elif kn == "pruned_topk":
             # ONE launch serves all M models: the CSR tails are read once, every model writes its output rows
             byts = (ab["p1"] - 48 * k + M * 48 * k) * bs / shard
-            note = "CSR tail reads (once for all models) + output rows per query and model (search probes not counted)"
+            note = ("CSR tail reads (once for all models) + output rows per query and model (search probes not counted); the kernel is "
+                    "ONE wavefront per query row and the whole launch is resident at once (3 B waves on the chip), so its time is a "
+                    "wave's chain of DEPENDENT memory round trips + its selection: latency_model")
         elif kn == "gru_update":
             byts = 2 * (4 * (2 * 100 + F + 100) + 8 * 100 + 4) * bs / shard
             note = None
@@ -641,6 +659,34 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         # HBM: `achieved` / `peak` / `frac` are still its algorithmic bytes against the HBM peak, for the record
         out_r = dict(kernel=kn, bound="latency" if kn == "tppr_stream" else "hbm", achieved=ach, peak=HBM_PEAK_GBS,
                      unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, traffic_source=pmc_source if tr is not None else None, note=note)
+        if kn == "pruned_topk":
+            # a query row's dependent chain (csrc/tppr_prune.hip): per level of the walk indptr -> the P-ary search of every
+            # frontier entry (P = 64 lanes for the single entry of level 0, 8 per entry for a full level: ceil(log_P(degree + 1))
+            # rounds of probes, each a round trip) -> the tails (one round of coalesced loads); degrees from the run's own
+            # adjacency: level 0 the batch's query nodes, level 1 their neighbours (degree-weighted: a neighbour is drawn by
+            # an edge).  One round trip = an Infinity-Cache hit (227 ns, MI355X_MICROARCH.md: the CSR of C4 is 48 MB -- beyond
+            # the 4 MB L2 of an XCD, inside the 256 MB cache).  The selection (de-duplication in the reference's summation
+            # order + the replayed argsort: compute, 26 us alone -- tools/exp/prune_phases.py) is given beside the chain.
+            tb0 = prefill + warmup
+            deg = np.bincount(np.concatenate([src, dst]), minlength=wl["n_nodes"] + 2).astype(np.float64)
+            qn = np.concatenate([src[tb0 * bs:(tb0 + steps) * bs], dst[tb0 * bs:(tb0 + steps) * bs], neg[tb0 * bs:(tb0 + steps) * bs]])
+            lg = lambda d_, P: np.ceil(np.log(np.maximum(d_, 1.0) + 1.0) / np.log(P))
+            r0 = float(lg(deg[qn], 64.0).max())                       # (the launch ends with its slowest wave: the largest degree)
+            r0_mean = float(lg(deg[qn], 64.0).mean())
+            dn = deg[deg > 0]
+            r1 = float(lg(dn, 8.0).max())
+            r1_mean = float((lg(dn, 8.0) * dn).sum() / dn.sum())
+            depth_ = wl.get("depth", 2)
+            trips_mean = (1 + r0_mean + 1) + (depth_ - 1) * (1 + r1_mean + 1)
+            trips_max = (1 + r0 + 1) + (depth_ - 1) * (1 + r1 + 1)
+            rt_ns, sel_us = 227.0, 26.0
+            kt_us = kern[kn]["avg_us"]
+            out_r["latency_model"] = dict(
+                dependent_round_trips_mean=trips_mean, dependent_round_trips_slowest_wave=trips_max, ns_per_round_trip=rt_ns,
+                memory_chain_floor_us=trips_max * rt_ns / 1e3, selection_us_alone=sel_us,
+                floor_us=trips_max * rt_ns / 1e3 + sel_us, kernel_us=kt_us, frac=(trips_max * rt_ns / 1e3 + sel_us) / kt_us,
+                note="floor = (dependent round trips of the slowest wave: per level indptr + ceil(log_P(degree + 1)) search rounds + the "
+                     "tails) x an Infinity-Cache hit + the selection phase measured alone; frac = floor / kernel time")
         if kn == "tppr_stream":
             out_r["edges_per_launch"] = per_launch
             # the yardstick that fits: the longest chain of edges through ONE node in a launch (every edge that touches
@@ -668,6 +714,9 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         # the largest THROUGHPUT kernel as well, when the dominant one is the latency-bound T-PPR chain
         if dom != "fc1_agg" and "fc1_agg" in kern:
             roof2 = kernel_roofline("fc1_agg")
+        for r_ in (roof, roof2):
+            if r_ is not None and r_.get("traffic") is not None:
+                r_["traffic_stale"] = pmc_stale       # True: the summary's kernel sources are not this run's (csrc_sha16)
 
     cpu = None
     if cpu_nb:
@@ -842,7 +891,8 @@ def main():
     res = {}
     for name in [x for x in legs.split(",") if x and x != "none"]:
         # the other BASELINE configs, short: the driver's one run times all four (CPU legs bounded to ~2-4 s each)
-        leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 8 * 600, "c4": 6 * 1000, "c5": 8 * 4096}[name]
+        # (10 warm-up batches come first in the sample: 16 / 14 / 14 batches leave 6 / 4 / 4 TIMED ones for parity_in_run)
+        leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 14 * 600, "c4": 14 * 1000, "c5": 14 * 4096}[name]
         r = run_workload(a, name, a.leg_steps, 10, world, rank, device, False, leg_cpu)
         if r is not None:
             res[name] = {kk: r[kk] for kk in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "host_enqueue_ms_per_step", "exchange_us_per_step", "chain_hops", "chain_bound_ms_per_step", "with_scorer", "parity_in_run",

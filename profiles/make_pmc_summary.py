@@ -14,7 +14,10 @@ launch -- so that bench.py merges its `traffic` only into a line of the same lau
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 
 def per_kernel(path, counter, last):
@@ -25,6 +28,14 @@ def per_kernel(path, counter, last):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         agg[name].append(float(r["Counter_Value"]))
     return {k: sum(v[-last:]) / len(v[-last:]) for k, v in agg.items()}
+
+
+def _csrc_sha():
+    try:
+        from zebra_amd.build import csrc_sha16
+        return csrc_sha16()
+    except Exception:
+        return None
 
 
 def main():
@@ -38,7 +49,7 @@ def main():
             cfg = d.get("config", {})
             out["measured_on"] = {"commit": sys.argv[6] if len(sys.argv) > 6 else None, "workload_line": cfg.get("workload"),
                                   "tppr_launch_group": cfg.get("tppr_launch_group"), "tppr_cus": cfg.get("tppr_cus"),
-                                  "steps": d.get("steps"),
+                                  "steps": d.get("steps"), "csrc_sha16": _csrc_sha(),
                                   "edges_per_k_stream_launch": (cfg.get("tppr_launch_group") or 1) * (cfg.get("global_batch") or 0)}
     # kernel-name prefix -> bench.py's name (template arguments vary with the workload)
     prefixes = [("k_stream", "tppr_stream"), ("k_fc1_agg_reg", "fc1_agg"), ("k_fc1_agg_wide", "fc1_agg"), ("k_fc1_agg_d100", "fc1_agg"),

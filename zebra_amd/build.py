@@ -38,6 +38,19 @@ HOOKS_LIB = os.path.join(LIBDIR, "libzebra_amd_testhooks.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, *.hpp, *.h, names and contents): what a profile
+    summary under profiles/ was measured on, and what bench.py holds it against before it quotes the summary's traffic."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            hsh.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
