@@ -786,6 +786,124 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     return out
 
 
+def run_train_workload(a, name, steps, warmup, device):
+    """The TRAINING step of workload `name` (streaming strategy): train.py:195-215 -- compute_edge_probabilities(train=True)
+    through the drop-in's reference surface (numpy batches in, as train.py hands them over), BCE on the positive and negative
+    probabilities, backward through the fused HIP kernels (aggregate_bwd.hip, train_ops.hip), Adam step, dropout on -- timed
+    over `steps` batches after `warmup`, from a state the first 10 % of the stream has filled (eval steps through the native
+    pipeline: rows full, memory warm).  Beside it the same step on the host: oracle/torch_cpu_train.py (the torch-CPU
+    restatement pinned to the reference's own gradients, T-PPR by the C port on one thread), started from the same warm
+    state.  The one figure of this bench that can be held against a PUBLISHED one."""
+    import torch
+    from zebra_amd import synth
+
+    base = name[:-len("_train")]
+    wl = dict(synth.WORKLOADS[base])
+    bs, k, M, F = wl["bs"], wl["k"], len(wl["alpha"]), wl["F"]
+    prefill = (wl["n_edges"] // 10) // bs
+    n_total = prefill + warmup + steps
+    src, dst, neg, ts, eidx = make_stream(wl, n_total * bs, perm_seed=None if a.perm_seed < 0 else a.perm_seed)
+    n_edge_rows = (wl["n_edges"] if F == 1 else n_total * bs) + 1
+    tgn = build_model(wl, device, n_edge_rows)
+    drop_p = float(tgn.embedding_module.drop.p)
+    # ---- warm state: the first 10 % of the stream as eval steps (native loop), then the pipeline goes ----
+    if prefill:
+        d = [torch.from_numpy(x[:prefill * bs]).to(device) for x in (src, dst, neg, ts, eidx)]
+        tppr_cus, group = synth.pipeline_settings(wl, prefill)
+        tgn.enable_pipeline(tppr_cus=tppr_cus, group=group)
+        bt = [tuple(x[b * bs:(b + 1) * bs] for x in d) for b in range(prefill)]
+        with torch.cuda.stream(tgn.main_stream):
+            tgn.run_device(tgn.prepare_run(bt), look=synth.pipeline_look(group))
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        tgn.enable_pipeline(False)
+        del d, bt
+    e0 = prefill * bs
+    touched = np.unique(np.concatenate([src[:e0], dst[:e0]])) if e0 else np.zeros(0, np.int64)
+    snap = snapshot_state(tgn, wl, touched)
+    weights, time_w = model_weights(tgn)
+    efeat_host = tgn.edge_raw_features.cpu().numpy()
+    tgn.train()
+    opt = torch.optim.Adam(tgn.parameters(), lr=1e-4)                 # train.py:29,150
+    crit = torch.nn.BCELoss()
+    ones, zeros = torch.ones(bs, device=device), torch.zeros(bs, device=device)
+    losses = []
+
+    def step(b):
+        s_, e_ = b * bs, (b + 1) * bs
+        opt.zero_grad()
+        pos, negp = tgn.compute_edge_probabilities(src[s_:e_], dst[s_:e_], neg[s_:e_], ts[s_:e_], eidx[s_:e_], 10, True)
+        loss = crit(pos.squeeze(), ones) + crit(negp.squeeze(), zeros)
+        loss.backward()
+        opt.step()
+        tgn.memory.detach_memory()
+        return loss
+
+    for b in range(prefill, prefill + warmup):
+        step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in range(prefill + warmup, n_total):
+        losses.append(step(b))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss_first, loss_last = float(losses[0].item()), float(losses[-1].item())
+    tgn.embedding_module.tppr_finder.check_status()
+    del tgn, opt
+    torch.cuda.empty_cache()
+    sys.stderr.write("[bench] %s: %.3f ms/step (training)\n" % (name, 1e3 * dt / steps))
+    # ---- the same step on the host, from the same warm state ----
+    cpu = None
+    if a.cpu_edges != 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_cpu_train
+        n_thr = min(16, os.cpu_count() or 1)
+        keep_thr = torch.get_num_threads()
+        tr = torch_cpu_train.TorchCpuTrainer(wl["n_nodes"] + 1, 100, F, 100, k, wl["alpha"], wl["beta"], weights, efeat_host, time_w,
+                                             dropout=drop_p, lr=1e-4, n_threads=n_thr)
+        ids = snap["ids"]
+        for m in range(M):
+            tr.tppr.import_rows(m, ids, snap["tppr"][m])
+        tr.mem.memory[ids] = snap["memory"]
+        tr.mem.last_update[ids] = snap["last_update"]
+        tr.mem.messages[ids] = snap["messages"]
+        tr.mem.timestamps[ids] = snap["timestamps"]
+        tr.mem.flags[ids] = snap["flags"]
+        nb_cpu = max(3, min(steps + warmup, 12))
+        t_c, n_c, l_c = 0.0, 0, []
+        for q, b in enumerate(range(prefill, prefill + nb_cpu)):
+            s_, e_ = b * bs, (b + 1) * bs
+            t1 = time.perf_counter()
+            l_c.append(tr.step(src[s_:e_], dst[s_:e_], neg[s_:e_], ts[s_:e_], eidx[s_:e_]))
+            if q >= 2:                                   # (two steps to warm the allocator and the thread pool)
+                t_c += time.perf_counter() - t1
+                n_c += bs
+        torch.set_num_threads(keep_thr)
+        cpu = dict(value=n_c / t_c, unit="edges/s", cores=n_thr, kind="port", host_cpus=os.cpu_count(),
+                   sample="%d training steps (%d edges timed, the first two steps untimed) of the same stream from the GPU run's warm "
+                          "state: oracle/torch_cpu_train.py -- T-PPR by the C port on 1 thread, everything else torch-CPU ops with "
+                          "autograd on %d threads, Adam step included" % (nb_cpu, n_c, n_thr),
+                   p1_share=tr.t_tppr / max(t_c, 1e-9), loss_first_step=l_c[0])
+    return {
+        "value": steps * bs / dt, "unit": "edges/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+        "config": {"workload": "%s: the TRAINING step on %s's stream (%d nodes, bs=%d, k=%d, %d T-PPR models, F=%d): "
+                               "compute_edge_probabilities(train=True) + BCE + backward + Adam(lr 1e-4), dropout %.1f, numpy batches "
+                               "handed over per step as train.py does; prefill %d eval batches + warmup %d"
+                               % (name, base, wl["n_nodes"], bs, k, M, F, drop_p, prefill, warmup),
+                   "global_batch": bs, "step_loop": "python (the reference's training loop, train.py:195-215)"},
+        "loss_first_timed_step": loss_first, "loss_last_timed_step": loss_last,
+        "cpu_baseline": cpu,
+        "published_context": {"value": 12000.0, "unit": "edges/s (derived upper bound)",
+                              "source": "technical_report.pdf p.12 Table 6: Wikipedia, m = 2, k = 20: 8.91 s per training epoch on an RTX 2080 Ti + "
+                                        "Xeon 2.60 GHz (Numba T-PPR on the host); <= 110 K training edges / 8.91 s (BASELINE.md section 1)",
+                              "note": "other hardware, the real Wikipedia stream, an epoch that starts from empty state: context, not a "
+                                      "same-node comparison; vs_baseline stays null"},
+        "parity": "the training path is held to the reference's own loss and gradients by fixture g8_train_grads "
+                  "(tests/test_embed_gpu.py::test_training_step_gradients_match_reference; the CPU restatement timed here by "
+                  "tests/test_oracle_golden.py::test_torch_cpu_training_step_matches_reference_gradients)",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -795,7 +913,8 @@ def main():
     ap.add_argument("--legs", default="default",
                     help="further workloads timed after the headline one and printed under \"workloads\" of the same JSON "
                          "line, each with its own ms_per_step / roofline / cpu_baseline: comma-separated names, 'none', or "
-                         "'default' = c2,c3,c4 behind the c5 headline (nothing behind another --workload)")
+                         "'default' = c2,c3,c2_train,c4 behind the c5 headline (nothing behind another --workload); <name>_train = the TRAINING "
+                         "step of that workload (run_train_workload)")
     ap.add_argument("--leg-steps", type=int, default=100, help="timed steps of every leg (warm-up 10)")
     ap.add_argument("--steady-steps", type=int, default=200,
                     help="a further timed region of this many steps behind the headline's (printed as \"steady_state\"; skipped "
@@ -887,9 +1006,15 @@ def main():
     out = run_workload(a, a.workload, a.steps, a.warmup, world, rank, device, True, ce, steady=a.steady_steps)
     legs = a.legs
     if legs == "default":
-        legs = "c2,c3,c4" if a.workload == "c5" else "none"
+        legs = "c2,c3,c2_train,c4" if a.workload == "c5" else "none"
     res = {}
     for name in [x for x in legs.split(",") if x and x != "none"]:
+        if name.endswith("_train"):
+            if world == 1:
+                r = run_train_workload(a, name, a.leg_steps, 10, device)
+                if rank == 0:
+                    res[name] = r
+            continue
         # the other BASELINE configs, short: the driver's one run times all four (CPU legs bounded to ~2-4 s each)
         # (10 warm-up batches come first in the sample: 16 / 14 / 14 batches leave 6 / 4 / 4 TIMED ones for parity_in_run)
         leg_cpu = 0 if a.cpu_edges == 0 else {"c1": 16 * 200, "c2": 16 * 200, "c3": 14 * 600, "c4": 14 * 1000, "c5": 14 * 4096}[name]

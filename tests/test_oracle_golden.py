@@ -327,3 +327,33 @@ def test_oracle_under_sanitizers():
     r = subprocess.run([os.path.join(root, "_san", "sanitize_driver")], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "sanitize_driver: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
+
+
+def test_torch_cpu_training_step_matches_reference_gradients(oracle):
+    """oracle/torch_cpu_train.py (the CPU baseline of bench.py's training leg) against fixture g8_train_grads: loss and every
+    parameter gradient of four training steps of the reference itself (train.py:205-215, no optimizer step, dropout 0)."""
+    import torch_cpu_train
+    name = "d20_f7"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    g = golden("g8_train_grads")
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    tr = torch_cpu_train.TorchCpuTrainer(N, D, F, T, k, al, be, w, efeat, I.time_encode_weights(T), dropout=0.0, n_threads=1,
+                                         optimizer=False)
+    seen = 0
+    for b in range(nb):
+        s, e = b * bs, (b + 1) * bs
+        loss = tr.step(src[s:e], dst[s:e], neg[s:e], ts[s:e], eidx[s:e], optimize=False)
+        assert abs(loss - float(g["b%d_loss" % b])) <= 1e-5, "loss of batch %d" % b
+        for pn, p in tr.p.items():
+            key = "b%d_grad_%s" % (b, pn)
+            if key in g.files:
+                assert p.grad is not None, pn
+                want = g[key]
+                err = np.abs(p.grad.detach().numpy() - want).max()
+                assert err <= 1e-5 + 1e-4 * np.abs(want).max(), "%s in batch %d: %g" % (pn, b, err)
+                seen += 1
+            else:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, pn
+    assert seen >= 12 * nb
