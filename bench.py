@@ -757,7 +757,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
         # this much of the step does not shrink with N -- a flat curve is explained by the line itself
         # hub chains of the timed region, all chains and models: positions that shared a critical section with their neighbour
         # (csrc/tppr_pair.hpp) against positions taken singly -- the hit rate of the paired hop, measured in the kernel
-        "chain_hops": None if chain_stats is None else dict(
+        "chain_hops": None if (chain_stats is None or not (a.chain_pairs or a.chain_mode)) else dict(
             chain_stats, paired_share=(2.0 * chain_stats["pairs_done"] /
                                        max(1, 2 * chain_stats["pairs_claimed"] + chain_stats["singles"]))),
         "chain_bound_ms_per_step": (kern["tppr_stream"]["avg_us"] * kern["tppr_stream"]["launches"] / steps / 1e3)

@@ -62,9 +62,13 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_GRU 2         /* zt_gru_update: ZT_GRU_TILE, ZT_GRU_SPLIT */
 #define ZT_CHOICE_MESSAGES 3    /* zt_store_messages: ZT_MSG_ONE, ZT_MSG_TWO (batch positions per wavefront) */
 #define ZT_CHOICE_TPPR_CHAIN 4  /* hub chains of zt_tppr_stream: ZT_CHAIN_SINGLE (one position per critical section: the
-                                 * library's pick), ZT_CHAIN_PAIRED (two where the preconditions hold, csrc/tppr_pair.hpp), ZT_CHAIN_SPINE (below) */
+                                 * library's pick).  ZT_CHAIN_PAIRED / _SPINE / _DUO were built, are bit-exact and were measured
+                                 * SLOWER: they are compiled into variant builds only
+                                 * (tools/build_variant.sh, sources under tools/exp/variants/); the product library answers
+                                 * ZT_ERR_UNSUPPORTED */
 #define ZT_CHOICE_TPPR_PREPASS 5 /* dependency prepass of a launch of more than 4 096 accesses: ZT_PREPASS_LAUNCHES (one kernel per step,
-                                 * eleven launches: the library's pick), ZT_PREPASS_COOP (one cooperative kernel with grid barriers) */
+                                 * eleven launches: the library's pick); ZT_PREPASS_COOP (one cooperative kernel with grid barriers:
+                                 * not faster) likewise in variant builds only */
 #define ZT_CHOICE_COUNT 6
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
@@ -74,7 +78,7 @@ int zt_stream_destroy(void *stream);
 #define ZT_GRU_SPLIT 2
 #define ZT_CHAIN_SINGLE 1
 #define ZT_CHAIN_PAIRED 2
-#define ZT_CHAIN_SPINE 3   /* one wave per chain runs every critical section with the hub's row in registers (csrc/tppr_chain.hpp) */
+#define ZT_CHAIN_SPINE 3   /* one wave per chain runs every critical section with the hub's row in registers (tools/exp/variants/tppr_spine.hpp) */
 #define ZT_CHAIN_DUO 4     /* spine mode with the weights' recurrence (network + lane shift) on a wave of its own, ahead of the spine */
 #define ZT_PREPASS_LAUNCHES 1
 #define ZT_PREPASS_COOP 2
@@ -114,7 +118,8 @@ int zt_tppr_set_device_share(zt_tppr *h, int32_t n_processes);
  * consecutive chain positions claimed by one wavefront, [1] pairs applied in ONE critical section, [2] / [3] pairs left
  * to the single hop before / inside the section (a precondition failed), [4] positions taken singly.
  * ZT_CHAIN_SPINE / ZT_CHAIN_DUO: [1] = sections the spine ran, [3] = positions it left to their helpers.
- * (csrc/tppr_pair.hpp, csrc/tppr_chain.hpp; the reference applies the edges one by one, utils/util.py:495-574.) */
+ * All zero in the product library, whose one chain mode keeps no statistics on its hot path (variant builds:
+ * tools/exp/variants/tppr_pair.hpp, tppr_spine.hpp; the reference applies the edges one by one, utils/util.py:495-574.) */
 int zt_tppr_chain_stats(zt_tppr *h, int64_t *out5, void *stream);
 
 /* tppr_finder.reset_tppr (utils/util.py:419-434). */

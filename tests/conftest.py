@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# ZT_TEST_LIB=<path>: run the suite against another build of the library (tools/build_variant.sh: the chain modes and the
+# cooperative prepass that were measured slower live in variant builds only) -- test infrastructure, not a product switch
+if os.environ.get("ZT_TEST_LIB"):
+    from zebra_amd import _capi as _capi_for_tests
+    _p = os.environ["ZT_TEST_LIB"]
+    _capi_for_tests.LIB_PATH = _p if os.path.isabs(_p) else os.path.join(ROOT, _p)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

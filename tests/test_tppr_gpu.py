@@ -12,6 +12,17 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 
+def _variant_choice(which, value):
+    """The chain modes / prepass forms that were measured slower than the library's pick are compiled into VARIANT builds only
+    (tools/build_variant.sh, sources under tools/exp/variants/): the product library refuses them, and their tests run with
+    ZT_TEST_LIB=tools/out/libzebra_<variant>.so (tests/conftest.py)."""
+    from zebra_amd import _capi
+    try:
+        _capi.set_kernel_choice(which, value)
+    except ValueError as exc:
+        pytest.skip("variant build only: %s" % exc)
+
+
 @pytest.fixture(scope="module")
 def zt():
     import torch
@@ -58,7 +69,7 @@ def test_streaming_golden_paired_hops(zt, name):
     (csrc/tppr_pair.hpp; zt_set_kernel_choice(ZT_CHOICE_TPPR_CHAIN, ZT_CHAIN_PAIRED); k <= 20): outputs and state equal the
     reference's bit for bit -- the hub-tie stream included --, and on the streams with a hub pairs do form."""
     from zebra_amd import _capi
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED)
     try:
         test_streaming_golden(zt, name)
     finally:
@@ -70,7 +81,7 @@ def test_streaming_golden_duo(zt, name):
     """... and in duo mode (ZT_CHAIN_DUO: the weights' recurrence on a wave of its own, running ahead of the spine on the
     assumption that every test of the lean section passes; the spine voids its records whenever one does not)."""
     from zebra_amd import _capi
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
     try:
         test_streaming_golden(zt, name)
     finally:
@@ -82,7 +93,7 @@ def test_streaming_golden_spine(zt, name):
     """The same goldens with hub chains in spine mode (csrc/tppr_chain.hpp: one wave per chain runs every critical section
     with the hub's row in registers, the others prepare and finish; ZT_CHAIN_SPINE): bit for bit the reference's."""
     from zebra_amd import _capi
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
     try:
         test_streaming_golden(zt, name)
     finally:
@@ -94,7 +105,7 @@ def test_duo_dense_hub_and_soak(zt, oracle):
     spine leaves to a helper voids its records)."""
     from zebra_amd import _capi
     import soak_tppr
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_DUO)
     try:
         for seed in (1, 2):
             test_dense_hub_graph_vs_oracle(zt, oracle, seed)
@@ -110,7 +121,7 @@ def test_spine_dense_hub_and_soak(zt, oracle):
     stream long enough for chains, against the oracle; the chain statistics show the spine running the sections."""
     from zebra_amd import _capi
     import soak_tppr
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_SPINE)
     try:
         for seed in (1, 2):
             test_dense_hub_graph_vs_oracle(zt, oracle, seed)
@@ -146,7 +157,7 @@ def test_paired_hops_dense_hub_and_soak(zt, oracle):
     ties) and a slice of the randomised soak, against the oracle; the chain statistics show pairs completing."""
     from zebra_amd import _capi
     import soak_tppr
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED)
+    _variant_choice(_capi.CHOICE_TPPR_CHAIN, _capi.CHAIN_PAIRED)
     try:
         for seed in (1, 2):
             test_dense_hub_graph_vs_oracle(zt, oracle, seed)
@@ -808,7 +819,7 @@ def test_dependency_plan_cooperative_kernel(zt, oracle, shape):
     without fences -- the steps hand their arrays over through write-through stores and sc1 loads), and the goldens' state
     after streaming with it."""
     from zebra_amd import _capi
-    _capi.set_kernel_choice(_capi.CHOICE_TPPR_PREPASS, _capi.PREPASS_COOP)
+    _variant_choice(_capi.CHOICE_TPPR_PREPASS, _capi.PREPASS_COOP)
     try:
         test_dependency_plan_of_large_launches(zt, shape)
         if shape == "many_big_groups":

@@ -93,6 +93,9 @@ constexpr int TPPR_MAX_LAUNCH = 16384;     // edges one T-PPR launch can cover (
 inline unsigned sync_event_flags() { return 0u; }
 // zt_set_kernel_choice: 0 = the library picks by shape (runtime.hip)
 int kernel_choice(int which);
+// alternatives that were measured slower are compiled into variant builds only (tools/build_variant.sh): what THIS build has
+bool tppr_chain_mode_compiled(int mode);       // tppr_stream.hip
+bool tppr_prepass_coop_compiled();             // tppr_prepass.hip
 // CUs a stream may use (CU-masked streams: the size of the mask; queried per call -- runtime.hip)
 int stream_cu_count(hipStream_t s);
 #define ZT_PROF_BEGIN(s, id) do { if (zt::g_prof_on) zt::prof_begin((s), (id)); } while (0)

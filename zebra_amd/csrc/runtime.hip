@@ -99,6 +99,13 @@ using namespace zt;
 extern "C" int zt_set_kernel_choice(int32_t which, int32_t value)
 {
     if (which < 0 || which >= ZT_CHOICE_COUNT || value < 0) { set_error("zt_set_kernel_choice: unknown selector %d", which); return ZT_ERR_ARG; }
+    // alternatives that were measured slower than the library's pick live in variant builds only (tools/build_variant.sh,
+    // tools/exp/variants/): this build says so instead of silently running its default
+    if ((which == ZT_CHOICE_TPPR_CHAIN && !zt::tppr_chain_mode_compiled(value)) ||
+        (which == ZT_CHOICE_TPPR_PREPASS && value == ZT_PREPASS_COOP && !zt::tppr_prepass_coop_compiled())) {
+        set_error("zt_set_kernel_choice: value %d of selector %d is compiled into variant builds only (tools/build_variant.sh)", value, which);
+        return ZT_ERR_UNSUPPORTED;
+    }
     g_choice[which] = value;
     return ZT_OK;
 }

@@ -42,7 +42,11 @@
 //     quicksort replay on the ranks when ties decide, LDS / sequential replays
 //     for more than 64 candidates (numba_sort.hpp).
 #include "numba_sort.hpp"
-#include "tppr_pair.hpp"
+#ifdef ZT_CHAIN_VARIANTS                 // variant builds only (tools/build_variant.sh): the chain modes that were measured slower
+#include "tppr_pair.hpp"                 // (tools/exp/variants/: two positions per critical section; spine / duo via tppr_chain.hpp)
+#else
+#include "tppr_chain.hpp"
+#endif
 
 #include <cstdlib>
 #include <vector>
@@ -54,6 +58,7 @@ namespace {
 #ifndef ZT_STREAM_BOUNDS
 #define ZT_STREAM_BOUNDS (WAVE * WAVES_PER_WG)      // (tools/exp/bounds_exp.sh: 768 = three waves per SIMD, 168 VGPRs)
 #endif
+// (variant builds, -DZT_CHAIN_VARIANTS, instantiate MODE 1 .. 3 as well; the product library has MODE 0 alone)
 // PAIRS: the instantiation whose chain waves may take two positions per critical section (tppr_pair.hpp).  A kernel of its
 // own: the paired hop is a real call that needs all 256 registers a wave may have at two waves per SIMD, and a k_stream of
 // 256 registers leaves the message kernels no room beside its workgroups on the T-PPR stream's CUs (round 5: with the call
@@ -64,6 +69,7 @@ template <int MODE>
 __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamArgs A)
 {
     constexpr bool PAIRS = MODE == 1;
+    (void)PAIRS;
     __shared__ WaveLds lds[WAVES_PER_WG];
     __shared__ Mail mail;
     __shared__ int ch_edge[CH_MAX], ch_partner[CH_MAX], ch_wop[CH_MAX], ch_pch[CH_MAX];   // chain workgroups: HopRec
@@ -126,9 +132,13 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
         // partner's update, the emission -- runs elsewhere (process_chain_partner), but a hop's preparation and its
         // off-chain half (replay, order, stores) still add up to ~5 hop periods of one wave's time.
         if ((int)(threadIdx.x / WAVE) >= A.chain_waves) return;
+#ifdef ZT_CHAIN_VARIANTS
         const bool spine_on = MODE >= 2 && h.k <= REG_K_MAX && len > 0;
         if (spine_on && threadIdx.x < WAVE) { chain_spine<MODE == 3>(h, lds, lane, &mail, len); return; }
         if (spine_on && MODE == 3 && threadIdx.x < 2 * WAVE) { chain_weights(h, lds, lane, &mail, len); return; }
+#else
+        constexpr bool spine_on = false;
+#endif
         ChainHint hint;
         hint.norm_out = 0.0; hint.tpos = -1;
         // (Assigning hop t to wave t mod 8 statically -- so that the SIMD mate of the wave on the chain is the one four
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
 #define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
+#ifdef ZT_CHAIN_VARIANTS
             // ---- two positions in one critical section (tppr_pair.hpp): both edges have a partner other than the hub, not
             // ---- the same one, and nobody has claimed position t + 1 yet ----
             if (PAIRS && t >= 1 && t + 1 < len && h.k <= PAIR_K_MAX) {
@@ -172,13 +183,16 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
                     }
                 }
             }
+#endif
             if (MODE != 0) chain_stat(h.ctl, lane, ST_SINGLE);      // (statistics of the alternative chain modes only: the default kernel's hot path
                                                                     //  carries no atomic to a shared word that nobody reads -- round-5 advisor)
             const int pe = t > 0 ? ZT_U(ch_edge[t - 1]) : -1, ne = t + 1 < len ? ZT_U(ch_edge[t + 1]) : -1, ce = ZT_U(ch_edge[t]);
             HopRec rec;
             rec.partner = ZT_U(ch_partner[t]); rec.wo_p = ZT_U(ch_wop[t]); rec.pchain = ZT_U(ch_pch[t]);
 #undef ZT_U
+#ifdef ZT_CHAIN_VARIANTS
             if (spine_on && (pe < 0 || rec.partner < 0)) spine_post_none(&mail, lane, t);      // (chain_hop does not take these)
+#endif
             if (!chain_hop(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c, rec, spine_on))
                 process_edge(h, A, L, lane, ce, mo, &mail, hub, pe, ne, t, &hint, c);
         }
@@ -450,10 +464,13 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     }
 #endif
     ZT_PROF_BEGIN(s, P_STREAM);
+#ifdef ZT_CHAIN_VARIANTS
     if (sa.pairs) k_stream<1><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     else if (chain_choice == ZT_CHAIN_SPINE) k_stream<2><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
     else if (chain_choice == ZT_CHAIN_DUO) k_stream<3><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
-    else k_stream<0><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);
+    else
+#endif
+    k_stream<0><<<grid, WAVE * WAVES_PER_WG, 0, s>>>(*h, sa);      // (zt_set_kernel_choice refuses the other modes in a build without them)
     ZT_PROF_END(s, P_STREAM);
     ZT_LAUNCH_CHECK();
     ZT_HIP(hipEventRecord(P.consumed, s));
@@ -463,6 +480,16 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     return ZT_OK;
 }
 
+
+// which values of ZT_CHOICE_TPPR_CHAIN this build of the library can run (runtime.hip: zt_set_kernel_choice)
+bool zt::tppr_chain_mode_compiled(int mode)
+{
+#ifdef ZT_CHAIN_VARIANTS
+    return mode >= 0 && mode <= ZT_CHAIN_DUO;
+#else
+    return mode == 0 || mode == ZT_CHAIN_SINGLE;
+#endif
+}
 
 // zt_tppr_stream with two extras for callers inside the library (pipeline.hip): plan_ordered = `stream` already
 // waits for the stream that made the plan (no second wait packet); *done_out = the event recorded behind the
