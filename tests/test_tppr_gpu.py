@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _variant_choice(which, value):
     """The chain modes / prepass forms that were measured slower than the library's pick are compiled into VARIANT builds only
     (tools/build_variant.sh, sources under tools/exp/variants/): the product library refuses them, and their tests run with
-    ZT_TEST_LIB=tools/out/libzebra_<variant>.so (tests/conftest.py)."""
+    ZT_TEST_LIB=tools/out/<variant>/libzebra_amd.so (tests/conftest.py)."""
     from zebra_amd import _capi
     try:
         _capi.set_kernel_choice(which, value)

@@ -5,7 +5,7 @@
 # The alternatives that were measured slower than the library's pick are variant builds too (their sources: tools/exp/variants/):
 #   tools/build_variant.sh chainvariants "-DZT_CHAIN_VARIANTS"                            (paired / spine / duo hub chains)
 #   tools/build_variant.sh prepasscoop "-DZT_PREPASS_COOP_VARIANT" tppr_prepass.hip       (the prepass as one cooperative kernel)
-#   ZT_TEST_LIB=tools/out/libzebra_chainvariants.so python -m pytest tests/test_tppr_gpu.py -m gpu -k "paired or spine or duo"
+#   ZT_TEST_LIB=tools/out/chainvariants/libzebra_amd.so python -m pytest tests/test_tppr_gpu.py -m gpu -k "paired or spine or duo"
 set -e
 NAME=${1:?name}; FLAGS=$2; SRC=${3:-tppr_stream.hip}
 cd /root/repo/zebra_amd/csrc
@@ -16,4 +16,9 @@ hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FP $FLAGS -I/root/repo/zebra_a
 L=/root/repo/zebra_amd/lib
 OBJS=$(ls $L/*.o | grep -v "/${SRC%.hip}.o\|test_hooks.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libzebra_$NAME.so $O/v_$NAME.o $OBJS -ldl -lrt
+# the same library under the product's file name in a directory of its own, with the test hooks linked against it: what
+# ZT_TEST_LIB=tools/out/NAME/libzebra_amd.so (tests/conftest.py) loads -- the hooks resolve against THIS build
+mkdir -p $O/$NAME
+cp $O/libzebra_$NAME.so $O/$NAME/libzebra_amd.so
+hipcc --offload-arch=gfx950 -shared -fPIC -o $O/$NAME/libzebra_amd_testhooks.so $L/test_hooks.o -L$O/$NAME -lzebra_amd -Wl,-rpath,'$ORIGIN'
 echo $O/libzebra_$NAME.so

@@ -2,7 +2,7 @@
 // and therefore not part of the product library: this header is compiled only into variant builds
 //     tools/build_variant.sh chainvariants "-DZT_CHAIN_VARIANTS -I/root/repo/tools/exp/variants"
 // (tppr_chain.hpp includes it inside its anonymous namespace; tests/test_tppr_gpu.py runs its tests against such a build:
-//  ZT_TEST_LIB=tools/out/libzebra_chainvariants.so).
+//  ZT_TEST_LIB=tools/out/chainvariants/libzebra_amd.so).
 #pragma once
 
 // ---------------------------------------------------------------------------------------------------------------------
