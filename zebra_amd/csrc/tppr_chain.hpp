@@ -68,9 +68,20 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     const long long e = A.eidx[i];
     const bool hub_to_memory = next_edge < 0;                               // see process_edge: the chain's last hop only
     MailSlot *in_slot = &mail->slot[(tpos - 1) % MAIL_R], *out_slot = &mail->slot[tpos % MAIL_R];
-    // (the two float64 divisions of the scale factors: while the partner's row is on its way)
     PreScale pre_scale;
     pre_scale.valid = false;
+#ifndef ZT_CHAIN_VARIANTS
+    // the norm the hub's row will arrive with and the scale factors that follow from it: worked out for every position when
+    // the workgroup started (zt_tppr::hubscale, k_stream) -- four doubles, on their way beside the partner's row; the lean
+    // section still holds the norm that ARRIVES against this one, bit for bit
+    {
+        const double *sc = hub_scale(h, m, chain_idx, tpos);
+        const double sn = sc[0], sn1 = sc[1], s1 = sc[2], s2 = sc[3];
+        pre_scale.norm = sn; pre_scale.norm_next = sn1; pre_scale.scale_s1 = s1; pre_scale.scale_s2 = s2;
+        pre_scale.valid = sn != 0.0;
+    }
+#else
+    // (the two float64 divisions of the scale factors: while the partner's row is on its way)
     // the norm the hub's row will arrive with: norm <- norm * beta + beta from hop to hop, starting from this wave's own
     // last hop or, if that is long ago (or never was), from the latest kept set in the ring
     double pn = 0.0;
@@ -99,6 +110,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
         }
     };
     if (psteps >= 0) set_scale();
+#endif
     if (row_from_raw(praw, k, lane, psrc.expect, rp) != psrc.expect && psrc.polled)
         if (!load_row_wait_at(psrc.base, k, lane, psrc.expect, rp, h.ctl + 2, (int)pnode, psrc.aux(m), psrc.version)) wl_fail |= 2;
     // ---- while the hub's row is on its way: everything that depends on the partner only ----
@@ -181,6 +193,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
     }
     // (a wave's first hop of a launch has no norm to start from until somebody has published: the kept set two positions
     //  back is out now -- its successor is in its critical section --, which leaves time to prepare the partner's side)
+#ifdef ZT_CHAIN_VARIANTS
     if (!spine && !pre_scale.valid && tpos >= 2 && pre_hash != 2) {
         const MailSlot *sl = &mail->slot[(tpos - 2) % MAIL_R];
         if (lds_load_seq(&sl->seq_set) == tpos - 1) {
@@ -191,6 +204,7 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
             if (pre_scale.valid) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b, h2slot);
         }
     }
+#endif
     if (!by_spine) {
         if (!wait_seq(&in_slot->seq_set, tpos, h.ctl + 2, i, prev_edge, true)) wl_fail |= 16;
         __builtin_amdgcn_s_setprio(3);

@@ -167,6 +167,12 @@ __device__ __forceinline__ u64 *hub_version(const zt_tppr &h, int m, int c, int 
     return h.hubver + (((size_t)m * MAX_CHAINS + c) * (CH_MAX + 1) + t) * h.rg;
 }
 
+// the scale factors of chain c's hub at position t for model m (see zt_tppr::hubscale)
+__device__ __forceinline__ double *hub_scale(const zt_tppr &h, int m, int c, int t)
+{
+    return h.hubscale + (((size_t)m * MAX_CHAINS + c) * (CH_MAX + 1) + t) * 4;
+}
+
 // Where an access finds its row: in `rows` under the tag of the node's last earlier writer of the launch, or -- a hub's row
 // for everybody but the hub's own chain -- in the chain's versions, slot = that writer ordinal, under the launch's version tag.
 struct RowSrc {

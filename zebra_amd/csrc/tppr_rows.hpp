@@ -571,10 +571,45 @@ __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u
     if (__ballot(el && bw != bw) != 0ull) return;                                   // NaN: the general path
     // descending order, equal weights by element number: rb = elements that come before mine
     int rb = 0;
-    for (int q = 0; q < nb; ++q) {
-        const double x = readlane_f64(bw, q);
-        rb += (x > bw || (x == bw && q < lane)) ? 1 : 0;
+    {
+        // A pruned row is stored in ascending order of weight (the reference's dictionary order IS its argsort, :553-559) and
+        // scaling keeps that order: then an entry's place follows from the runs of equal weights -- the entries behind its run
+        // come before it, and so do the earlier members of its run -- without comparing it with every other one.  (21 lane
+        // broadcasts and compares, ~130 instructions, on a compute unit whose instruction issue bounds the chain: round 6.)
+        // Rows that never were full (or hold the new key already, whose weight is replaced) take the loop.
+        const long long bwb = __double_as_longlong(bw);
+        const int plo = __builtin_amdgcn_mov_dpp((int)(unsigned)(bwb & 0xffffffffll), 0x138, 0xf, 0xf, true);   // wave_shr:1
+        const int phi = __builtin_amdgcn_mov_dpp((int)(bwb >> 32), 0x138, 0xf, 0xf, true);
+        const double prev = __longlong_as_double(((long long)phi << 32) | (unsigned)plo);
+        const bool inr = lane > 0 && lane < len2;
+        const bool sorted_in = __ballot(inr && bw < prev) == 0ull;
+        if (sorted_in) {
+            const unsigned starts = (unsigned)__ballot(in2 && (lane == 0 || bw != prev));       // len2 <= 30: bits 0 .. len2-1
+            const unsigned upto = starts & ((2u << (lane & 31)) - 1u);                            // run starts at or below my entry
+            const int rs = 31 - __clz((int)upto);                                                 // start of my run
+            const unsigned after = starts & ~((2u << (lane & 31)) - 1u);
+            const int re = after ? __ffs((int)after) - 2 : len2 - 1;                              // its last member
+            const int ge_new = __popcll(__ballot(in2 && bw >= v));                                // entries that come before the new key
+            rb = in2 ? (len2 - 1 - re) + (lane - rs) + ((!present2 && v > bw) ? 1 : 0) : ge_new;
+        } else {
+            for (int q = 0; q < nb; ++q) {
+                const double x = readlane_f64(bw, q);
+                rb += (x > bw || (x == bw && q < lane)) ? 1 : 0;
+            }
+        }
     }
+#ifdef ZT_PREP_EXTRA      // timing experiment (tools/exp): the rank loop ZT_PREP_EXTRA more times, results unchanged -- is the chain
+    {                     // workgroup bound by its SIMDs' issue capacity (then every extra off-chain instruction shows in the hop)?
+        int junk = 0;
+        for (int rep = 0; rep < ZT_PREP_EXTRA; ++rep)
+            for (int q = 0; q < nb; ++q) {
+                double x = readlane_f64(bw, q);
+                asm volatile("" : "+v"(x));
+                junk += (x > bw || (x == bw && q < lane)) ? 1 : 0;
+            }
+        asm volatile("" :: "v"(junk));
+    }
+#endif
     // sorted lane of my element; lanes without one push to lane 0 (nobody reads the low half of these registers)
     const int dst = el ? 64 - nb + rb : 0;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);

@@ -64,6 +64,12 @@ struct zt_tppr {
                      // (dictionary order, tagged with the launch epoch), or nullptr (k > REG_K_MAX: no chains).  Within a
                      // launch a hub's row lives HERE: everybody but its own chain reads it by version, and only the
                      // chain's last hop stores it back to `rows`
+    double *hubscale;  // [M][MAX_CHAINS][CH_MAX + 1][4]: {norm, norm * beta + beta, scale_s1, scale_s2} of a chain's hub at every
+                       // position (utils/util.py:519-522).  A node's norm moves by norm <- norm * beta + beta with every edge that
+                       // touches it, whatever the rows hold: the whole sequence follows from the norm the launch finds, and the
+                       // chain workgroup works it out ONCE, all positions in parallel, when it starts (k_stream) -- a hop loads four
+                       // doubles instead of iterating the recurrence and dividing twice (~100 instructions of a compute unit whose
+                       // instruction issue is what bounds a chain: round 6).  Allocated with hubver.
     // hub chains of the launch
     int *chain_of;     // [N] chain index of a hub node, -1 otherwise (all -1 between calls)
     int *hot_node;     // [MAX_HOT] candidates, hot_cnt their access counts; [MAX_HOT .. MAX_HOT + MAX_BIG): nodes of big groups

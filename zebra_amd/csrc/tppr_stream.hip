@@ -126,8 +126,31 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
             Row r0;
             (void)load_row(h, m0, hub, lane, 0u, r0);
             store_row_at(hub_version(h, m0, c, 0), h.k, lane, r0.len, r0.key, r0.ts, r0.w, r0.norm, (A.epoch << ORD_BITS) | 1u);
+            // the hub's norm at every position of the chain: norm <- norm * beta + beta per edge (utils/util.py:567-572), a
+            // recurrence that does not look at the rows -- one lane runs it from the norm the launch finds (zt_tppr::hubscale)
+            if (lane == 0) {
+                const double beta = h.beta[m0];
+                double pn = r0.norm;
+                double *tab = hub_scale(h, m0, c, 0);
+                for (int t = 0; t <= len; ++t) { st_agent(tab + 4 * t, pn); pn = pn * beta + beta; }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         __syncthreads();
+        if (len > 0) {
+            // ... and the scale factors that follow from it, two float64 divisions per position, every position by a thread of
+            // its own: scale_s1 = norm / norm' * beta, scale_s2 = beta / norm' * (1 - alpha) with norm' = norm * beta + beta (:519-522)
+            const int m0 = A.m_lo + mo;
+            const double alpha = h.alpha[m0], beta = h.beta[m0];
+            for (int t = threadIdx.x; t <= len; t += blockDim.x) {
+                double *e = hub_scale(h, m0, c, t);
+                const double pn = ld_agent(e), nn = pn * beta + beta;
+                e[1] = nn;
+                e[2] = pn / nn * beta;
+                e[3] = beta / nn * (1.0 - alpha);
+            }
+            __syncthreads();
+        }
         // chain_waves (ZT_CHAIN_WAVES, default all eight) waves take hops: what a hop needs besides the hub's update -- the
         // partner's update, the emission -- runs elsewhere (process_chain_partner), but a hop's preparation and its
         // off-chain half (replay, order, stores) still add up to ~5 hop periods of one wave's time.
@@ -321,6 +344,7 @@ extern "C" int zt_tppr_destroy(zt_tppr *h)
     (void)hipDeviceSynchronize();
     (void)hipFree(h->rows); (void)hipFree(h->done); (void)hipFree(h->cdone);
     if (h->hubver) (void)hipFree(h->hubver);
+    if (h->hubscale) (void)hipFree(h->hubscale);
     if (h->latch_host) (void)hipHostFree(h->latch_host);
     for (int q = 0; q < 2; ++q) {
         zt_tppr::PlanSet &P = h->set[q];
@@ -437,6 +461,8 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
         const size_t vb = (size_t)h->M * MAX_CHAINS * (CH_MAX + 1) * h->rg * sizeof(u64);
         ZT_HIP(hipMalloc(&h->hubver, vb));
         ZT_HIP(hipMemsetAsync(h->hubver, 0, vb, s));
+        ZT_HIP(hipMalloc(&h->hubscale, (size_t)h->M * MAX_CHAINS * (CH_MAX + 1) * 4 * sizeof(double)));   // (written by every chain workgroup
+                                                                                                          //  before it is read: no clear)
     }
     StreamArgs sa;
     sa.use_chains = use_chains;
