@@ -132,6 +132,13 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
         }
     }
     const u64 nkey = ((u64)(unsigned)e << 32) | (u64)(unsigned)pnode;      // (edge_idx, partner, ts) enters the hub's dictionary
+    // what the lean section needs as SCALARS, worked out here, off the chain: the multipliers of the slot function the
+    // table was filled with, and the bits of the norm the row must arrive with
+    unsigned hm0, hm1;
+    key_hash_muls(pre_hash, hm0, hm1);
+    hm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)hm0); hm1 = (unsigned)__builtin_amdgcn_readfirstlane((int)hm1);
+    const long long pnb = __double_as_longlong(pre_scale.norm);
+    const unsigned pn0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pnb), pn1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(pnb >> 32));
     PreB pre_b;
     pre_b.ok = false;
     if (pre_hash != 2) prepare_b(lane, k, alpha, rp, nkey, tnow, pre_scale, pre_b, h2slot);
@@ -267,23 +274,19 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
 #ifndef ZT_NO_LEAN
     if (pre_b.ok && (by_spine || !spine)) {          // (a hop the spine left to this wave failed one of the section's tests already)
         lean_done = [&]() -> bool {
-            double hn;
-            int hlen_v, hmunc_v, hnalt_v, hsorted_v;
-            unsigned hunc_v;
-            mail_hdr_read(in_slot, hn, hlen_v, hunc_v, hmunc_v, hnalt_v, hsorted_v);
+            // the header: one 16-byte LDS word, its four words straight to scalar registers (the fields come apart on the scalar unit)
+            const mail_v4u hdr = *reinterpret_cast<const mail_v4u *>(&in_slot->norm);
             const bool low = __builtin_amdgcn_inverse_ballot_w64(0xffffffffull);        // lanes 0..31: the hub's entries
             u64 ckey = pre_b.cb_key;
             double cts = pre_b.cb_ts, cw = pre_b.cb_w, hw = 0.0;
             if (low) { ckey = in_slot->key[lane]; cts = in_slot->ts[lane]; hw = in_slot->w[lane]; }
             const int fs = by_spine ? 0 : lds_load_seq(&out_slot->seq_free);
-            const int n1 = __builtin_amdgcn_readfirstlane(hlen_v), munc = __builtin_amdgcn_readfirstlane(hmunc_v);
-            const int nalt = __builtin_amdgcn_readfirstlane(hnalt_v);
-            const unsigned hunc = (unsigned)__builtin_amdgcn_readfirstlane((int)hunc_v);
+            const unsigned hz = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+            const unsigned hunc = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.w);
+            const int n1 = (int)(hz & 0xffu), munc = (int)((hz >> 8) & 0xffu), nalt = (int)((hz >> 16) & 0xffu);
             if (!by_spine) {   // sorted arrangement, predicted norm (bit patterns on the scalar unit: both are finite and positive)
-                const long long hb = __double_as_longlong(hn), pb = __double_as_longlong(pre_scale.norm);
-                const unsigned h0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb), h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32));
-                const unsigned p0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pb), p1 = (unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32));
-                if (__builtin_amdgcn_readfirstlane(hsorted_v) == 0 || h0 != p0 || h1 != p1 || (h0 | h1) == 0u) { LEANC(1); return false; }
+                const unsigned h0 = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.x), h1 = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.y);
+                if ((hz >> 24) == 0u || h0 != pn0 || h1 != pn1 || (h0 | h1) == 0u) { LEANC(1); return false; }
             }
             const int nb = pre_b.nb, n = n1 + nb, drop = n - k;
             if (!by_spine && (n1 <= 0 || drop <= 0)) { LEANC(2); return false; }
@@ -303,12 +306,12 @@ __device__ __attribute__((always_inline)) inline bool chain_hop(const zt_tppr &h
                 // members of a straddling run that were not picked may turn out to be in the row (see below)
                 const u64 alt = in_slot->alt_key[lane & 31];
                 bool t = lane < nalt && alt == nkey;
-                if (table) t = t || (lane < nalt && L.htab[key_hash_by(alt, pre_hash)] >= 0);
+                if (table) t = t || (lane < nalt && L.htab[key_hash_m(alt, hm0, hm1)] >= 0);
                 if (__ballot(t) != 0ull) { LEANC(3); return false; }
             }
             // is a key of the hub's row in the partner's row?  Read now, looked at after the network
             const bool in1 = lane < n1;
-            const int cand = (table && in1) ? L.htab[key_hash_by(ckey, pre_hash)] : -1;
+            const int cand = (table && in1) ? L.htab[key_hash_m(ckey, hm0, hm1)] : -1;
             const double inf = __longlong_as_double(0x7ff0000000000000ll);
             double sw = pre_b.sw;
             int sid = pre_b.sid;

@@ -93,6 +93,18 @@ __device__ __forceinline__ int key_hash_by(u64 key, int code)
 {
     return code == 5 ? key_hash3(key) : (code == 3 ? key_hash2(key) : key_hash(key));
 }
+// ... and the same with the slot function's two multipliers handed over (key_hash_muls): inside a hub hop's critical
+// section the choice by code was a chain of exec-masked branches, ~20 instructions per probe (round 6: an instruction on the
+// chain costs 0.09 % of the kernel)
+__device__ __forceinline__ void key_hash_muls(int code, unsigned &m0, unsigned &m1)
+{
+    m0 = code == 5 ? 0x27D4EB2Fu : (code == 3 ? 0x85EBCA77u : 0x9E3779B1u);
+    m1 = code == 5 ? 0x165667B1u : (code == 3 ? 0xC2B2AE3Du : 0x85EBCA77u);
+}
+__device__ __forceinline__ int key_hash_m(u64 key, unsigned m0, unsigned m1)
+{
+    return (int)((((unsigned)key * m0) ^ ((unsigned)(key >> 32) * m1)) >> 22);
+}
 
 // ------------------------------------------------------------- row access ----
 struct Row {
@@ -598,18 +610,6 @@ __device__ inline void prepare_b(int lane, int k, double alpha, const Row &r2, u
             }
         }
     }
-#ifdef ZT_PREP_EXTRA      // timing experiment (tools/exp): the rank loop ZT_PREP_EXTRA more times, results unchanged -- is the chain
-    {                     // workgroup bound by its SIMDs' issue capacity (then every extra off-chain instruction shows in the hop)?
-        int junk = 0;
-        for (int rep = 0; rep < ZT_PREP_EXTRA; ++rep)
-            for (int q = 0; q < nb; ++q) {
-                double x = readlane_f64(bw, q);
-                asm volatile("" : "+v"(x));
-                junk += (x > bw || (x == bw && q < lane)) ? 1 : 0;
-            }
-        asm volatile("" :: "v"(junk));
-    }
-#endif
     // sorted lane of my element; lanes without one push to lane 0 (nobody reads the low half of these registers)
     const int dst = el ? 64 - nb + rb : 0;
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
