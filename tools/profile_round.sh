@@ -10,9 +10,9 @@
 # put names to the frames of the rocprofv3 counter-mode crash.  Each pass runs under its own timeout and keeps its stderr.
 WL=${1:-c5}; STEPS=${2:-20}; WARM=${3:-5}; COMMIT=${4:-unknown}; LAST=${5:-10}; CRASH=${6:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/prof_r5_$WL
+O=gpurun_out/prof_r6_$WL
 rm -rf $O && mkdir -p $O
-CMD="bench.py --workload $WL --steps $STEPS --warmup $WARM --legs none --cpu-edges 0 --no-score"
+CMD="bench.py --workload $WL --steps $STEPS --warmup $WARM --legs none --cpu-edges 0 --no-score --steady-steps 0"
 RE='k_stream|k_fc1_agg|k_gru|k_out_gru|k_embed_out|k_build_messages|k_last_pos|k_pruned_topk|k_affinity'
 RE_WIDE="$RE|k_deps|k_own|k_reserve|k_hot_select|k_count|k_fill|k_hubacc|k_prepass_fused|k_cleanup"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $CMD > $O/bench_under_rocprof.json 2> $O/kt.err
