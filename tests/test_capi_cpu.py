@@ -60,3 +60,26 @@ def test_round5_entry_points_validate_their_arguments(capi):
     assert lib.zt_exchange_unique_id(buf, C.c_int64(64)) == capi.ZT_ERR_ARG       # the id is 128 bytes
     assert lib.zt_pipeline_set_exchange(None, None) == capi.ZT_ERR_ARG
     assert lib.zt_exchange_destroy(None) == capi.ZT_OK
+
+
+def test_k_stream_leaves_room_for_the_message_kernels(capi, tmp_path):
+    """k_stream's workgroups sit two waves to a SIMD on the T-PPR stream's compute units and the message kernels of the
+    step (k_last_pos, k_build_messages2: <= 64 registers) run BESIDE them: that needs 2 x (k_stream's registers, in
+    granules of 8) + 64 <= 512, i.e. k_stream <= 224 vector registers.  At 225 (round 6, a replay-server experiment) the message
+    kernels waited for every k_stream to end and the step DOUBLED; at 256 (round 5, the paired hop inlined) likewise.  The
+    count is read from the built object's code-object metadata (no GPU needed)."""
+    import re
+    import subprocess
+    obj = os.path.join(os.path.dirname(capi.LIB_PATH), "tppr_stream.o")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(llvm, "clang-offload-bundler"))):
+        pytest.skip("no built object / no LLVM tools here (the GPU box runs the prebuilt library)")
+    fat, co = str(tmp_path / "fat.bin"), str(tmp_path / "ts.co")
+    subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section=.hip_fatbin=" + fat, obj, str(tmp_path / "unused.o")], check=True)
+    subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co], check=True)
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"\.name:\s+\S*k_streamILi0E\S*.*?\.vgpr_count:\s+(\d+)", notes, re.S)
+    assert m, "k_stream<0> not found in the code object's metadata"
+    vgprs = int(m.group(1))
+    assert vgprs <= 224, "k_stream<0> needs %d vector registers: the message kernels no longer fit beside it" % vgprs
