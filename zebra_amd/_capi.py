@@ -162,3 +162,27 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_device(device, arrays):
+    """Several host arrays to the device with ONE transfer: packed into a pinned staging buffer (torch's caching host
+    allocator: reused once the copy that read it has completed) and copied asynchronously on the current stream, so the host
+    does not wait for the work already queued there -- eight pageable copies per training step were eight synchronisations
+    (round 6: 1.3 of the step's 4.2 ms).  Returns device tensors of the arrays' dtypes and shapes."""
+    import numpy as np
+    import torch
+    arrs = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in arrs:
+        offs.append(total)
+        total += (a.nbytes + 15) & ~15
+    host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, o in zip(arrs, offs):
+        hv[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = host.to(device, non_blocking=True)
+    out = []
+    for a, o in zip(arrs, offs):
+        t = dev[o:o + a.nbytes].view(getattr(torch, str(a.dtype)))
+        out.append(t.view(a.shape))
+    return out

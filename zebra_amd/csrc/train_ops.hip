@@ -19,14 +19,19 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // C[M][N] = op(A)[M][K] op(B)[K][N] (+ C), row-major; op(A)(m, k) = TA ? A[k * lda + m] : A[m * lda + k], likewise B.
-// 64 x 64 tile per workgroup (4 waves, 32 x 32 each as 2 x 2 MFMA tiles), K in steps of 16 through LDS.
+// 64 x 64 tile per workgroup (4 waves, 32 x 32 each as 2 x 2 MFMA tiles), K in steps of 64 through LDS.
+// (Round 6: the K step was 16 with a load, a store and two barriers per step -- a weight gradient dW = dY^T X of a training
+//  step runs on 4-40 workgroups with K = the batch's rows, i.e. a chain of ~40 dependent memory round trips per workgroup:
+//  222 us for 6 MFLOP, 1.3 of the training step's 3.5 ms of GPU time.  Now 64 columns of K per step, all sixteen loads of a
+//  thread in flight before the first LDS store: a quarter of the round trips.  Same products, same k order: same results.)
+constexpr int GK = 64;
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
                                                   long long M, long long N, long long K, long long lda, long long ldb,
                                                   long long ldc, int accumulate)
 {
-    __shared__ float As[64][17];      // [m][k]
-    __shared__ float Bs[16][65];      // [k][n]
+    __shared__ float As[64][GK + 1];      // [m][k]
+    __shared__ float Bs[GK][65];          // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long m0 = (long long)blockIdx.y * 64, n0 = (long long)blockIdx.x * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -36,21 +41,31 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const float *__restrict__ A, c
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long long k0 = 0; k0 < K; k0 += 16) {
+    constexpr int PT = 64 * GK / 256;     // elements of each operand per thread and step
+    for (long long k0 = 0; k0 < K; k0 += GK) {
+        float va[PT], vb[PT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < PT; ++t) {
             const int idx = tid + t * 256;
             // consecutive threads walk the contiguous dimension of the operand as it lies in memory
-            const int am = TA ? (idx & 63) : (idx >> 4), ak = TA ? (idx >> 6) : (idx & 15);
+            const int am = TA ? (idx & 63) : (idx / GK), ak = TA ? (idx >> 6) : (idx % GK);
             const long long gm = m0 + am, gk = k0 + ak;
-            As[am][ak] = (gm < M && gk < K) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : 0.f;
-            const int bn = TB ? (idx >> 4) : (idx & 63), bk = TB ? (idx & 15) : (idx >> 6);
+            va[t] = (gm < M && gk < K) ? (TA ? A[gk * lda + gm] : A[gm * lda + gk]) : 0.f;
+            const int bn = TB ? (idx / GK) : (idx & 63), bk = TB ? (idx % GK) : (idx >> 6);
             const long long gn = n0 + bn, gk2 = k0 + bk;
-            Bs[bk][bn] = (gn < N && gk2 < K) ? (TB ? B[gn * ldb + gk2] : B[gk2 * ldb + gn]) : 0.f;
+            vb[t] = (gn < N && gk2 < K) ? (TB ? B[gn * ldb + gk2] : B[gk2 * ldb + gn]) : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int idx = tid + t * 256;
+            const int am = TA ? (idx & 63) : (idx / GK), ak = TA ? (idx >> 6) : (idx % GK);
+            As[am][ak] = va[t];
+            const int bn = TB ? (idx / GK) : (idx & 63), bk = TB ? (idx % GK) : (idx >> 6);
+            Bs[bk][bn] = vb[t];
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 16; kk += 4) {
+        for (int kk = 0; kk < GK; kk += 4) {
             float a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = As[wm + i * 16 + r16][kk + g4];
@@ -91,20 +106,35 @@ int gemm(const float *A, const float *B, float *C, long long M, long long N, lon
     return ZT_OK;
 }
 
-// out[c] (+)= sum_r X[r][c]; one workgroup per 64 columns, rows strided over 4 waves
-__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ X, long long R, long long Cn, long long ldx,
-                                                float *__restrict__ out, int accumulate)
+// out[c] (+)= sum_r X[r][c]; one workgroup of sixteen waves per 64 columns, rows strided over the waves, eight loads of a
+// wave in flight (round 6: four waves with one dependent load each took 110 us for 600 rows -- 150 round trips in a row)
+constexpr int CS_WAVES = 16;
+__global__ __launch_bounds__(64 * CS_WAVES) void k_colsum(const float *__restrict__ X, long long R, long long Cn, long long ldx,
+                                                          float *__restrict__ out, int accumulate)
 {
-    __shared__ float part[4][64];
+    __shared__ float part[CS_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long c = (long long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < Cn)
-        for (long long r = wave; r < R; r += 4) s += X[r * ldx + c];
+    if (c < Cn) {
+        // (one accumulator, rows in ascending order per wave: the sum's association is fixed -- wave w adds rows w, w + 16, ...)
+        for (long long r0 = wave; r0 < R; r0 += (long long)CS_WAVES * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long r = r0 + (long long)u * CS_WAVES;
+                v[u] = r < R ? X[r * ldx + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
     part[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && c < Cn) {
-        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < CS_WAVES; ++w) t += part[w][lane];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -193,7 +223,7 @@ extern "C" int zt_colsum_f32(const float *X_dev, int64_t rows, int64_t cols, int
 {
     if (rows < 0 || cols < 0 || (cols > 0 && (!out_dev || (rows > 0 && !X_dev)))) { set_error("zt_colsum_f32: bad argument"); return ZT_ERR_ARG; }
     if (cols == 0) return ZT_OK;
-    k_colsum<<<(unsigned)((cols + 63) / 64), 256, 0, (hipStream_t)stream>>>(X_dev, rows, cols, ldx, out_dev, accumulate != 0);
+    k_colsum<<<(unsigned)((cols + 63) / 64), 64 * CS_WAVES, 0, (hipStream_t)stream>>>(X_dev, rows, cols, ldx, out_dev, accumulate != 0);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }
@@ -264,8 +294,8 @@ extern "C" int zt_gru_train_backward(const float *d_h_dev, const float *messages
     if (rc != ZT_OK) return rc;
     rc = gemm(dgh, H, d_w_hh_dev, 3 * D, D, U, 3 * D, D, D, true, false, false, s);                         // dW_hh = dgh^T H
     if (rc != ZT_OK) return rc;
-    k_colsum<<<(unsigned)((3 * D + 63) / 64), 256, 0, s>>>(dgi, U, 3 * D, 3 * D, d_b_ih_dev, 0);
-    k_colsum<<<(unsigned)((3 * D + 63) / 64), 256, 0, s>>>(dgh, U, 3 * D, 3 * D, d_b_hh_dev, 0);
+    k_colsum<<<(unsigned)((3 * D + 63) / 64), 64 * CS_WAVES, 0, s>>>(dgi, U, 3 * D, 3 * D, d_b_ih_dev, 0);
+    k_colsum<<<(unsigned)((3 * D + 63) / 64), 64 * CS_WAVES, 0, s>>>(dgh, U, 3 * D, 3 * D, d_b_hh_dev, 0);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -595,15 +595,18 @@ class GraphDiffusionEmbedding(nn.Module):
         return out
 
     def compute_embedding_tppr_ensemble(self, memory, source_nodes, timestamps, edge_idxs, memory_updater, train,
-                                        row_sel=None):
+                                        row_sel=None, on_device=None):
         """modules/embedding_module.py:217-278.  ``memory`` is the Memory object
         in train mode and the raw memory tensor in eval mode, as in the reference.
         ``row_sel`` (train mode, optional): LongTensor of the rows to embed -- a data-parallel rank embeds (and
         back-propagates through) its share of the batch only; the T-PPR update always covers the whole batch."""
         d = self.device
-        nodes_d = torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=d)
-        ts_d = torch.as_tensor(np.ascontiguousarray(timestamps, np.float64), device=d)
-        eidx_d = torch.as_tensor(np.ascontiguousarray(edge_idxs, np.int64), device=d)
+        if on_device is not None:                  # (the caller has the three arrays on the device already: TGN's training step)
+            nodes_d, ts_d, eidx_d = on_device
+        else:
+            nodes_d, ts_d, eidx_d = _capi.to_device(d, [np.ascontiguousarray(source_nodes, np.int32),
+                                                        np.ascontiguousarray(timestamps, np.float64),
+                                                        np.ascontiguousarray(edge_idxs, np.int64)])
         t = time.time()
         on, oe, od, ow = self.topk_device(nodes_d, ts_d, eidx_d)
         if self.sync_timers:

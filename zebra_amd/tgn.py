@@ -513,15 +513,19 @@ class TGN(torch.nn.Module):
         unique_positives = np.unique(positives)
         self.n_update_memory += len(positives)
         d = self.device
-        src_d = torch.as_tensor(np.ascontiguousarray(source_nodes, np.int32), device=d)
-        dst_d = torch.as_tensor(np.ascontiguousarray(destination_nodes, np.int32), device=d)
-        ts_d = torch.as_tensor(np.ascontiguousarray(edge_times, np.float64), device=d)
-        eidx_d = torch.as_tensor(np.ascontiguousarray(edge_idxs, np.int64), device=d)
+        # the batch goes to the device in ONE asynchronous transfer (a training step used to make eight synchronous ones)
+        host = [np.ascontiguousarray(source_nodes, np.int32), np.ascontiguousarray(destination_nodes, np.int32),
+                np.ascontiguousarray(edge_times, np.float64), np.ascontiguousarray(edge_idxs, np.int64),
+                np.ascontiguousarray(unique_positives, np.int32)]
+        if negative_nodes is not None:
+            host.append(np.ascontiguousarray(negative_nodes, np.int32))
+        dev = _capi.to_device(d, host)
+        src_d, dst_d, ts_d, eidx_d, upos_d = dev[:5]
 
         if not train:
             if negative_nodes is None:
                 raise ValueError("the accelerated eval path expects negatives (tgn_model.py:132)")
-            neg_d = torch.as_tensor(np.ascontiguousarray(negative_nodes, np.int32), device=d)
+            neg_d = dev[5]
             node_embedding = self.step_device(src_d, dst_d, neg_d, ts_d, eidx_d, check_status=True, stats=True)
         else:
             if self.pipeline_outstanding():
@@ -537,11 +541,15 @@ class TGN(torch.nn.Module):
                 es = torch.as_tensor(np.asarray(edge_sel), device=d).long()
                 row_sel = torch.cat([es, es + n_samples, es + 2 * n_samples])
                 n_samples = int(es.numel())
+            on_device = None
+            if negative_nodes is not None:
+                on_device = (torch.cat([src_d, dst_d, dev[5]]), ts_d.repeat(3), eidx_d)
             node_embedding = self.embedding_module.compute_embedding_tppr_ensemble(
                 memory=self.memory, source_nodes=nodes, timestamps=timestamps, edge_idxs=edge_idxs,
-                memory_updater=self.memory_updater, train=True, row_sel=row_sel)
+                memory_updater=self.memory_updater, train=True, row_sel=row_sel, on_device=on_device)
             # update memory without gradients, THEN collect raw messages (:155-168)
-            self.update_memory(self.memory, unique_positives)
+            with torch.no_grad():
+                self.memory_updater.update_device(self.memory, upos_d, upos_d.numel())
             with torch.no_grad():
                 self.store_messages_device(src_d, dst_d, ts_d, eidx_d)
         self._last_node_embedding = node_embedding if edge_sel is None else None
