@@ -18,6 +18,9 @@ import inputs as I
 from helpers import build_tgn
 from zebra_amd import _capi
 
+if os.environ.get("ZT_LIB"):          # another build of the library (tools/build_variant.sh)
+    _capi.LIB_PATH = os.path.join(ROOT, os.environ["ZT_LIB"])
+
 
 def timed(fn, n=30):
     for _ in range(5):
