@@ -416,6 +416,16 @@ int zt_gemm_f32(const float *A_dev, const float *B_dev, float *C_dev, int64_t M,
 /* out[c] (+)= sum over rows of X[r][c] (bias gradients). */
 int zt_colsum_f32(const float *X_dev, int64_t rows, int64_t cols, int64_t ldx, float *out_dev,
                   int32_t accumulate, void *stream);
+/* The batch's own rows of the lazily updated memory -- get_updated_memory(...)[nodes]
+ * (modules/memory_updater.py:61-90, modules/embedding_module.py:320-322): out[i] =
+ * overlay[row_map[nodes[i]]] where row_map (NULL: none) names an overlay row, else
+ * memory[nodes[i]]; sel[i] = that overlay row or -1.  The backward adds d_out[i] to
+ * d_overlay[sel[i]] (atomic: a node may appear several times; the caller zeroes d_overlay). */
+int zt_overlay_rows(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev,
+                    const int32_t *nodes_dev, int64_t n, int32_t D, int64_t num_nodes,
+                    float *out_dev, int32_t *sel_dev, void *stream);
+int zt_overlay_rows_backward(const float *d_out_dev, const int32_t *sel_dev, int64_t n, int32_t D,
+                             float *d_overlay_dev, void *stream);
 /* h_out[u] = GRUCell(messages[ids[u]], memory[ids[u]]) for the U rows ids (the
  * lazily updated rows of get_updated_memory); saved [U][4 D] keeps r, z, n and
  * W_hn h + b_hn for the backward.  workspace: zt_gru_train_workspace_bytes. */

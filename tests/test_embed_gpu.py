@@ -1231,6 +1231,35 @@ def test_fused_training_backward_full_dims(F, k):
     assert any(np.abs(res[True][b][1]["memory_updater.memory_updater.weight_ih"]).max() > 0 for b in range(1, 6))
 
 
+def test_overlay_rows_forward_and_backward():
+    """zt_overlay_rows: the batch's own rows of the lazily updated memory (get_updated_memory(...)[nodes],
+    modules/memory_updater.py:61-90) and the gradient to the overlay rows, against torch's index / where composition --
+    nodes that repeat within the batch, nodes without an overlay row, and no overlay at all."""
+    from zebra_amd.modules import _OverlayRows
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    N, D, U, n = 500, 100, 37, 600
+    memory = torch.randn((N, D), generator=g).to(dev)
+    ids = torch.randperm(N, generator=g)[:U].to(dev)
+    row_map = torch.full((N,), -1, dtype=torch.int32, device=dev)
+    row_map[ids] = torch.arange(U, dtype=torch.int32, device=dev)
+    nodes = torch.randint(0, N, (n,), generator=g).to(dev)
+    nodes[:50] = ids[torch.randint(0, U, (50,), generator=g).to(dev)]          # repeated overlay rows
+    cot = torch.randn((n, D), generator=g).to(dev)
+    ov_a = torch.randn((U, D), generator=g).to(dev).requires_grad_(True)
+    ov_b = ov_a.detach().clone().requires_grad_(True)
+    out = _OverlayRows.apply(ov_a, memory, row_map, nodes.to(torch.int32), True)
+    (out * cot).sum().backward()
+    m = row_map[nodes].long()
+    ref = torch.where((m >= 0).unsqueeze(1), ov_b[m.clamp(min=0)], memory[nodes])
+    (ref * cot).sum().backward()
+    assert torch.equal(out, ref)
+    assert (m >= 0).sum() >= 50 and (m < 0).sum() > 0
+    assert torch.allclose(ov_a.grad, ov_b.grad, rtol=0, atol=1e-5)           # (sums of a few float32 terms in another order)
+    none = _OverlayRows.apply(torch.zeros((1, D), device=dev), memory, row_map, nodes.to(torch.int32), False)
+    assert torch.equal(none, memory[nodes])
+
+
 @pytest.mark.parametrize("F,k", [(1, 20), (4, 10)])
 def test_fused_training_dropout(F, k):
     """The reference trains with nn.Dropout(0.1) between fc1's ReLU and fc2 (modules/embedding_module.py:89,

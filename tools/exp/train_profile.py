@@ -11,6 +11,8 @@ src, dst, neg, ts, eidx = bench.make_stream(wl, n * bs, perm_seed=7)
 dev = torch.device("cuda")
 tgn = bench.build_model(wl, dev, n * bs + 1)
 tgn.train()
+if os.environ.get("ZT_NO_OVERLAY_OP"):
+    tgn.embedding_module.overlay_rows_op = False      # A/B: the batch's own rows by torch index / where
 opt = torch.optim.Adam(tgn.parameters(), lr=1e-4)
 crit = torch.nn.BCELoss()
 ones, zeros = torch.ones(bs, device=dev), torch.zeros(bs, device=dev)

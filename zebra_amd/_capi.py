@@ -26,7 +26,7 @@ SYMBOLS = [
     "zt_tppr_export", "zt_tppr_export_rows", "zt_tppr_import", "zt_tppr_import_rows",
     "zt_csr_build", "zt_csr_from_sorted", "zt_csr_size", "zt_csr_export", "zt_csr_destroy", "zt_csr_find_before", "zt_pruned_topk", "zt_pruned_topk_multi",
     "zt_embed_workspace_bytes", "zt_embed", "zt_project_table_bytes", "zt_project_memory", "zt_agg_train_forward", "zt_agg_backward_workspace_bytes", "zt_agg_train_backward", "zt_pipeline_create", "zt_pipeline_destroy", "zt_pipeline_main_stream", "zt_pipeline_update", "zt_pipeline_step", "zt_pipeline_step_ahead", "zt_pipeline_set_group",
-    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention",
+    "zt_store_messages", "zt_store_messages_range", "zt_gru_workspace_bytes", "zt_gru_rows_offset", "zt_gru_update", "zt_gemm_f32", "zt_colsum_f32", "zt_overlay_rows", "zt_overlay_rows_backward", "zt_gru_train_workspace_bytes", "zt_gru_train_forward", "zt_gru_train_backward", "zt_pipeline_set_stats", "zt_pipeline_outstanding", "zt_pack_rows", "zt_scatter_rows", "zt_attention_workspace_bytes", "zt_temporal_attention",
     "zt_affinity_workspace_bytes", "zt_affinity", "zt_link_metrics", "zt_pipeline_set_scoring", "zt_pipeline_last_scores", "zt_pipeline_run",
     "zt_exchange_unique_id", "zt_exchange_create", "zt_exchange_set_tables", "zt_exchange_destroy", "zt_pipeline_set_exchange",
 ]

@@ -149,6 +149,36 @@ __global__ void k_gather_rows_f32(const float *__restrict__ T, const int *__rest
     out[i] = T[(long long)ids[u] * W + (i - u * W)];
 }
 
+// The batch's own rows of the lazily updated memory (get_updated_memory(...)[nodes], modules/memory_updater.py:61-90 +
+// modules/embedding_module.py:320-322): out[i] = overlay[row_map[nodes[i]]] where the map names an overlay row, else
+// memory[nodes[i]]; sel[i] = that overlay row or -1, kept for the backward (the map is shared scratch and reset right after).
+__global__ void k_overlay_rows(const float *__restrict__ memory, const float *__restrict__ overlay, const int *__restrict__ row_map,
+                               const int *__restrict__ nodes, long long n, int D, long long num_nodes, float *__restrict__ out,
+                               int *__restrict__ sel)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const long long r = i / D;
+    const int c = (int)(i - r * D);
+    int v = nodes[r];
+    if (v < 0 || v >= num_nodes) v = 0;                          // (ids are checked by the T-PPR update of the same batch)
+    const int ov = row_map != nullptr ? row_map[v] : -1;
+    out[i] = ov >= 0 ? overlay[(long long)ov * D + c] : memory[(long long)v * D + c];
+    if (c == 0) sel[r] = ov;
+}
+
+// d_overlay[sel[i]] += d_out[i] for the rows that came from the overlay (d_overlay zeroed by the caller; a node may appear
+// several times in a batch: atomic adds, as in k_fc1_agg_bwd)
+__global__ void k_overlay_rows_bwd(const float *__restrict__ d_out, const int *__restrict__ sel, long long n, int D,
+                                   float *__restrict__ d_overlay)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const long long r = i / D;
+    const int ov = sel[r];
+    if (ov >= 0) atomicAdd(d_overlay + (long long)ov * D + (i - r * D), d_out[i]);
+}
+
 // torch.nn.GRUCell's gate arithmetic: gi = W_ih x + b_ih, gh = W_hh h + b_hh (gate order r, z, n);
 // r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n), h' = (1 - z) n + z h.
 // saved[u] = [r | z | n | gh_n] for the backward.
@@ -224,6 +254,30 @@ extern "C" int zt_colsum_f32(const float *X_dev, int64_t rows, int64_t cols, int
     if (rows < 0 || cols < 0 || (cols > 0 && (!out_dev || (rows > 0 && !X_dev)))) { set_error("zt_colsum_f32: bad argument"); return ZT_ERR_ARG; }
     if (cols == 0) return ZT_OK;
     k_colsum<<<(unsigned)((cols + 63) / 64), 64 * CS_WAVES, 0, (hipStream_t)stream>>>(X_dev, rows, cols, ldx, out_dev, accumulate != 0);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int zt_overlay_rows(const float *memory_dev, const float *overlay_dev, const int32_t *row_map_dev, const int32_t *nodes_dev,
+                               int64_t n, int32_t D, int64_t num_nodes, float *out_dev, int32_t *sel_dev, void *stream)
+{
+    if (n < 0 || D <= 0 || num_nodes <= 0 || (n > 0 && (!memory_dev || !nodes_dev || !out_dev || !sel_dev)) || (row_map_dev && !overlay_dev)) {
+        set_error("zt_overlay_rows: bad argument");
+        return ZT_ERR_ARG;
+    }
+    if (n == 0) return ZT_OK;
+    k_overlay_rows<<<(unsigned)((n * D + 255) / 256), 256, 0, (hipStream_t)stream>>>(memory_dev, overlay_dev, row_map_dev, nodes_dev, n, D,
+                                                                                    num_nodes, out_dev, sel_dev);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
+}
+
+extern "C" int zt_overlay_rows_backward(const float *d_out_dev, const int32_t *sel_dev, int64_t n, int32_t D, float *d_overlay_dev,
+                                        void *stream)
+{
+    if (n < 0 || D <= 0 || (n > 0 && (!d_out_dev || !sel_dev || !d_overlay_dev))) { set_error("zt_overlay_rows_backward: bad argument"); return ZT_ERR_ARG; }
+    if (n == 0) return ZT_OK;
+    k_overlay_rows_bwd<<<(unsigned)((n * D + 255) / 256), 256, 0, (hipStream_t)stream>>>(d_out_dev, sel_dev, n, D, d_overlay_dev);
     ZT_LAUNCH_CHECK();
     return ZT_OK;
 }

@@ -311,6 +311,34 @@ class _HipGruRows(torch.autograd.Function):
         return d_w_ih, d_w_hh, d_b_ih, d_b_hh, None, None, None
 
 
+class _OverlayRows(torch.autograd.Function):
+    """rows[i] = get_updated_memory(...)[nodes[i]] (modules/memory_updater.py:61-90, modules/embedding_module.py:320-322):
+    the overlay row where ``row_map`` names one, else the memory row; the gradient flows to the overlay rows only (memory is a
+    buffer).  One kernel forward, one backward (zt_overlay_rows / zt_overlay_rows_backward) in place of an index, a clamp, a
+    compare, a where and -- backward -- a sort-based index_put."""
+
+    @staticmethod
+    def forward(ctx, overlay, memory_t, row_map, nodes32, use_map):
+        n, D = int(nodes32.numel()), memory_t.shape[1]
+        out = torch.empty((n, D), dtype=torch.float32, device=memory_t.device)
+        sel = torch.empty(n, dtype=torch.int32, device=memory_t.device)
+        ov = overlay.detach().contiguous()
+        check(lib().zt_overlay_rows(ptr(memory_t), ptr(ov) if use_map else None, ptr(row_map) if use_map else None, ptr(nodes32),
+                                    C.c_int64(n), C.c_int32(D), C.c_int64(memory_t.shape[0]), ptr(out), ptr(sel), stream_ptr()),
+              "zt_overlay_rows")
+        ctx.save_for_backward(sel)
+        ctx.shape = tuple(overlay.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (sel,) = ctx.saved_tensors
+        d_ov = torch.zeros(ctx.shape, dtype=torch.float32, device=d_out.device)
+        check(lib().zt_overlay_rows_backward(ptr(d_out.contiguous()), ptr(sel), C.c_int64(sel.numel()), C.c_int32(ctx.shape[1]),
+                                             ptr(d_ov), stream_ptr()), "zt_overlay_rows_backward")
+        return d_ov, None, None, None, None
+
+
 class _NeighbourAggregate(torch.autograd.Function):
     """H[m][n] = sum_k w_k/sum(w) relu(fc1([memory'[nbr] | ef | cos(dt w)])), S[m][n] = (sum_k w != 0) with
     memory' = overlay rows where row_map says so (zt_agg_train_forward / zt_agg_train_backward)."""
@@ -648,11 +676,15 @@ class GraphDiffusionEmbedding(nn.Module):
             overlay = torch.zeros((1, self.embedding_dimension), device=self.device)
         row_map = memory.row_map()
         ids32 = ids.to(torch.int32)
-        src_rows = memory.memory[nodes_d.long()]
         if U:
             row_map[ids] = torch.arange(U, dtype=torch.int32, device=self.device)
-            m = row_map[nodes_d.long()].long()
-            src_rows = torch.where((m >= 0).unsqueeze(1), overlay[m.clamp(min=0)], src_rows)
+        if hip_dense and getattr(self, "overlay_rows_op", True):
+            src_rows = _OverlayRows.apply(overlay, memory.memory, row_map, nodes_d.to(torch.int32).contiguous(), bool(U))
+        else:
+            src_rows = memory.memory[nodes_d.long()]
+            if U:
+                m = row_map[nodes_d.long()].long()
+                src_rows = torch.where((m >= 0).unsqueeze(1), overlay[m.clamp(min=0)], src_rows)
         if hip_dense:                                                           # transform_source on the HIP GEMM (:320-322)
             embeddings = _HipLinear.apply(self.drop(self.act(_HipLinear.apply(src_rows, self.fc1_source.weight, self.fc1_source.bias))),
                                           self.fc2_source.weight, self.fc2_source.bias)
