@@ -338,6 +338,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
 
     # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
     # its real shape against the oracle with exactly these settings)
+    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH if a.release_by_launch else 0)
     tppr_cus, group = synth.pipeline_settings(wl, steps, a.tppr_cus if headline else -1, a.group if headline else -1)
     no_pipeline = a.no_pipeline and headline
     if not no_pipeline:
@@ -745,6 +746,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],
                                                                    wl["beta"], wl["strategy"], F, prefill, warmup),
                    "global_batch": bs, "tppr_launch_group": group, "tppr_cus": tppr_cus,
+                   "tppr_group_release": "launch (event)" if a.release_by_launch else "member (a counter per batch inside the launch)",
                    "clock_spin": spun, "step_loop": "native (zt_pipeline_run)" if native else "python",
                    "row_exchange": None if xchg is None else ("in the native step: %s, %d rank%s, [id | memory row | last_update] per touched row"
                                                                % ("RCCL ncclAllGather" if xchg == "rccl" else "shared memory (ranks share one GPU)",
@@ -941,6 +943,9 @@ def main():
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
     ap.add_argument("--chain-mode", type=int, default=0,
                     help="hub chains of the T-PPR update: 0 the library's pick, 1 single hops through the mailbox, 3 spine (zt_set_kernel_choice)")
+    ap.add_argument("--release-by-launch", action="store_true",
+                    help="the aggregation of a batch waits for the END of the T-PPR launch its group shares (the form before round 6, "
+                         "with tapering groups) instead of for that batch's rows (A/B)")
     ap.add_argument("--prepass-coop", action="store_true", help="the dependency prepass of big launches as ONE cooperative kernel (A/B against the eleven launches)")
     ap.add_argument("--chain-pairs", action="store_true",
                     help="hub chains take TWO positions per critical section where they can (csrc/tppr_pair.hpp; zt_set_kernel_choice: "

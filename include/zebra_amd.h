@@ -69,7 +69,11 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_TPPR_PREPASS 5 /* dependency prepass of a launch of more than 4 096 accesses: ZT_PREPASS_LAUNCHES (one kernel per step,
                                  * eleven launches: the library's pick); ZT_PREPASS_COOP (one cooperative kernel with grid barriers:
                                  * not faster) likewise in variant builds only */
-#define ZT_CHOICE_COUNT 6
+#define ZT_CHOICE_GROUP_RELEASE 6 /* zt_pipeline_*: when the aggregation of a batch may start whose streaming T-PPR update shares a launch
+                                 * with other batches.  ZT_RELEASE_MEMBER: as soon as that batch's rows are written (a counter per batch
+                                 * inside the launch: the library's pick); ZT_RELEASE_LAUNCH: when the whole launch has ended (an event;
+                                 * launch groups then taper towards the end of the batches in sight) */
+#define ZT_CHOICE_COUNT 7
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
 #define ZT_OUT_LATENCY 2
@@ -82,6 +86,8 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHAIN_DUO 4     /* spine mode with the weights' recurrence (network + lane shift) on a wave of its own, ahead of the spine */
 #define ZT_PREPASS_LAUNCHES 1
 #define ZT_PREPASS_COOP 2
+#define ZT_RELEASE_MEMBER 1
+#define ZT_RELEASE_LAUNCH 2
 #define ZT_MSG_ONE 1
 #define ZT_MSG_TWO 2
 int zt_set_kernel_choice(int32_t which, int32_t value);

@@ -1,11 +1,14 @@
 """GPU parity of the aggregation (P2) and memory-update (P3) kernels and of the
 whole per-batch protocol, through the reference-shaped Python surface:
 golden vectors (1e-4, BASELINE.json north_star tolerance) and the CPU oracle."""
+import time
+
 import numpy as np
 import pytest
 import torch
 
 import inputs as I
+from zebra_amd import _capi
 from conftest import golden
 from helpers import build_tgn
 
@@ -306,12 +309,24 @@ def test_out_gru_gate_gives_up_and_reports():
     tgn.enable_pipeline(False)
 
 
-@pytest.mark.parametrize("group,look,ragged", [(2, 5, False), (3, 8, True), (4, 11, False), (2, 2, False), (3, 1, True)])
-def test_grouped_tppr_launches_match_sequential(group, look, ragged):
+@pytest.mark.parametrize("group,look,ragged,release", [(2, 5, False, 0), (3, 8, True, 0), (4, 11, False, 0), (2, 2, False, 0),
+                                                       (3, 1, True, 0), (8, 25, True, 0), (3, 8, True, _capi.RELEASE_LAUNCH),
+                                                       (4, 11, False, _capi.RELEASE_LAUNCH)])
+def test_grouped_tppr_launches_match_sequential(group, look, ragged, release):
     """zt_pipeline_set_group: the streaming T-PPR update of `group` consecutive batches as ONE launch (edges in
     order across the batches, every batch's rows in its own block) must not change any result -- whole batches and
     row shards, a full view ahead (3 * group - 1 batches), a short one (smaller groups come out), and a stream
-    whose last batch is shorter."""
+    whose last batch is shorter.  release: how the aggregation of a batch learns that its rows are written -- the
+    library's pick (round 6: a counter per batch inside the launch, the main stream passes a gate per batch) or the
+    event behind the whole launch (ZT_CHOICE_GROUP_RELEASE)."""
+    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, release)
+    try:
+        _grouped_launches_match_sequential(group, look, ragged)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, 0)
+
+
+def _grouped_launches_match_sequential(group, look, ragged):
     name = "d100_f1"
     N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
     src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
@@ -490,6 +505,55 @@ def test_output_layer_kernels_agree(F, k, n):
         _capi.set_kernel_choice(_capi.CHOICE_EMBED_OUT, 0)
     for mode in ("latency", "persist", "auto"):
         assert np.array_equal(outs["tiled"], outs[mode]), mode
+
+
+def test_group_members_are_released_when_the_launch_is_rejected():
+    """A launch group whose T-PPR update the prepass rejects (a node id out of range in ONE of its batches: ZT_ERR_RANGE, the
+    state untouched, every output row an empty dictionary) must still let the main stream through: the rejected launch opens
+    the gate of every member, no gate wait gives up (the pipeline's latch stays clear), the error is reported by the finder's
+    status, and the steps after it run."""
+    name = "d100_f1"
+    N, E, D, F, T, k, al, be, seed, bs, nb = I.EMBED_CASES[name]
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+    tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=3)
+    neg_bad = neg.copy()
+    neg_bad[2 * bs + 3] = N + 7                              # third batch: a negative sample that is no node
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg_bad, ts, eidx)]
+    batches = [tuple(x[a:a + bs] for x in t) for a in range(0, 7 * bs, bs)]
+    t0 = time.perf_counter()
+    embs, refused = [], False
+    with torch.cuda.stream(tgn.main_stream):
+        # batch 0 alone, batches 1 .. 3 as one launch (rejected), 4 .. 6 as the next.  The handle's host-mapped latch may
+        # refuse a later launch as soon as the rejected one has run: either way nothing may wait for rows that never come
+        try:
+            for b, cur in enumerate(batches[:4]):
+                embs.append(tgn.step_device(*cur, ahead=batches[b + 1: b + 9]).clone())
+        except IndexError:
+            refused = True
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 3.0, "a gate waited for a launch that was rejected"
+    if not refused:
+        with pytest.raises(IndexError):
+            tgn.embedding_module.tppr_finder.check_status()
+    else:
+        try:
+            tgn.embedding_module.tppr_finder.check_status()      # (reports and clears what is left of it)
+        except IndexError:
+            pass
+    assert len(embs) >= 2 and all(torch.isfinite(e).all() for e in embs)
+    tgn.embedding_module._status.zero_()
+    tgn.enable_pipeline(False)                                # (the groups staged around the refused call are void)
+    tgn.enable_pipeline(tppr_cus=0, max_batch=64, group=3)
+    with torch.cuda.stream(tgn.main_stream):                  # no latched time-out: the next steps are taken
+        for b in range(4, 7):
+            tgn.step_device(*batches[b], ahead=batches[b + 1: b + 9])
+    torch.cuda.synchronize()
+    tgn.embedding_module.tppr_finder.check_status()
+    tgn.enable_pipeline(False)
 
 
 @pytest.mark.parametrize("strategy,group", [("streaming", 1), ("streaming", 3), ("pruning", 1)])

@@ -34,6 +34,8 @@ SYMBOLS = [
 
 # zt_set_kernel_choice selectors / values (include/zebra_amd.h)
 CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES, CHOICE_TPPR_CHAIN, CHOICE_TPPR_PREPASS = 0, 1, 2, 3, 4, 5
+CHOICE_GROUP_RELEASE = 6
+RELEASE_MEMBER, RELEASE_LAUNCH = 1, 2
 PREPASS_LAUNCHES, PREPASS_COOP = 1, 2
 CHAIN_SINGLE, CHAIN_PAIRED, CHAIN_SPINE, CHAIN_DUO = 1, 2, 3, 4
 AGG_GENERIC = 1
@@ -46,6 +48,15 @@ def set_kernel_choice(which, value):
     """Pin one of the kernels of a step process-wide (0: the library picks by shape again) -- for tests that hold the
     kernels against each other."""
     check(lib().zt_set_kernel_choice(C.c_int32(which), C.c_int32(value)), "zt_set_kernel_choice")
+    _choices[which] = value
+
+
+_choices = {}
+
+
+def kernel_choice(which):
+    """What set_kernel_choice last pinned for selector `which` in this process (0: the library's pick)."""
+    return _choices.get(which, 0)
 
 
 class RowTables(C.Structure):

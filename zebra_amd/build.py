@@ -18,7 +18,9 @@ LIB = os.path.join(LIBDIR, "libzebra_amd.so")
 # file -> extra flags
 SOURCES = {
     "runtime.hip": [],
-    "tppr_prepass.hip": [],
+    # (k_reserve's atomicAdd of a per-lane count: the compiler's default wraps it in a scan over the lanes one at a time, ~580
+    #  scalar instructions per wave; the DPP form of the same scan is ~20)
+    "tppr_prepass.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=DPP"],
     "tppr_stream.hip": ["-ffp-contract=off"],
     "tppr_io.hip": [],
     "tppr_prune.hip": ["-ffp-contract=off"],

@@ -25,7 +25,13 @@ void prof_end(hipStream_t s, int id);
 int tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B,
                    int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                    float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
-                   hipEvent_t *done_out, int32_t sub_B);
+                   hipEvent_t *done_out, int32_t sub_B, int32_t *member_done_dev = nullptr);
+// member_done_dev (launches over several batches: sub_B > 0): TPPR_MEMBER_WORDS ints, zero when the launch starts.  Word g counts
+// the (edge, model) tasks of batch g whose output rows are written -- visible at agent scope when the count is -- so that a
+// consumer of batch g's rows need not wait for the end of the launch: word g == B_g * models opens it (pipeline.hip:
+// k_member_gate).  A launch that k_count rejected (ZT_ERR_RANGE) writes its empty rows and sets every word to INT_MAX.
+constexpr int TPPR_MAX_MEMBERS = 8;         // batches per launch that can be released one by one
+constexpr int TPPR_MEMBER_WORDS = TPPR_MAX_MEMBERS + 1;      // (the last word: workgroups of a rejected launch that are through)
 // zt_gru_update with the projected-table refresh folded into the GRU kernel (memory_update.hip); wm_p from embed_wm_ptr.
 // counter_zeroed: the row counter (first word of the workspace) is zero already; select_done: the row list and the counter
 // are filled (pipeline.hip: the message kernel hands its list of winners over), no compaction of flagged ids
@@ -174,6 +180,10 @@ __device__ __forceinline__ void st_agent(int *p, int v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_agent(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -181,6 +191,51 @@ __device__ __forceinline__ unsigned ld_agent(const unsigned *p)
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ONE lane's atomic add on behalf of its wave, without a branch in the program: the wave's queue claims (k_stream).
+// What the obvious forms compile to (seen in the ISA, round 6): `if (lane == 0) old = atomicAdd(p, 1)` is jump-threaded with
+// lane-0 code around it and the structurizer replays the loop body for the other lanes; `atomicAdd(p, lane == 0 ? 1 : 0)` --
+// written to avoid that -- makes the compiler's atomic optimizer wrap the add in a scan over the 64 lanes ONE LANE AT A TIME
+// (s_ff1 / v_readlane / v_writelane / s_andn2 ...: 9 instructions x 64 = ~580 per claim, on a chain workgroup whose instruction
+// issue is what bounds a hub chain); `atomicAdd(p, 1)` by every lane with a pointer the compiler cannot prove uniform is 64
+// atomics to one address (~10 ns each at the memory side).  Here: exec = lane 0 for the one instruction.
+// Returns the value before the add, wave-uniform.  p: LDS.
+__device__ __forceinline__ int wave_claim_lds(int *p, int v)
+{
+    int old;
+    unsigned long long save;
+    const unsigned a = (unsigned)(unsigned long long)p;              // generic -> LDS: the low 32 bits are the LDS address
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(old), "=&s"(save) : "v"(a), "v"(v) : "memory");
+    return __builtin_amdgcn_readlane(old, 0);
+}
+// p: global memory (agent scope, as atomicAdd)
+__device__ __forceinline__ int wave_claim_global(int *p, int v)
+{
+    int old;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, off sc0\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(old), "=&s"(save) : "v"(p), "v"(v) : "memory");
+    return __builtin_amdgcn_readlane(old, 0);
+}
+// ... and without a result: fire and forget
+__device__ __forceinline__ void wave_add_global(int *p, int v)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %1, %2, off\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(p), "v"(v) : "memory");
 }
 
 // cos(x) for the time encoding.  |x| < 4e6: float32 Cody-Waite reduction with three FMA steps

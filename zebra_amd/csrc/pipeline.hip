@@ -19,6 +19,14 @@
 // two kernels on the T-PPR stream, the kernel's start and tail, its cold instruction cache -- is paid once per
 // group.  The caller shows the batches that follow (zt_pipeline_step_ahead); with fewer than 3 * group of
 // them in sight the groups simply come out smaller.  The pruning strategy has no state to carry: group = 1.
+//
+// RELEASE BY MEMBER (round 6).  The aggregation of a group's batch b needs batch b's T-PPR rows, not the end of the launch
+// that wrote them: k_stream counts, per member of the group, the (edge, model) tasks whose rows are out (write-through
+// stores; Slot::mdone), and the main stream passes a one-wave gate kernel (k_member_gate: bounded wait, ZT_ERR_TIMEOUT to the
+// status word and the pipeline's latch) instead of waiting for the launch's event.  So the main stream follows the T-PPR
+// stream at a distance of ONE batch whatever the group size: no tapering of the groups towards the end of the batches in
+// sight, and a short timed region runs in the launch groups of a long one.  ZT_CHOICE_GROUP_RELEASE = ZT_RELEASE_LAUNCH
+// brings the event (and the taper) back.
 #include "common.hpp"
 
 #include <cstring>
@@ -29,6 +37,7 @@ using namespace zt;
 #define ZT_MAX_GROUP 8
 #endif
 constexpr int MAX_GROUP = ZT_MAX_GROUP;
+static_assert(MAX_GROUP <= zt::TPPR_MAX_MEMBERS, "a slot's member counters (common.hpp: TPPR_MEMBER_WORDS)");
 
 struct zt_pipeline {
     zt_pipeline_desc d;
@@ -45,6 +54,8 @@ struct zt_pipeline {
         int32_t *buf;          // 4 x [M][3 * cap][k]
         int32_t *on, *oe;      // the group's four output arrays inside buf ([member][M][3 * B][k] each)
         float *od, *ow;
+        int32_t *mdone;        // [TPPR_MEMBER_WORDS] per member: the (edge, model) tasks whose output rows are written (k_stream)
+        bool by_member;        // the launch counts there: the main stream passes a gate per member instead of waiting for `ready_ev`
         hipEvent_t ready;      // T-PPR outputs complete (side stream)
         hipEvent_t ready_ev;   // the event to wait on for that: `ready`, or the one the T-PPR update recorded itself
         hipEvent_t consumed;   // main stream is done with the slot
@@ -98,8 +109,9 @@ struct GroupPtrs {
 // ids of a group into a slot: role-major over the whole group (what the T-PPR launch reads), batch-major per
 // member (what the aggregation reads), the concatenated edge ids and times; ts3 = 1: the query time of every row
 __global__ void k_stage_group(GroupPtrs g, int32_t *__restrict__ nodes, int32_t *__restrict__ nodes_m,
-                              double *__restrict__ ts, long long *__restrict__ eidx, int ts3)
+                              double *__restrict__ ts, long long *__restrict__ eidx, int ts3, int32_t *__restrict__ mdone)
 {
+    if (blockIdx.x == 0 && (int)threadIdx.x < zt::TPPR_MEMBER_WORDS) mdone[threadIdx.x] = 0;     // (the slot's previous user is done: `consumed`)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= g.Btot) return;
     int m = 0;
@@ -129,6 +141,29 @@ __global__ __launch_bounds__(256) void k_avg_topk(const float *__restrict__ w, l
         __syncthreads();
     }
     if (threadIdx.x == 0) *out = rows > 0 ? (float)(part[0] / (double)rows) : 0.f;
+}
+
+// The main stream's wait for ONE member of a launch group: a wave that polls the member's counter (agent scope) until every
+// task of the batch has written its rows.  The kernel behind it on the stream starts with the acquire every kernel starts
+// with and reads rows that were stored write-through.  Bounded like every in-kernel wait of the library (4 s): a launch that
+// never gets there -- it failed, its own waits gave up -- is reported, not waited for.
+__global__ void k_member_gate(const int32_t *word, int target, int *status, int *latch)
+{
+    if (threadIdx.x != 0) return;
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (ld_agent(word) < target) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 1023u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 400000000ll) {          // 4 s of the 100 MHz wall clock
+                atomicExch(status, ZT_ERR_TIMEOUT);
+                if (latch != nullptr) __hip_atomic_store(latch, (int)ZT_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+        }
+    }
 }
 
 bool same_batch(const zt_batch *a, const int64_t *key, int64_t B) { return a->eidx == key && a->B == B; }
@@ -189,7 +224,9 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     // them along: the last THREE batches of a region are queried one by one (round 4; two before: the driver's 20-step
     // run ended with a two-batch launch and two aggregations behind it) and the aggregation of each runs beside the update
     // of the next.  A full group needs want + 1 followers in sight (synth.pipeline_look).
-    if (n_more <= want) want = n_more >= 2 ? n_more - 1 : 1;
+    // (round 6: with the batches of a launch released one by one -- see the top of the file -- neither holds: no taper)
+    const bool by_member = streaming && zt::kernel_choice(ZT_CHOICE_GROUP_RELEASE) != ZT_RELEASE_LAUNCH;
+    if (!by_member && n_more <= want) want = n_more >= 2 ? n_more - 1 : 1;
     for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
         const zt_batch *b = more + q;
         // members are equally long, except that the last one may be shorter; everything fits one launch and the slot
@@ -209,7 +246,7 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
         ZT_HIP(hipStreamWaitEvent(st, p->entry, 0));
     }
     k_stage_group<<<(unsigned)((g.Btot + 255) / 256), 256, 0, st>>>(g, s.nodes, s.nodes_m, s.ts,
-                                                                     reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1);
+                                                                     reinterpret_cast<long long *>(s.eidx), streaming ? 0 : 1, s.mdone);
     ZT_LAUNCH_CHECK();
     if (record) ZT_HIP(hipEventRecord(s.filled, st));
     // the four output arrays of the group, back to back in the slot's buffer
@@ -218,6 +255,7 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     s.od = reinterpret_cast<float *>(s.buf + 2 * per); s.ow = reinterpret_cast<float *>(s.buf + 3 * per);
     for (int j = 0; j < g.n; ++j) { s.key[j] = g.eidx[j]; s.B[j] = g.B[j]; }
     s.n = g.n; s.n_done = 0; s.Btot = g.Btot; s.token = 0; s.launched = false; s.used = true; s.waited = false;
+    s.by_member = by_member && g.n > 1;
     s.q_lo = 0; s.q_hi = 0;
     *out = &s;
     return ZT_OK;
@@ -235,7 +273,7 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
         // records for the plan set doubles as this slot's `ready`
         hipEvent_t done = nullptr;
         int rc = zt::tppr_stream_ex(d.tppr, s.nodes, s.ts, s.eidx, s.Btot, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
-                                    true, &done, s.n > 1 ? (int32_t)s.B[0] : 0);
+                                    true, &done, s.n > 1 ? (int32_t)s.B[0] : 0, s.by_member ? s.mdone : nullptr);
         if (rc != ZT_OK) return rc;
         if (done != nullptr) { s.ready_ev = done; s.launched = true; s.waited = false; return ZT_OK; }
     } else {
@@ -312,6 +350,8 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
         ZT_HIP(hipMalloc(&s.ts, rows * sizeof(double)));
         ZT_HIP(hipMalloc(&s.eidx, (size_t)p->cap * sizeof(int64_t)));
         ZT_HIP(hipMalloc(&s.buf, 4 * per * 4));
+        ZT_HIP(hipMalloc(&s.mdone, zt::TPPR_MEMBER_WORDS * sizeof(int32_t)));
+        ZT_HIP(hipMemset(s.mdone, 0, zt::TPPR_MEMBER_WORDS * sizeof(int32_t)));
         ZT_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming | zt::sync_event_flags()));
         ZT_HIP(hipEventCreateWithFlags(&s.filled, hipEventDisableTiming | zt::sync_event_flags()));
@@ -328,7 +368,7 @@ extern "C" int zt_pipeline_destroy(zt_pipeline *p)
     if (!p) return ZT_OK;
     (void)hipDeviceSynchronize();
     for (auto &s : p->slot) {
-        (void)hipFree(s.nodes); (void)hipFree(s.nodes_m); (void)hipFree(s.ts); (void)hipFree(s.eidx); (void)hipFree(s.buf);
+        (void)hipFree(s.nodes); (void)hipFree(s.nodes_m); (void)hipFree(s.ts); (void)hipFree(s.eidx); (void)hipFree(s.buf); (void)hipFree(s.mdone);
         (void)hipEventDestroy(s.ready); (void)hipEventDestroy(s.consumed); (void)hipEventDestroy(s.filled);
     }
     (void)hipFree(p->sh_on); (void)hipFree(p->sh_oe); (void)hipFree(p->sh_od); (void)hipFree(p->sh_ow);
@@ -464,7 +504,11 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     //  the strategy carries no state)
     if (pruning && s->launched && (s->q_lo != row_lo || s->q_hi != row_hi)) s->launched = false;
     if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
-    if (!s->waited) { ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0)); s->waited = true; }
+    if (s->by_member) {
+        // this member's rows, not the launch: one count per (edge, model) task (k_stream's general queue)
+        k_member_gate<<<1, 64, 0, p->main_s>>>(s->mdone + j, (int)(s->B[j] * d.M), d.status, p->latch_dev);
+        ZT_LAUNCH_CHECK();
+    } else if (!s->waited) { ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0)); s->waited = true; }
     // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
     int a = s->n - 1 - j;                     // ahead[0 .. a) are the rest of this group
     if (a < n_ahead && valid_batch(p, ahead + a)) {

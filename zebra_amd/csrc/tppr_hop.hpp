@@ -108,6 +108,7 @@ struct StreamArgs {
     int pairs;         // 1: chain waves take two consecutive positions in one critical section where they can (tppr_pair.hpp)
     int sub_B;         // > 0: the launch covers several consecutive batches of sub_B edges (the last may be shorter); the
                        // output rows of batch g form their own [n_models][n_roles][B_g][k] block, blocks back to back
+    int *member_done;  // sub_B > 0 and the caller wants batches released one by one: TPPR_MEMBER_WORDS counters (common.hpp), else NULL
 };
 
 __device__ __forceinline__ int lds_load_seq(const int *p)

@@ -180,14 +180,16 @@ __device__ __forceinline__ unsigned row_from_raw(const RawRow &q, int k, int lan
 __device__ __forceinline__ void emit_row(const Row &r, int k, int lane, double tnow, int *on, int *oe, float *od,
                                          float *ow)
 {
+    // (write-through stores, as the rows': a consumer on another XCD may be let at a batch's rows while this launch is still
+    //  running -- StreamArgs::member_done -- and must find them in memory, not in this XCD's L2)
     if (lane >= k) return;
-    if (r.len == 0) { on[lane] = 0; oe[lane] = 0; od[lane] = 0.f; ow[lane] = 0.f; return; }
+    if (r.len == 0) { st_agent(on + lane, 0); st_agent(oe + lane, 0); st_agent(od + lane, 0.f); st_agent(ow + lane, 0.f); return; }
     const bool a = lane < r.len;
-    on[lane] = a ? (int)(unsigned)(r.key & 0xffffffffull) : 0;
-    oe[lane] = a ? (int)(unsigned)(r.key >> 32) : 0;
-    ow[lane] = a ? (float)r.w : 0.f;
+    st_agent(on + lane, a ? (int)(unsigned)(r.key & 0xffffffffull) : 0);
+    st_agent(oe + lane, a ? (int)(unsigned)(r.key >> 32) : 0);
+    st_agent(ow + lane, a ? (float)r.w : 0.f);
     const float tsf = a ? (float)r.ts : 0.f;      // tmp_timestamps is float32
-    od[lane] = (float)(tnow - (double)tsf);        // f64 - f32 -> f64 -> stored f32
+    st_agent(od + lane, (float)(tnow - (double)tsf));        // f64 - f32 -> f64 -> stored f32
 }
 
 // One (s1, s2) pair of the update block (utils/util.py:509-564).  Returns the

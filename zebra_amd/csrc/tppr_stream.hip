@@ -86,6 +86,12 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
                 A.out_nodes[o] = 0; A.out_eidx[o] = 0; A.out_dt[o] = 0.f; A.out_w[o] = 0.f;
             }
         }
+        if (A.member_done != nullptr) {                // batches released one by one: all of them, once every workgroup's rows are out
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0 && atomicAdd(A.member_done + zt::TPPR_MAX_MEMBERS, 1) == (int)gridDim.x - 1)
+                for (int g = 0; g < zt::TPPR_MAX_MEMBERS; ++g) st_agent(A.member_done + g, 0x7fffffff);
+        }
         return;
     }
     __builtin_amdgcn_s_setprio(3);                     // chain hops must not queue behind throughput kernels
@@ -169,8 +175,7 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
         // hop right after publishing, to have the partner's row requested early, was measured too: claims then follow
         // the order of publication -- the same fixed rotation -- and a wave with a long off-chain half holds the chain up.)
         for (;;) {
-            int t = atomicAdd(&mail.head, lane == 0 ? 1 : 0);     // branch-free (see the general dequeue)
-            t = __builtin_amdgcn_readfirstlane(t);
+            const int t = wave_claim_lds(&mail.head, 1);          // one lane's add, no branch (common.hpp)
             if (t >= len) break;
             if (t == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1);   // (the first hop has no mailbox to wait for)
 #define ZT_U(x) __builtin_amdgcn_readfirstlane(x)
@@ -225,14 +230,19 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
 
     // ---- general queue: every (edge, model) task not owned by a chain, in order ----
     const int total = A.B * n_models;
+    // member_done: the batch of the task this wave has just finished, not counted yet.  Counted behind the NEXT dequeue -- its
+    // returning atomic has waited for every store of the task anyway, the emission's write-through stores included -- so the
+    // count costs the queue one wave-level add per task and no wait of its own.
+    int pend = -1;
     for (;;) {
-        // Dequeue with NO divergent branch: every lane issues the add (lane 0
-        // adds 1, the rest 0; the compiler folds it into one wave-level atomic).
-        // An `if (lane == 0)` here gets jump-threaded with lane-0 code at the
-        // end of the previous iteration and the structurizer then replays the
-        // body for the remaining lanes (seen in the ISA).
-        int idx = atomicAdd(h.ctl + 1, lane == 0 ? 1 : 0);
-        idx = __builtin_amdgcn_readfirstlane(idx);
+        // Dequeue with NO divergent branch in the program (an `if (lane == 0)` here gets jump-threaded with lane-0 code at the
+        // end of the previous iteration and the structurizer then replays the body for the remaining lanes: seen in the ISA)
+        // and no scan over the lanes either (what `lane == 0 ? 1 : 0` as the addend compiled to until round 6): common.hpp
+        const int idx = wave_claim_global(h.ctl + 1, 1);
+        if (pend >= 0) {
+            wave_add_global(A.member_done + pend, 1);      // (the claim above has waited for every store of the task: vmcnt(0))
+            pend = -1;
+        }
 #ifdef ZT_CRIT
         if (idx >= total) {                                // diagnostic: when the last general wave left, and who it was
             if (lane == 0) atomicMax((unsigned long long *)&g_crit[8191 * 16 + 0], (unsigned long long)__builtin_readcyclecounter());
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(ZT_STREAM_BOUNDS) void k_stream(zt_tppr h, StreamAr
         if (idx >= total) return;
 #endif
         const int i = idx / n_models;
+        if (A.member_done != nullptr) pend = A.sub_B > 0 ? i / A.sub_B : 0;
         if (A.use_chains && h.owner_of[i] >= 0) {           // its chain applies the hub's update, this wave the rest
             process_chain_partner(h, A, L, lane, i, idx % n_models);
             continue;
@@ -430,7 +441,7 @@ extern "C" int zt_tppr_copy(zt_tppr *dst, const zt_tppr *src, void *stream)
 static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, const long long *eidx,
                      long long role_stride, int B, int n_roles, int emit, int model, long long out_rows, int32_t *on,
                      int32_t *oe, float *od, float *ow, hipStream_t s, bool plan_ordered = false,
-                     hipEvent_t *done_out = nullptr, int sub_B = 0)
+                     hipEvent_t *done_out = nullptr, int sub_B = 0, int *member_done = nullptr)
 {
     zt_tppr::PlanSet &P = h->set[q];
     if (h->epoch >= EPOCH_MAX) {               // launch epoch about to wrap: forget all tags
@@ -470,6 +481,7 @@ static int run_chunk(zt_tppr *h, int q, const int32_t *nodes, const double *ts, 
     sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = out_rows;
     sa.out_nodes = on; sa.out_eidx = oe; sa.out_dt = od; sa.out_w = ow; sa.epoch = h->epoch;
     sa.sub_B = sub_B;
+    sa.member_done = (emit && sub_B > 0) ? member_done : nullptr;
     // two chain positions per critical section (tppr_pair.hpp): bit-exact, 79 % of C5's chain positions pair up -- and slower
     // (the section 4.0-4.4 k clocks against 2 x 2.3 k, its preparation 25 k per pair: DESIGN.md section 5): on request only
     const int chain_choice = zt::kernel_choice(ZT_CHOICE_TPPR_CHAIN);
@@ -524,9 +536,13 @@ bool zt::tppr_chain_mode_compiled(int mode)
 int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_dev, const int64_t *eidx_dev, int64_t B,
                        int32_t n_roles, int32_t emit, int32_t model, int32_t *out_nodes_dev, int32_t *out_eidx_dev,
                        float *out_dt_dev, float *out_w_dev, uint64_t plan_token, void *stream, bool plan_ordered,
-                       hipEvent_t *done_out, int32_t sub_B)
+                       hipEvent_t *done_out, int32_t sub_B, int32_t *member_done_dev)
 {
     if (done_out) *done_out = nullptr;
+    if (member_done_dev != nullptr && (sub_B <= 0 || (B + sub_B - 1) / sub_B > TPPR_MAX_MEMBERS)) {
+        set_error("zt_tppr_stream: batches are released one by one in launches over 2 .. %d batches", TPPR_MAX_MEMBERS);
+        return ZT_ERR_ARG;
+    }
     if (sub_B < 0 || (sub_B > 0 && (B > MAX_CHUNK || sub_B > B))) {
         set_error("zt_tppr_stream: a launch over several batches must fit one chunk (%d edges)", MAX_CHUNK);
         return ZT_ERR_ARG;
@@ -555,7 +571,7 @@ int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_de
                     return ZT_ERR_ARG;
                 }
                 return run_chunk(h, q, nodes_dev, ts_dev, e64, B, (int)B, n_roles, emit, model, (long long)n_roles * B,
-                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s, plan_ordered, done_out, sub_B);
+                                 out_nodes_dev, out_eidx_dev, out_dt_dev, out_w_dev, s, plan_ordered, done_out, sub_B, member_done_dev);
             }
         }
         // the plan is gone (reset / copy / import, or two newer plans): fall through to an inline prepass
@@ -572,7 +588,8 @@ int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_de
         if (rc != ZT_OK) return rc;
         rc = run_chunk(h, q, nodes_dev + c0, ts_dev + c0, e64 + c0, B, bc, n_roles, emit, model,
                        (long long)n_roles * B, emit ? out_nodes_dev + oo : nullptr, emit ? out_eidx_dev + oo : nullptr,
-                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s, true, done_out, sub_B);   // planned on s itself
+                       emit ? out_dt_dev + oo : nullptr, emit ? out_w_dev + oo : nullptr, s, true, done_out, sub_B,
+                       member_done_dev);                                                            // planned on s itself
         if (rc != ZT_OK) return rc;
     }
     return ZT_OK;

@@ -90,8 +90,9 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     the ONE place the choice is made -- bench.py and the per-config parity tests (tests/test_configs_gpu.py)
     both call it, so the tests run exactly the launch configuration that is timed.
     group: as many batches per T-PPR launch as fit (<= 16384 edges, <= 8: a launch's start, tail and the gap to the
-    next one -- ~110 us -- are paid once per launch; C3 0.149 -> 0.141 ms/step from 4 to 8, worse again at 16), fewer for a short region (the first
-    and the last batches of a region are queried one by one, which a 20-step run pays for with large groups);
+    next one -- ~110 us -- are paid once per launch; C3 0.149 -> 0.141 ms/step from 4 to 8, worse again at 16); with
+    ZT_RELEASE_LAUNCH fewer for a short region (the first and the last batches of a region are then queried one by one, which a
+    20-step run pays for with large groups);
     1 for the pruning strategy.  tppr_cus: whole XCDs (32 CUs, one L2 each: a mask that splits an XCD costs the
     aggregation 55-75 %) -- two for the T-PPR stream: 16 hub chains x 2 models + a general queue need 48 workgroups
     (on one XCD only 10 chains fit, measured 0.181 -> 0.153 ms/step on C3); at C5's batch the general queue needs ~53
@@ -102,7 +103,13 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     whole chip."""
     streaming = wl["strategy"] == "streaming"
     if group < 1:
-        group = max(1, min(8, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
+        from . import _capi
+        if _capi.kernel_choice(_capi.CHOICE_GROUP_RELEASE) == _capi.RELEASE_LAUNCH:
+            group = max(1, min(8, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
+        else:
+            # round 6: the batches of a launch are released to the aggregation one by one (pipeline.hip, "release by member"),
+            # so the first and last batches of a short region no longer pay for large groups: full groups whatever `steps` is
+            group = max(1, min(8, 16384 // wl["bs"])) if streaming else 1
     if tppr_cus < 0:
         tppr_cus = 64 if streaming else 0
     return tppr_cus, group
