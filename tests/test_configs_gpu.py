@@ -51,8 +51,19 @@ def _compare_tables(tgn, p, ids=None):
 
 
 def _run(oracle, name, first_batch, fill, nb, steps_for_group, group=-1, tppr_cus=-1, csr_edges=None, touched_only=False,
-         wl=None, perm=7):
-    """Step batches first_batch .. first_batch+fill+nb of workload ``name`` through the pipeline and the oracle."""
+         wl=None, perm=7, by_launch=False):
+    """Step batches first_batch .. first_batch+fill+nb of workload ``name`` through the pipeline and the oracle.
+    by_launch: the aggregation of a batch waits for the END of the T-PPR launch its group shares (ZT_RELEASE_LAUNCH: the form
+    before round 6, whose groups depend on the length of the timed region) instead of for that batch's rows."""
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH if by_launch else 0)
+    try:
+        return _run_inner(oracle, name, first_batch, fill, nb, steps_for_group, group, tppr_cus, csr_edges, touched_only, wl, perm)
+    finally:
+        _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, 0)
+
+
+def _run_inner(oracle, name, first_batch, fill, nb, steps_for_group, group, tppr_cus, csr_edges, touched_only, wl, perm):
     from zebra_amd import synth
     from zebra_amd.tppr import get_neighbor_finder
     wl = wl or synth.WORKLOADS[name]
@@ -117,12 +128,13 @@ def _run(oracle, name, first_batch, fill, nb, steps_for_group, group=-1, tppr_cu
 def test_wikipedia_configs_vs_oracle(oracle, name, steps):
     """C1 (one T-PPR model, alpha 0.1 / beta 0.9: train.py:57) and C2 (two models) at Wikipedia's shape: 9 228 node
     ids, bipartite 8 227 + 1 000, F = 172, bs = 200, k = 20; bench.py's prefill (10 % of the stream = 78 batches), then
-    32 checked batches; launch groups as the 200-step bench run (8 batches per launch) and as the driver's 20-step run (2)
-    choose them."""
+    32 checked batches; launch groups of 8 batches released to the aggregation one by one (what bench.py runs whatever the
+    length of the region, round 6) and, steps = 20, the groups of 2 that the release by launch picks for the driver's 20-step
+    run."""
     from zebra_amd import synth
     wl = synth.WORKLOADS[name]
     fill = (wl["n_edges"] // 10) // wl["bs"]
-    worst, cus, grp = _run(oracle, name, 0, fill, 32, steps)
+    worst, cus, grp = _run(oracle, name, 0, fill, 32, steps, by_launch=steps < 80)
     assert cus == 64 and grp == (8 if steps >= 80 else 2)
 
 
@@ -134,7 +146,7 @@ def test_reddit_config_vs_oracle(oracle, steps):
     from zebra_amd import synth
     wl = synth.WORKLOADS["c3"]
     fill = (wl["n_edges"] // 10) // wl["bs"]
-    worst, cus, grp = _run(oracle, "c3", 0, fill, 30, steps)
+    worst, cus, grp = _run(oracle, "c3", 0, fill, 30, steps, by_launch=steps < 80)
     assert cus == 64 and grp == (8 if steps >= 80 else 2)
 
 
@@ -157,13 +169,14 @@ def test_bench_path_vs_oracle_c5_launch_shapes(oracle, group, perm):
     from zebra_amd import synth
     wl = dict(synth.WORKLOADS["c5"], n_nodes=100_000, n_edges=16 * 4096)
     steps = 20 if group == 2 else 200
-    worst, cus, grp = _run(oracle, "c5 on 100 K nodes", 0, 4, 12, steps, wl=wl, perm=perm)
+    worst, cus, grp = _run(oracle, "c5 on 100 K nodes", 0, 4, 12, steps, wl=wl, perm=perm, by_launch=group == 2)
     assert (cus, grp) == (64, group)
 
 
 def test_wiki_talk_scale_config_vs_oracle(oracle):
     """C5 at FULL size: 10 000 001 node ids (T-PPR state 19.8 GB, memory tables 16 GB), bs = 4096, k = 20, two models,
-    the driver's launch shape (64 CUs, two batches per launch): 6 unchecked + 30 checked batches against the oracle;
-    state and tables compared on the rows the stream touched (the others were never written on either side)."""
+    the driver's launch shape (64 CUs, four batches per launch, released to the aggregation one by one): 6 unchecked + 30
+    checked batches against the oracle; state and tables compared on the rows the stream touched (the others were never written
+    on either side)."""
     worst, cus, grp = _run(oracle, "c5", 0, 6, 30, 20, touched_only=True)
-    assert (cus, grp) == (64, 2)
+    assert (cus, grp) == (64, 4)

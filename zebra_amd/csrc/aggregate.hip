@@ -709,7 +709,8 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
     const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
     long long num_edges, int F, long long N, int M, const int *__restrict__ nbr, const int *__restrict__ eix,
     const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ Wfrag,
-    const float *__restrict__ b1, float *__restrict__ H, float *__restrict__ S, int *status)
+    const float *__restrict__ b1, float *__restrict__ H, float *__restrict__ S, int *status,
+    const int *gate_word, int gate_target, int *gate_latch)
 {
     constexpr int D = 100, T = 100, DP = 112, ROWS = 80, RQ = ROWS / KK;
     static_assert(KK % 4 == 0 && ROWS % KK == 0, "groups of 4 rows must not straddle query rows");
@@ -803,6 +804,9 @@ __global__ __launch_bounds__(AGG_THREADS, 1) void k_fc1_agg_reg(
             for (int c = 0; c < 4; ++c) pf_ef[h][c] = (ok && c < F) ? efeat[(size_t)ei * F + c] : 0.f;
         }
     };
+    // the T-PPR rows of this batch may still be on their way (a launch group released batch by batch: common.hpp,
+    // member_gate): the weights above were requested first, the wait is behind them
+    member_gate_enter(gate_word, gate_target, status, gate_latch);
     if (tile < n_tiles) { fetch(tile); fetch_ef(); }
 
 #pragma nounroll
@@ -1389,7 +1393,7 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
                       const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                       const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
                       const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
-                      zt::embed_out_deferred *defer = nullptr)
+                      zt::embed_out_deferred *defer = nullptr, const zt::member_gate *gate = nullptr)
 {
     if (defer) defer->valid = false;
     if (!memory_dev || !efeat_dev || !wt || !status_dev || N < 0 || D <= 0 || F < 0 || T < 0 || M <= 0 || k <= 0) {
@@ -1448,11 +1452,16 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     const bool regk = tab && D == 100 && T == 100 && F <= 4 && (k == 20 || k == 40) && p.K2p == 112 && !generic;
     // wide edge features (F = 172), D = T = 100, k in {20, 40}: weights resident in LDS (aggregate_wide.hip)
     const bool widek = tab && p.hg > 1 && !generic;
+    // (a wait for this batch's T-PPR rows: inside the two persistent kernels, a one-wave kernel in front of the others)
+    if (gate != nullptr && gate->word != nullptr && !widek && !regk) {
+        const int rc = zt::member_gate_launch(*gate, status_dev, s);
+        if (rc != ZT_OK) return rc;
+    }
     ZT_PROF_BEGIN(s, P_FC1_AGG);
     if (widek) {
         const int rc = fc1_agg_wide_launch(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, N, M, k, nbr_dev, eix_dev,
                                            dt_dev, w_dev, reinterpret_cast<const float *>(ws + p.off_wl), wt->fc1_b, H, S,
-                                           status_dev, stream_cu_count(s), s);
+                                           status_dev, stream_cu_count(s), s, gate);
         if (rc != ZT_OK) return rc;
     } else if (regk) {
         const long long rq = 80 / k, tiles = ((N + rq - 1) / rq) * M;
@@ -1460,10 +1469,13 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
         const int cus = stream_cu_count(s);
         if (wgs > cus) wgs = cus;                                      // persistent: one workgroup (4 waves) per CU
         const size_t reg_lds = 0;
+        const int *gw = gate ? gate->word : nullptr;
+        const int gt = gate ? gate->target : 0;
+        int *gl = gate ? gate->latch : nullptr;
 #ifdef ZT_DIAG
         static const int dbg = getenv("ZT_AGG_DBG") ? atoi(getenv("ZT_AGG_DBG")) : 0;       // diagnostic (wrong results)
 #define ZT_REG_DBG(DB) k_fc1_agg_reg<20, DB><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, \
-            num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev)
+            num_edges, F, N, M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev, gw, gt, gl)
         if (k == 20 && dbg == 1) ZT_REG_DBG(1);
         else if (k == 20 && dbg == 2) ZT_REG_DBG(2);
         else if (k == 20 && dbg == 6) ZT_REG_DBG(6);
@@ -1474,10 +1486,12 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
 #endif
         if (k == 20)
             k_fc1_agg_reg<20><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
-                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev);
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev,
+                                                                 gw, gt, gl);
         else
             k_fc1_agg_reg<40><<<(unsigned)wgs, AGG_THREADS, reg_lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, F, N,
-                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev);
+                                                                 M, nbr_dev, eix_dev, dt_dev, w_dev, Wfrag, wt->fc1_b, H, S, status_dev,
+                                                                 gw, gt, gl);
     } else if (d100) {
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
 #define ZT_D100(KK) k_fc1_agg_d100<KK><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes,     \
@@ -1620,10 +1634,27 @@ int zt::embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_no
                  const int32_t *nbr_dev, const int32_t *eix_dev, const float *dt_dev, const float *w_dev,
                  const zt_embed_weights *wt, float *out_dev, void *workspace_dev, int32_t *status_dev,
                  const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
-                 zt::embed_out_deferred *defer)
+                 zt::embed_out_deferred *defer, const zt::member_gate *gate)
 {
     return embed_impl(memory_dev, efeat_dev, num_nodes, num_edges, D, F, T, nodes_dev, N, M, k, nbr_dev, eix_dev, dt_dev, w_dev,
-                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, mid_wait, defer);
+                      wt, out_dev, workspace_dev, status_dev, proj_table_dev, weights_ready, stream, mid_wait, defer, gate);
+}
+
+// The wait for one batch's T-PPR rows as a kernel of its own: a wave that polls the batch's counter.  The kernel behind it on
+// the stream starts with the acquire every kernel starts with and reads rows that were stored write-through.
+namespace {
+__global__ void k_member_gate(const int *word, int target, int *status, int *latch)
+{
+    if (threadIdx.x == 0) (void)member_gate_wait(word, target, status, latch);
+}
+}  // namespace
+
+int zt::member_gate_launch(const zt::member_gate &g, int32_t *status_dev, void *stream)
+{
+    if (g.word == nullptr) return ZT_OK;
+    k_member_gate<<<1, 64, 0, (hipStream_t)stream>>>(g.word, g.target, status_dev, g.latch);
+    ZT_LAUNCH_CHECK();
+    return ZT_OK;
 }
 
 // Training forward of the neighbour half (backward: aggregate_bwd.hip):

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_fc1_agg_wide(
     const float *__restrict__ P, const float *__restrict__ efeat, const float *__restrict__ time_w, long long num_nodes,
     long long num_edges, long long N, int M, const int *__restrict__ nbr, const int *__restrict__ eix,
     const float *__restrict__ dt, const float *__restrict__ w, const float *__restrict__ Wl, const float *__restrict__ b1,
-    float *__restrict__ G, float *__restrict__ S, int *status)
+    float *__restrict__ G, float *__restrict__ S, int *status, const int *gate_word, int gate_target, int *gate_latch)
 {
     static_assert(KK % 4 == 0 && KK >= 16 && KK <= 64, "groups of 4 rows must not straddle query rows; a tile touches <= 2 query rows");
     constexpr int HG = KK / 4;
@@ -197,6 +197,9 @@ __global__ __launch_bounds__(WIDE_THREADS, 1) void k_fc1_agg_wide(
         const f32x4 v = *reinterpret_cast<const f32x4 *>(Wl + WBIAS_OFF + 8 * r16 + 4 * q);
         bias[4 * q] = v[0]; bias[4 * q + 1] = v[1]; bias[4 * q + 2] = v[2]; bias[4 * q + 3] = v[3];
     }
+    // (the T-PPR rows of this batch may still be on their way -- a launch group released batch by batch, common.hpp:
+    //  member_gate --: the wait sits behind the requests for the weights, in front of the first read of a row)
+    member_gate_enter(gate_word, gate_target, status, gate_latch);
     Scal cur, nxt;
     fetch(tile, cur);
     fetch(tile + stride, nxt);
@@ -378,8 +381,12 @@ void fc1_agg_wide_pack(const float *fc1_w_dev, const float *time_w_dev, const fl
 // H_groups: [M][N][k/4][D] partial sums (k_embed_out adds them); S: [M][N].  cus: compute units of the stream.
 int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w, long long num_nodes, long long num_edges,
                         long long N, int M, int k, const int *nbr, const int *eix, const float *dt, const float *w,
-                        const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s)
+                        const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s,
+                        const member_gate *gate)
 {
+    const int *gw = gate ? gate->word : nullptr;
+    const int gt = gate ? gate->target : 0;
+    int *gl = gate ? gate->latch : nullptr;
     const size_t lds = (size_t)WLDS_PAD * 4;
     static size_t attr[2] = {0, 0};
     const int ki = k == 20 ? 0 : 1;
@@ -395,10 +402,10 @@ int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w,
     if (wgs < 1) wgs = 1;
     if (k == 20)
         k_fc1_agg_wide<20><<<(unsigned)wgs, WIDE_THREADS, lds, s>>>(P, efeat, time_w, num_nodes, num_edges, N, M, nbr, eix, dt, w,
-                                                                    packed, b1, G, S, status);
+                                                                    packed, b1, G, S, status, gw, gt, gl);
     else
         k_fc1_agg_wide<40><<<(unsigned)wgs, WIDE_THREADS, lds, s>>>(P, efeat, time_w, num_nodes, num_edges, N, M, nbr, eix, dt, w,
-                                                                    packed, b1, G, S, status);
+                                                                    packed, b1, G, S, status, gw, gt, gl);
     return ZT_OK;
 }
 

@@ -66,6 +66,16 @@ int store_messages_ex(const float *memory_dev, const float *last_update_dev, con
                       int64_t pos_hi, float *messages_dev, float *msg_ts_dev, uint8_t *flags_dev, int32_t *scratch_dev,
                       int32_t *uniq_ids_dev, int32_t *n_uniq_dev, int32_t *status_dev, int32_t *zero_word_dev, void *stream,
                       bool *zeroed_out = nullptr, bool set_flags = true);
+// The wait for ONE batch's T-PPR rows inside a launch that covers several (pipeline.hip, "release by member"; the counter is
+// tppr_stream_ex's member_done_dev): word == nullptr: none.  The persistent aggregation kernels take it as arguments and wait
+// behind their weight prologue (no packet of its own on the stream); for the others member_gate_launch puts a one-wave kernel
+// in front.
+struct member_gate {
+    const int32_t *word;
+    int32_t target;
+    int *latch;            // host-mapped word a wait that gives up writes ZT_ERR_TIMEOUT to (or NULL)
+};
+int member_gate_launch(const member_gate &g, int32_t *status_dev, void *stream);      // aggregate.hip
 // zt_embed with an event the stream waits for between the aggregation kernel and the output layer (pipeline.hip: the
 // message build; a wait packet right in front of the GRU costs the step ~6 us of command-processor time, here it is
 // processed while the aggregation runs)
@@ -73,7 +83,7 @@ int embed_ex(const float *memory_dev, const float *efeat_dev, int64_t num_nodes,
              const int32_t *nodes_dev, int64_t N, int32_t M, int32_t k, const int32_t *nbr_dev, const int32_t *eix_dev,
              const float *dt_dev, const float *w_dev, const zt_embed_weights *wt, float *out_dev, void *workspace_dev,
              int32_t *status_dev, const float *proj_table_dev, int32_t weights_ready, void *stream, hipEvent_t mid_wait,
-             embed_out_deferred *defer = nullptr);
+             embed_out_deferred *defer = nullptr, const member_gate *gate = nullptr);
 // W_m (the memory columns of fc1, padded to [Dp][Dp]) inside an embed workspace prepared for (N, D, F, T, M, k) (aggregate.hip)
 const float *embed_wm_ptr(void *embed_ws, int64_t N, int32_t D, int32_t F, int32_t T, int32_t M, int32_t k);
 // the persistent aggregate kernel for wide edge features (aggregate_wide.hip: F = 172, weights resident in LDS)
@@ -82,7 +92,8 @@ size_t fc1_agg_wide_weight_bytes();
 void fc1_agg_wide_pack(const float *fc1_w_dev, const float *time_w_dev, const float *fc1_b_dev, float *packed_dev, hipStream_t s);
 int fc1_agg_wide_launch(const float *P, const float *efeat, const float *time_w, long long num_nodes, long long num_edges,
                         long long N, int M, int k, const int *nbr, const int *eix, const float *dt, const float *w,
-                        const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s);
+                        const float *packed, const float *b1, float *G, float *S, int *status, int cus, hipStream_t s,
+                        const member_gate *gate = nullptr);
 int pruned_topk_multi_fill(const zt_csr *c, const int32_t *q_nodes_dev, const double *q_ts_dev, int64_t nq, int32_t width,
                            int32_t depth, int32_t n_models, const double *alpha_host, const double *beta_host, int32_t k,
                            int32_t *out_nodes_dev, int32_t *out_eidx_dev, float *out_dt_dev, float *out_w_dev,
@@ -236,6 +247,38 @@ __device__ __forceinline__ void wave_add_global(int *p, int v)
                  "global_atomic_add %1, %2, off\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(save) : "v"(p), "v"(v) : "memory");
+}
+
+// by ONE thread: poll `word` (agent scope) until it reaches `target`; bounded like every in-kernel wait of the library (4 s of
+// the 100 MHz wall clock), then ZT_ERR_TIMEOUT to the status word and the latch.  false: gave up.
+// SLEEP: 64-clock units between two polls.  Inside the persistent aggregation kernels EVERY workgroup polls the one word:
+// at ~0.3 us a poll, 192 of them kept one memory channel busy with nothing else and k_stream -- whose counters live in that
+// line -- lost 5 % (measured); there a poll every ~4 us (a gate that is open when the kernel arrives costs no sleep at all).
+template <int SLEEP = 8>
+__device__ __forceinline__ bool member_gate_wait(const int *word, int target, int *status, int *latch)
+{
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (ld_agent(word) < target) {
+        __builtin_amdgcn_s_sleep(SLEEP);
+        if ((++spins & (SLEEP >= 64 ? 127u : 1023u)) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > 400000000ll) {
+                atomicExch(status, ZT_ERR_TIMEOUT);
+                if (latch != nullptr) __hip_atomic_store(latch, (int)ZT_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+// a whole workgroup: thread 0 waits, the others wait for it (word == nullptr: nothing, not even the barrier)
+__device__ __forceinline__ void member_gate_enter(const int *word, int target, int *status, int *latch)
+{
+    if (word == nullptr) return;
+    if (threadIdx.x == 0) (void)member_gate_wait<127>(word, target, status, latch);
+    __syncthreads();
 }
 
 // cos(x) for the time encoding.  |x| < 4e6: float32 Cody-Waite reduction with three FMA steps

@@ -143,29 +143,6 @@ __global__ __launch_bounds__(256) void k_avg_topk(const float *__restrict__ w, l
     if (threadIdx.x == 0) *out = rows > 0 ? (float)(part[0] / (double)rows) : 0.f;
 }
 
-// The main stream's wait for ONE member of a launch group: a wave that polls the member's counter (agent scope) until every
-// task of the batch has written its rows.  The kernel behind it on the stream starts with the acquire every kernel starts
-// with and reads rows that were stored write-through.  Bounded like every in-kernel wait of the library (4 s): a launch that
-// never gets there -- it failed, its own waits gave up -- is reported, not waited for.
-__global__ void k_member_gate(const int32_t *word, int target, int *status, int *latch)
-{
-    if (threadIdx.x != 0) return;
-    unsigned spins = 0;
-    long long t0 = 0;
-    while (ld_agent(word) < target) {
-        __builtin_amdgcn_s_sleep(4);
-        if ((++spins & 1023u) == 0) {
-            const long long now = (long long)wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > 400000000ll) {          // 4 s of the 100 MHz wall clock
-                atomicExch(status, ZT_ERR_TIMEOUT);
-                if (latch != nullptr) __hip_atomic_store(latch, (int)ZT_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                return;
-            }
-        }
-    }
-}
-
 bool same_batch(const zt_batch *a, const int64_t *key, int64_t B) { return a->eidx == key && a->B == B; }
 
 zt_pipeline::Slot *find_slot(zt_pipeline *p, const zt_batch *b, int *member)
@@ -236,6 +213,12 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
         add(b);
     }
     if (s.used) ZT_HIP(hipStreamWaitEvent(st, s.consumed, 0));
+    // (released by member, `consumed` says that every batch's rows were written and read -- not that the launch that wrote
+    //  them has ended: its last waves may still be on their way out.  The slot's ids and counters are not touched before it has.)
+    if (s.used && s.by_member && s.launched && hipEventQuery(s.ready_ev) != hipSuccess) {
+        (void)hipGetLastError();
+        ZT_HIP(hipStreamWaitEvent(st, s.ready_ev, 0));
+    }
     // the batches' tensors may have been produced on the caller's stream just before this call (the main stream is
     // ordered behind it): the staging copy must not read them earlier
     // (`entry` was recorded when the step call began -- BEFORE the main stream was told to wait for the current group's
@@ -275,6 +258,14 @@ int launch_tppr(zt_pipeline *p, zt_pipeline::Slot &s, int64_t row_lo, int64_t ro
         int rc = zt::tppr_stream_ex(d.tppr, s.nodes, s.ts, s.eidx, s.Btot, 3, 1, -1, s.on, s.oe, s.od, s.ow, s.token, p->side,
                                     true, &done, s.n > 1 ? (int32_t)s.B[0] : 0, s.by_member ? s.mdone : nullptr);
         if (rc != ZT_OK) return rc;
+        if (s.by_member) {
+            // nobody waits for this launch on the main stream; the slot's NEXT user does (make_group), and for that the plan
+            // set's event will not do -- the launch after next records it again: an event of the slot's own (one packet per
+            // launch group on this stream)
+            ZT_HIP(hipEventRecord(s.ready, p->side));
+            s.launched = true; s.waited = false;
+            return ZT_OK;
+        }
         if (done != nullptr) { s.ready_ev = done; s.launched = true; s.waited = false; return ZT_OK; }
     } else {
         // rows whose dictionary is empty are left untouched by the query (utils/util.py:185): the kernel writes them as zeros
@@ -504,10 +495,21 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     //  the strategy carries no state)
     if (pruning && s->launched && (s->q_lo != row_lo || s->q_hi != row_hi)) s->launched = false;
     if (!s->launched) { rc = launch_tppr(p, *s, row_lo, row_hi); if (rc != ZT_OK) return rc; }
+    // this member's rows, not the launch: one count per (edge, model) task (k_stream's general queue).  Small batches, where
+    // the aggregation is the first reader of the rows on the main stream: the wait rides inside the aggregation kernel
+    // (embed_ex) -- their steps are bound by the main stream, the gate is open when the kernel arrives, and a kernel of its own
+    // in front would be ~13 us of every step (C2 0.083 -> 0.080 ms/step).  Large batches: a one-wave kernel here.  Measured on
+    // C5 (0.296 against 0.305 ms/step at 200 steps): while the main stream waits for the T-PPR update, a persistent aggregation
+    // kernel that is already resident fills all of its compute units' registers, and the prepass kernels of the next launch
+    // group -- on a stream without a CU mask -- are left with the T-PPR stream's compute units, beside the hub chains.
+    zt::member_gate gate = {nullptr, 0, p->latch_dev};
     if (s->by_member) {
-        // this member's rows, not the launch: one count per (edge, model) task (k_stream's general queue)
-        k_member_gate<<<1, 64, 0, p->main_s>>>(s->mdone + j, (int)(s->B[j] * d.M), d.status, p->latch_dev);
-        ZT_LAUNCH_CHECK();
+        gate.word = s->mdone + j; gate.target = (int32_t)(s->B[j] * d.M);
+        if (!(whole && n_rows > 0 && n_rows <= 2048 && p->avg_topk == nullptr)) {
+            rc = zt::member_gate_launch(gate, d.status, p->main_s);
+            if (rc != ZT_OK) return rc;
+            gate.word = nullptr;
+        }
     } else if (!s->waited) { ZT_HIP(hipStreamWaitEvent(p->main_s, s->ready_ev, 0)); s->waited = true; }
     // ---- the group after this one is queried beside this group's aggregation; the one after that is planned ----
     int a = s->n - 1 - j;                     // ahead[0 .. a) are the rest of this group
@@ -594,7 +596,7 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
         //  their tiled forms -- k_out_gru --, otherwise in front of it)
         rc = zt::embed_ex(d.memory, d.efeat, d.num_nodes, d.num_edges, d.D, d.F, d.T, nodes_cur + row_lo, n_rows, d.M, d.k, on, oe,
                           od, ow, &d.ew, out_emb_dev, d.embed_ws, d.status, d.proj_table, p->embed_ready ? 1 : 0, p->main_s,
-                          msgs_waited ? p->msgs_done : nullptr, &p->out_gru);
+                          msgs_waited ? p->msgs_done : nullptr, &p->out_gru, gate.word ? &gate : nullptr);
         if (rc != ZT_OK) return rc;
         p->embed_ready = true;
     }
