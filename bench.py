@@ -339,6 +339,9 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
     # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
     # its real shape against the oracle with exactly these settings)
     _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH if a.release_by_launch else 0)
+    for kv in a.choice:
+        which, value = kv.split("=")
+        _capi.set_kernel_choice(int(which), int(value))
     tppr_cus, group = synth.pipeline_settings(wl, steps, a.tppr_cus if headline else -1, a.group if headline else -1)
     no_pipeline = a.no_pipeline and headline
     if not no_pipeline:
@@ -943,6 +946,9 @@ def main():
                     help="one Python call per step (TGN.step_device) instead of the library's batch loop (TGN.run_device)")
     ap.add_argument("--chain-mode", type=int, default=0,
                     help="hub chains of the T-PPR update: 0 the library's pick, 1 single hops through the mailbox, 3 spine (zt_set_kernel_choice)")
+    ap.add_argument("--choice", action="append", default=[], metavar="SELECTOR=VALUE",
+                    help="zt_set_kernel_choice(SELECTOR, VALUE) before the run (A/B of kernels that compute the same function; "
+                         "numbers as in include/zebra_amd.h), repeatable")
     ap.add_argument("--release-by-launch", action="store_true",
                     help="the aggregation of a batch waits for the END of the T-PPR launch its group shares (the form before round 6, "
                          "with tapering groups) instead of for that batch's rows (A/B)")
