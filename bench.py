@@ -338,7 +338,8 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
 
     # the launch configuration: ONE function, shared with tests/test_configs_gpu.py (which runs every BASELINE config at
     # its real shape against the oracle with exactly these settings)
-    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH if a.release_by_launch else 0)
+    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH_FULL if a.release_by_launch_full else
+                            (_capi.RELEASE_LAUNCH if a.release_by_launch else 0))
     for kv in a.choice:
         which, value = kv.split("=")
         _capi.set_kernel_choice(int(which), int(value))
@@ -749,7 +750,7 @@ def run_workload(a, name, steps, warmup, world, rank, device, headline, cpu_edge
                                                                    "power-law", wl["n_nodes"], bs, k, wl["alpha"],
                                                                    wl["beta"], wl["strategy"], F, prefill, warmup),
                    "global_batch": bs, "tppr_launch_group": group, "tppr_cus": tppr_cus,
-                   "tppr_group_release": "launch (event)" if a.release_by_launch else "member (a counter per batch inside the launch)",
+                   "tppr_group_release": "launch (event)" if (a.release_by_launch or a.release_by_launch_full) else "member (a counter per batch inside the launch)",
                    "clock_spin": spun, "step_loop": "native (zt_pipeline_run)" if native else "python",
                    "row_exchange": None if xchg is None else ("in the native step: %s, %d rank%s, [id | memory row | last_update] per touched row"
                                                                % ("RCCL ncclAllGather" if xchg == "rccl" else "shared memory (ranks share one GPU)",
@@ -952,6 +953,9 @@ def main():
     ap.add_argument("--release-by-launch", action="store_true",
                     help="the aggregation of a batch waits for the END of the T-PPR launch its group shares (the form before round 6, "
                          "with tapering groups) instead of for that batch's rows (A/B)")
+    ap.add_argument("--release-by-launch-full", action="store_true",
+                    help="release by launch in full, untapered groups: uniform T-PPR launches for counter passes (rocprofv3 --pmc "
+                         "serialises kernels, so the release by member cannot run under it)")
     ap.add_argument("--prepass-coop", action="store_true", help="the dependency prepass of big launches as ONE cooperative kernel (A/B against the eleven launches)")
     ap.add_argument("--chain-pairs", action="store_true",
                     help="hub chains take TWO positions per critical section where they can (csrc/tppr_pair.hpp; zt_set_kernel_choice: "

@@ -72,7 +72,9 @@ int zt_stream_destroy(void *stream);
 #define ZT_CHOICE_GROUP_RELEASE 6 /* zt_pipeline_*: when the aggregation of a batch may start whose streaming T-PPR update shares a launch
                                  * with other batches.  ZT_RELEASE_MEMBER: as soon as that batch's rows are written (a counter per batch
                                  * inside the launch: the library's pick); ZT_RELEASE_LAUNCH: when the whole launch has ended (an event;
-                                 * launch groups then taper towards the end of the batches in sight) */
+                                 * launch groups then taper towards the end of the batches in sight); ZT_RELEASE_LAUNCH_FULL: the
+                                 * same without the taper (uniform launches for counter collection, which serialises kernels and so
+                                 * cannot run a release by member: tools/profile_round.sh) */
 #define ZT_CHOICE_COUNT 7
 #define ZT_AGG_GENERIC 1
 #define ZT_OUT_TILED 1
@@ -88,6 +90,7 @@ int zt_stream_destroy(void *stream);
 #define ZT_PREPASS_COOP 2
 #define ZT_RELEASE_MEMBER 1
 #define ZT_RELEASE_LAUNCH 2
+#define ZT_RELEASE_LAUNCH_FULL 3
 #define ZT_MSG_ONE 1
 #define ZT_MSG_TWO 2
 int zt_set_kernel_choice(int32_t which, int32_t value);

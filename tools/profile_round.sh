@@ -13,27 +13,34 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_r6_$WL
 rm -rf $O && mkdir -p $O
 CMD="bench.py --workload $WL --steps $STEPS --warmup $WARM --legs none --cpu-edges 0 --no-score --steady-steps 0"
+# Counter passes SERIALISE kernels: a kernel that waits for a kernel of another stream -- the gate that releases a T-PPR launch
+# group to the aggregation batch by batch (pipeline.hip) -- never sees it run (the first attempt, with hipStreamWaitValue32 as
+# the gate, hung; the bounded gate gives up after 4 s per step).  The counter passes therefore release by launch, in the
+# launch groups the timed run uses (C5: 4 batches, C2 / C3: 8); the kernel trace above them is the timed configuration itself.
+# (ZT_RELEASE_LAUNCH_FULL: no taper; the first batch of a region goes alone, so 1 + n full groups: 21 steps for C5, 97 for the others)
+case $WL in c5) PSTEPS=21; PLAST=5;; c2|c3|c1) PSTEPS=97; PLAST=10;; *) PSTEPS=$STEPS; PLAST=$LAST;; esac
+PMC_CMD="bench.py --workload $WL --steps $PSTEPS --warmup $WARM --legs none --cpu-edges 0 --no-score --steady-steps 0 --release-by-launch-full --no-profile"
 RE='k_stream|k_fc1_agg|k_gru|k_out_gru|k_embed_out|k_build_messages|k_last_pos|k_pruned_topk|k_affinity'
 RE_WIDE="$RE|k_deps|k_own|k_reserve|k_hot_select|k_count|k_fill|k_hubacc|k_prepass_fused|k_cleanup"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $CMD > $O/bench_under_rocprof.json 2> $O/kt.err
 echo "[profile] kernel trace rc=$?"
 python3 profiles/summarize.py $O/kt/kt_kernel_trace.csv $STEPS > $O/kernel_trace_summary.txt 2>> $O/kt.err
 cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RE_WIDE" -d $O/f -o f --output-format csv -- python3 -X faulthandler $CMD --no-profile > $O/f.log 2> $O/f_wide.err
+timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RE_WIDE" -d $O/f -o f --output-format csv -- python3 -X faulthandler $PMC_CMD > $O/f.log 2> $O/f_wide.err
 RC=$?; echo "[profile] FETCH_SIZE (timed step + prepass kernels) rc=$RC"
 if [ $RC -ne 0 ]; then
   rm -rf $O/f
-  timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RE" -d $O/f -o f --output-format csv -- python3 -X faulthandler $CMD --no-profile > $O/f.log 2> $O/f.err
+  timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$RE" -d $O/f -o f --output-format csv -- python3 -X faulthandler $PMC_CMD > $O/f.log 2> $O/f.err
   echo "[profile] FETCH_SIZE (timed step only) rc=$?"
 fi
-timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$RE" -d $O/w -o w --output-format csv -- python3 -X faulthandler $CMD --no-profile > $O/w.log 2> $O/w.err
+timeout -k 10 900 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$RE" -d $O/w -o w --output-format csv -- python3 -X faulthandler $PMC_CMD > $O/w.log 2> $O/w.err
 echo "[profile] WRITE_SIZE rc=$?"
-python3 profiles/make_pmc_summary.py $O/f/f_counter_collection.csv $O/w/w_counter_collection.csv $LAST $WL $O/f.log $COMMIT > $O/pmc_summary.json 2> $O/pmc_summary.err
-timeout -k 10 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "$RE" -d $O/sq -o sq --output-format csv -- python3 -X faulthandler $CMD --no-profile > $O/sq.log 2> $O/sq.err
+python3 profiles/make_pmc_summary.py $O/f/f_counter_collection.csv $O/w/w_counter_collection.csv $PLAST $WL $O/f.log $COMMIT > $O/pmc_summary.json 2> $O/pmc_summary.err
+timeout -k 10 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-include-regex "$RE" -d $O/sq -o sq --output-format csv -- python3 -X faulthandler $PMC_CMD > $O/sq.log 2> $O/sq.err
 echo "[profile] SQ rc=$?"
-python3 profiles/make_sq_summary.py $O/sq/sq_counter_collection.csv $LAST $WL > $O/sq_summary.json 2> $O/sq_summary.err
+python3 profiles/make_sq_summary.py $O/sq/sq_counter_collection.csv $PLAST $WL > $O/sq_summary.json 2> $O/sq_summary.err
 if [ -n "$CRASH" ]; then
-  ZT_DUMP_MAPS=$O/crash_maps.txt timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE -d $O/fa -o fa --output-format csv -- python3 -X faulthandler $CMD --no-profile > $O/fa.log 2> $O/crash_all_dispatches.err
+  ZT_DUMP_MAPS=$O/crash_maps.txt timeout -k 10 900 rocprofv3 --pmc FETCH_SIZE -d $O/fa -o fa --output-format csv -- python3 -X faulthandler $PMC_CMD > $O/fa.log 2> $O/crash_all_dispatches.err
   echo "[profile] FETCH_SIZE, every dispatch instrumented rc=$?"
   python3 tools/symbolise.py $O/crash_maps.txt $O/crash_all_dispatches.err > $O/crash_all_dispatches_symbolised.txt 2>&1
   rm -rf $O/fa

@@ -35,7 +35,7 @@ SYMBOLS = [
 # zt_set_kernel_choice selectors / values (include/zebra_amd.h)
 CHOICE_AGGREGATE, CHOICE_EMBED_OUT, CHOICE_GRU, CHOICE_MESSAGES, CHOICE_TPPR_CHAIN, CHOICE_TPPR_PREPASS = 0, 1, 2, 3, 4, 5
 CHOICE_GROUP_RELEASE = 6
-RELEASE_MEMBER, RELEASE_LAUNCH = 1, 2
+RELEASE_MEMBER, RELEASE_LAUNCH, RELEASE_LAUNCH_FULL = 1, 2, 3
 PREPASS_LAUNCHES, PREPASS_COOP = 1, 2
 CHAIN_SINGLE, CHAIN_PAIRED, CHAIN_SPINE, CHAIN_DUO = 1, 2, 3, 4
 AGG_GENERIC = 1

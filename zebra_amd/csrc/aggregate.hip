@@ -1652,26 +1652,11 @@ __global__ void k_member_gate(const int *word, int target, int *status, int *lat
 int zt::member_gate_launch(const zt::member_gate &g, int32_t *status_dev, void *stream)
 {
     if (g.word == nullptr) return ZT_OK;
-    // The command processor can do the waiting itself (hipStreamWaitValue32 on plain device memory, CU-masked streams included:
-    // tools/exp/waitvalue_probe.hip -- it sees the word within ~6 us of the store, and a wait that is satisfied on arrival costs
-    // ~2.5 us between two kernels where the one-wave kernel costs its launch and two kernel boundaries, ~13 us).  Such a wait has
-    // no time limit of its own; it needs none: every (edge, model) task of a launch is counted whether its own bounded waits
-    // held or gave up (k_stream counts a task when its wave comes back for the next one), and a rejected launch opens every
-    // counter -- the word reaches the target whenever the launch ends.
-    static int can_wait = -1;
-    if (can_wait < 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) v = 0;
-        (void)hipGetLastError();
-        can_wait = v ? 1 : 0;
-    }
-    if (can_wait == 1) {
-        if (hipStreamWaitValue32((hipStream_t)stream, const_cast<int32_t *>(g.word), (uint32_t)g.target, hipStreamWaitValueGte,
-                                 0xffffffffu) == hipSuccess)
-            return ZT_OK;
-        (void)hipGetLastError();
-        can_wait = 0;                                   // (refused after all: the kernel from here on)
-    }
+    // (The command processor could do the waiting itself -- hipStreamWaitValue32 works on plain device memory and on CU-masked
+    //  streams, tools/exp/waitvalue_probe.hip, and the runtime implements it as a one-wave kernel of its own: measured, the step
+    //  is the same to within the noise.  But that wait has no time limit, and a tool that serialises kernels -- rocprofv3's
+    //  counter mode -- turns it into a hang where this kernel gives up after 4 s and reports.  Every wait of the library is
+    //  bounded; so is this one.)
     k_member_gate<<<1, 64, 0, (hipStream_t)stream>>>(g.word, g.target, status_dev, g.latch);
     ZT_LAUNCH_CHECK();
     return ZT_OK;

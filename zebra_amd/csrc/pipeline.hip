@@ -26,7 +26,8 @@
 // status word and the pipeline's latch) instead of waiting for the launch's event.  So the main stream follows the T-PPR
 // stream at a distance of ONE batch whatever the group size: no tapering of the groups towards the end of the batches in
 // sight, and a short timed region runs in the launch groups of a long one.  ZT_CHOICE_GROUP_RELEASE = ZT_RELEASE_LAUNCH
-// brings the event (and the taper) back.
+// brings the event (and the taper) back -- also what a tool that SERIALISES kernels needs (rocprofv3's counter mode: a kernel
+// that waits for a kernel of another stream never sees it run; the gate then gives up after 4 s and reports).
 #include "common.hpp"
 
 #include <cstring>
@@ -46,6 +47,7 @@ struct zt_pipeline {
     hipStream_t msg_s;         // the message build of the current batch, beside its aggregation (reads the memory tables only)
     hipEvent_t step_begin, msgs_done;
     int group;                 // batches per T-PPR launch (streaming)
+    bool masked;               // the T-PPR stream and the main stream own disjoint compute units (zt_pipeline_create: tppr_cus > 0)
     struct Slot {
         int32_t *nodes;        // [3 * cap]   src of every member | dst ... | neg ...   (role stride = Btot)
         int32_t *nodes_m;      // [3 * cap]   per member: [src | dst | neg] of that batch (what zt_embed / the GRU read)
@@ -202,8 +204,9 @@ int make_group(zt_pipeline *p, const zt_batch *first, const zt_batch *more, int 
     // run ended with a two-batch launch and two aggregations behind it) and the aggregation of each runs beside the update
     // of the next.  A full group needs want + 1 followers in sight (synth.pipeline_look).
     // (round 6: with the batches of a launch released one by one -- see the top of the file -- neither holds: no taper)
-    const bool by_member = streaming && zt::kernel_choice(ZT_CHOICE_GROUP_RELEASE) != ZT_RELEASE_LAUNCH;
-    if (!by_member && n_more <= want) want = n_more >= 2 ? n_more - 1 : 1;
+    const int release = zt::kernel_choice(ZT_CHOICE_GROUP_RELEASE);
+    const bool by_member = streaming && release != ZT_RELEASE_LAUNCH && release != ZT_RELEASE_LAUNCH_FULL;
+    if (!by_member && release != ZT_RELEASE_LAUNCH_FULL && n_more <= want) want = n_more >= 2 ? n_more - 1 : 1;
     for (int q = 0; streaming && q < n_more && g.n < want; ++q) {
         const zt_batch *b = more + q;
         // members are equally long, except that the last one may be shorter; everything fits one launch and the slot
@@ -316,6 +319,7 @@ extern "C" int zt_pipeline_create(zt_pipeline **out, const zt_pipeline_desc *des
             return rc;
         }
         p->side = (hipStream_t)a; p->main_s = (hipStream_t)b; p->msg_s = (hipStream_t)c;
+        p->masked = true;
     } else {
         ZT_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
         ZT_HIP(hipStreamCreateWithFlags(&p->main_s, hipStreamNonBlocking));
@@ -498,14 +502,17 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // this member's rows, not the launch: one count per (edge, model) task (k_stream's general queue).  Small batches, where
     // the aggregation is the first reader of the rows on the main stream: the wait rides inside the aggregation kernel
     // (embed_ex) -- their steps are bound by the main stream, the gate is open when the kernel arrives, and a kernel of its own
-    // in front would be ~13 us of every step (C2 0.083 -> 0.080 ms/step).  Large batches: a one-wave kernel here.  Measured on
+    // in front would be ~13 us of every step (C2 0.083 -> 0.080 ms/step).  Large batches: a one-wave kernel here (bounded wait,
+    // ZT_ERR_TIMEOUT to the status word and the pipeline's latch: aggregate.hip, member_gate_launch).  Measured on
     // C5 (0.296 against 0.305 ms/step at 200 steps): while the main stream waits for the T-PPR update, a persistent aggregation
     // kernel that is already resident fills all of its compute units' registers, and the prepass kernels of the next launch
     // group -- on a stream without a CU mask -- are left with the T-PPR stream's compute units, beside the hub chains.
     zt::member_gate gate = {nullptr, 0, p->latch_dev};
     if (s->by_member) {
         gate.word = s->mdone + j; gate.target = (int32_t)(s->B[j] * d.M);
-        if (!(whole && n_rows > 0 && n_rows <= 2048 && p->avg_topk == nullptr)) {
+        // (inside the kernel only where the T-PPR stream has compute units of its own: a persistent aggregation kernel that
+        //  waits on EVERY compute unit of an unmasked device, registers full, would keep out the very launch it waits for)
+        if (!(p->masked && whole && n_rows > 0 && n_rows <= 2048 && p->avg_topk == nullptr)) {
             rc = zt::member_gate_launch(gate, d.status, p->main_s);
             if (rc != ZT_OK) return rc;
             gate.word = nullptr;

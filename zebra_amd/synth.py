@@ -104,7 +104,7 @@ def pipeline_settings(wl, steps, tppr_cus=-1, group=-1):
     streaming = wl["strategy"] == "streaming"
     if group < 1:
         from . import _capi
-        if _capi.kernel_choice(_capi.CHOICE_GROUP_RELEASE) == _capi.RELEASE_LAUNCH:
+        if _capi.kernel_choice(_capi.CHOICE_GROUP_RELEASE) == _capi.RELEASE_LAUNCH:       # (RELEASE_LAUNCH_FULL: full groups, as by member)
             group = max(1, min(8, 16384 // wl["bs"], max(1, steps // 10))) if streaming else 1
         else:
             # round 6: the batches of a launch are released to the aggregation one by one (pipeline.hip, "release by member"),
