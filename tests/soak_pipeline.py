@@ -35,6 +35,13 @@ def one(seed, torch, pyoracle):
     group = int(rng.choice([1, 2, 3, 4]))
     cus = int(rng.choice([0, 32, 64, 96]))
     look = int(rng.randint(0, 3 * group + 2))
+    # (round 6; drawn AFTER the variables above so that the earlier rounds' seeds keep their configurations) how a launch group
+    # reaches the aggregation: by member (the library's pick: the gate inside the aggregation kernel or as a one-wave kernel,
+    # by batch size and CU masks) or by launch; now and then groups of 8
+    rng2 = np.random.RandomState(seed + 777)
+    by_launch = rng2.random_sample() < 0.25
+    if rng2.random_sample() < 0.2:
+        group, look = 8, int(rng2.randint(0, 27))
     ragged = rng.random_sample() < 0.3
     perm = None if rng.random_sample() < 0.5 else int(rng.randint(1, 100))
     strategy = "pruning" if rng.random_sample() < 0.3 else "streaming"
@@ -42,6 +49,7 @@ def one(seed, torch, pyoracle):
     E = bs * nb - (int(rng.randint(1, bs)) if ragged and bs > 1 else 0)
     tag = "seed %d: %s N=%d bs=%d nb=%d E=%d k=%d D=%d T=%d F=%d M=%d beta=%s group=%d cus=%d look=%d perm=%s width=%d depth=%d" % (
         seed, strategy, N, bs, nb, E, k, D, T, F, M, be, group, cus, look, perm, width, depth)
+    tag += " release=%s" % ("launch" if by_launch else "member")
     if os.environ.get("ZT_SOAK_VERBOSE"):
         print(tag, flush=True)
     bip = (max(1, N // 3), N - max(1, N // 3)) if rng.randint(2) else None
@@ -60,6 +68,8 @@ def one(seed, torch, pyoracle):
         nf = get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
         ref_nf = pyoracle.CsrOracle(src, dst, eidx, ts, N + 1)
     tgn = build_tgn(N + 1, E + 1, D, F, T, k, al, be, w, efeat, strategy=strategy, nf=nf, width=width, depth=depth).eval()
+    from zebra_amd import _capi
+    _capi.set_kernel_choice(_capi.CHOICE_GROUP_RELEASE, _capi.RELEASE_LAUNCH if by_launch else 0)
     tgn.enable_pipeline(tppr_cus=cus, group=group, max_batch=max(bs, 64))
     p = pyoracle.ProtocolOracle(N + 1, D, F, T, k, al, be, w, efeat, tw, strategy, ref_nf, width, depth, n_threads=8)
     embs = []
