@@ -37,7 +37,12 @@ extern "C" {
 #define ZT_ERR_UNSUPPORTED (-4) /* shape outside what the kernels were built for */
 #define ZT_ERR_TIMEOUT (-5)     /* an in-kernel dependency wait hit its spin bound */
 
-#define ZT_MAX_K 63             /* top-k width supported by the wave-level merge */
+#define ZT_MAX_K 63             /* top-k width of the tuned paths: one dictionary entry per lane of a wavefront (streaming update with
+                                 * hub chains, pruning query) */
+#define ZT_MAX_K_WIDE 255       /* streaming T-PPR accepts k up to here (the reference's --topk is unbounded, train.py:46): beyond
+                                 * ZT_MAX_K a correct-first path takes over -- one wavefront per model applies the edges in order
+                                 * (csrc/tppr_wide.hpp), same state layout, same results as the oracle bit for bit, not tuned.  The
+                                 * aggregation takes k <= 80 (one query row per workgroup tile); the pruning strategy k <= ZT_MAX_K */
 
 /* Human-readable description of the last failure on this thread. */
 const char *zt_last_error(void);

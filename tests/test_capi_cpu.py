@@ -33,8 +33,8 @@ def test_bad_arguments_fail_without_gpu(capi):
     h = C.c_void_p()
     a = np.array([0.1]); b = np.array([0.9])
     assert lib.zt_tppr_create(C.byref(h), C.c_int64(0), C.c_int32(5), C.c_int32(1), capi.ptr(a), capi.ptr(b)) == capi.ZT_ERR_ARG
-    assert lib.zt_tppr_create(C.byref(h), C.c_int64(10), C.c_int32(64), C.c_int32(1), capi.ptr(a), capi.ptr(b)) == capi.ZT_ERR_UNSUPPORTED
-    assert b"k=64" in lib.zt_last_error()
+    assert lib.zt_tppr_create(C.byref(h), C.c_int64(10), C.c_int32(256), C.c_int32(1), capi.ptr(a), capi.ptr(b)) == capi.ZT_ERR_UNSUPPORTED
+    assert b"k=256" in lib.zt_last_error()
     with pytest.raises(ValueError):
         capi.check(capi.ZT_ERR_UNSUPPORTED)
     with pytest.raises(IndexError):

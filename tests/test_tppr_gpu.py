@@ -248,6 +248,55 @@ def test_fill_and_snapshots(zt):
     dict(N=400, E=12288, bs=4096, k=31, al=[0.2, 0.0], be=[0.95, 0.5], kind="hub", seed=106),   # ... and the first without
 ])
 def test_streaming_vs_oracle(zt, oracle, cfg):
+    _streaming_vs_oracle(zt, oracle, cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=300, E=3000, bs=200, k=64, al=[0.1, 0.0], be=[0.5, 0.95], kind="hub", seed=201),       # the first k beyond a wavefront; exact ties
+    dict(N=60, E=2400, bs=600, k=100, al=[0.2], be=[0.5], kind="general", seed=202),               # dense: rows fill, 2k + 1 = 201 candidates
+    dict(N=40, E=3000, bs=1000, k=255, al=[0.1, 0.1], be=[0.25, 0.8], kind="general", seed=203),   # the widest: up to 511 candidates
+    dict(N=500, E=1500, bs=500, k=80, al=[0.1], be=[0.9], kind="bipartite", seed=204),             # sparse: rows never fill
+])
+def test_streaming_wide_k_vs_oracle(zt, oracle, cfg):
+    """k beyond ZT_MAX_K (the reference's --topk is unbounded, train.py:46): the one-wavefront-per-model path
+    (csrc/tppr_wide.hpp) against the oracle -- every batch's four output arrays and the final state bit-identical; beta = 0.5 /
+    0.25 scale exactly (ties decide the top k: numba's argsort order over up to 2k + 1 candidates), alpha = 0, self-loops and
+    negatives equal to endpoints come with the stream kinds.  Then the finder's other entry points on the same handle:
+    no_fake, single model, backup / restore, export -> import."""
+    _streaming_vs_oracle(zt, oracle, cfg)
+    src, dst, neg, ts, eidx = I.make_stream(cfg["kind"], cfg["N"], cfg["E"], cfg["seed"])
+    al, be, k, N = cfg["al"], cfg["be"], cfg["k"], cfg["N"]
+    f = zt.tppr_finder(N, k, len(al), al, be)
+    o = oracle.TpprOracle(N, k, len(al), al, be)
+    n1 = min(400, cfg["E"] // 2)
+    two = np.concatenate([src[:n1], dst[:n1]])
+    a, b = f.streaming_topk_no_fake(two, ts[:n1], eidx[:n1]), o.streaming_topk_no_fake(two, ts[:n1], eidx[:n1])
+    for x, y in zip(a, b):
+        assert np.array_equal(np.stack(x), np.stack(y))
+    bk = f.backup_tppr()
+    three = np.concatenate([src[n1:2 * n1], dst[n1:2 * n1], neg[n1:2 * n1]])
+    a = f.single_streaming_topk(three, ts[n1:2 * n1], eidx[n1:2 * n1], 0)
+    b = o.single_streaming_topk(three, ts[n1:2 * n1], eidx[n1:2 * n1], 0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for m in range(len(al)):
+        _cmp_state(f.export_state(m), o.export(m), "model %d" % m)
+    st = f.state_dict(np.arange(N))
+    f2 = zt.tppr_finder(N, k, len(al), al, be)
+    f2.load_state_dict(st)
+    for m in range(len(al)):
+        _cmp_state(f2.export_state(m), o.export(m), "model %d after import" % m)
+    f.restore_tppr(bk)
+    a = f.single_streaming_topk(three, ts[n1:2 * n1], eidx[n1:2 * n1], 0)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    with pytest.raises(IndexError):                                # a rejected launch: state untouched, reported
+        f.streaming_topk(np.array([1, 2, N + 3], np.int32), np.array([1.0]), np.array([1], np.int64))
+    for m in range(len(al)):
+        _cmp_state(f.export_state(m), o.export(m), "model %d after a rejected call" % m)
+
+
+def _streaming_vs_oracle(zt, oracle, cfg):
     """Seeded streams at sizes the oracle finishes in seconds: every batch's
     four output arrays and the final state must be bit-identical."""
     src, dst, neg, ts, eidx = I.make_stream(cfg["kind"], cfg["N"], cfg["E"], cfg["seed"])
@@ -285,7 +334,7 @@ def test_streaming_edge_cases(zt, oracle):
     for x, y in zip(a, b):
         assert np.array_equal(np.stack(x), np.stack(y))
     with pytest.raises(ValueError):
-        zt.tppr_finder(20, 64, 1, [0.1], [0.9])                    # k > ZT_MAX_K
+        zt.tppr_finder(20, 256, 1, [0.1], [0.9])                   # k > ZT_MAX_K_WIDE
 
 
 @pytest.mark.parametrize("name", list(I.PRUNE_CASES))

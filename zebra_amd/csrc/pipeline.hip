@@ -433,7 +433,7 @@ extern "C" int zt_pipeline_set_exchange(zt_pipeline *p, zt_exchange *x)
 extern "C" int zt_pipeline_set_group(zt_pipeline *p, int32_t group)
 {
     if (!p || group < 1 || group > MAX_GROUP) { set_error("zt_pipeline_set_group: 1 <= group <= %d", MAX_GROUP); return ZT_ERR_ARG; }
-    p->group = group;
+    p->group = p->d.k > ZT_MAX_K ? 1 : group;        // (dictionaries wider than a wavefront: one batch per T-PPR launch, tppr_wide.hpp)
     return ZT_OK;
 }
 

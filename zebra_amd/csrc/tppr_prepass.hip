@@ -517,6 +517,7 @@ extern "C" int zt_tppr_plan(zt_tppr *h, const int32_t *nodes_dev, const int64_t 
     }
     if (int st = latched(h, "zt_tppr_plan")) return st;
     if (B == 0 || B > MAX_CHUNK) return ZT_OK;      // nothing to prepare / a multi-launch call plans inline
+    if (h->k > ZT_MAX_K) return ZT_OK;              // (dictionaries wider than a wavefront: tppr_wide.hpp has no prepass)
     if (!nodes_dev || !eidx_dev) { set_error("zt_tppr_plan: NULL buffer"); return ZT_ERR_ARG; }
     const int q = h->next_set;
     h->next_set ^= 1;

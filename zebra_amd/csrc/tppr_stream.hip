@@ -48,6 +48,8 @@
 #include "tppr_chain.hpp"
 #endif
 
+#include "tppr_wide.hpp"                 // ZT_MAX_K < k <= ZT_MAX_K_WIDE: one wavefront per model, edges in order
+
 #include <cstdlib>
 #include <vector>
 
@@ -278,8 +280,8 @@ extern "C" int zt_tppr_create(zt_tppr **out, int64_t num_nodes, int32_t k, int32
         set_error("zt_tppr_create: bad argument");
         return ZT_ERR_ARG;
     }
-    if (k > ZT_MAX_K || n_tppr > 16) {
-        set_error("zt_tppr_create: k=%d (max %d) or n_tppr=%d (max 16) unsupported", k, ZT_MAX_K, n_tppr);
+    if (k > ZT_MAX_K_WIDE || n_tppr > 16) {
+        set_error("zt_tppr_create: k=%d (max %d) or n_tppr=%d (max 16) unsupported", k, ZT_MAX_K_WIDE, n_tppr);
         return ZT_ERR_UNSUPPORTED;
     }
     zt_tppr *h = new zt_tppr();
@@ -560,6 +562,26 @@ int zt::tppr_stream_ex(zt_tppr *h, const int32_t *nodes_dev, const double *ts_de
     }
     hipStream_t s = (hipStream_t)stream;
     const long long *e64 = reinterpret_cast<const long long *>(eidx_dev);
+    if (h->k > ZT_MAX_K) {
+        // dictionaries wider than a wavefront (tppr_wide.hpp): the ids are checked, then one wavefront per model applies the
+        // whole call's edges in order -- no prepass, no plan sets, no launch groups (a caller's sub_B is a single batch here)
+        if (sub_B > 0 && sub_B < B) { set_error("zt_tppr_stream: k=%d takes one batch per launch", h->k); return ZT_ERR_UNSUPPORTED; }
+        if (B > 0x7fffffffll / 3) { set_error("zt_tppr_stream: batch too large"); return ZT_ERR_ARG; }
+        use_set(h, 0);
+        k_wide_begin<<<1, 64, 0, s>>>(h->ctl);
+        k_wide_check<<<(unsigned)((B * n_roles + 255) / 256 < 1024 ? (B * n_roles + 255) / 256 : 1024), 256, 0, s>>>(
+            nodes_dev, e64, B, (int)B, n_roles, h->N, h->ctl, h->latch_dev);
+        StreamArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.nodes = nodes_dev; sa.tsv = ts_dev; sa.eidx = e64; sa.role_stride = B; sa.B = (int)B; sa.n_roles = n_roles;
+        sa.emit = emit; sa.m_lo = model < 0 ? 0 : model; sa.n_models = model < 0 ? h->M : 1; sa.out_rows = (long long)n_roles * B;
+        sa.out_nodes = out_nodes_dev; sa.out_eidx = out_eidx_dev; sa.out_dt = out_dt_dev; sa.out_w = out_w_dev;
+        ZT_PROF_BEGIN(s, P_STREAM);
+        k_stream_wide<<<sa.n_models, WAVE, 0, s>>>(*h, sa);
+        ZT_PROF_END(s, P_STREAM);
+        ZT_LAUNCH_CHECK();
+        return ZT_OK;
+    }
     // a prepass made ahead of time by zt_tppr_plan for exactly this call: the caller hands back the token
     // that plan returned (a recycled device address alone must never select a stale plan)
     if (plan_token != 0) {
