@@ -90,6 +90,10 @@ def test_embeddings_golden_all_batches():
     dict(N=3000, E=6000, F=172, bs=200, k=20, al=[0.1, 0.1], be=[0.5, 0.95], warm=4000, nb=6, seed=201),
     dict(N=5000, E=9000, F=1, bs=512, k=20, al=[0.1, 0.1], be=[0.5, 0.95], warm=5000, nb=5, seed=202),
     dict(N=800, E=4000, F=4, bs=100, k=40, al=[0.2], be=[0.8], warm=3000, nb=5, seed=203),
+    # k beyond a wavefront (train.py:46 puts no bound on --topk): the wide streaming path (csrc/tppr_wide.hpp) feeding the
+    # generic aggregation kernel, whose workgroup tile holds one query row of up to 80 neighbours
+    dict(N=300, E=3000, F=1, bs=100, k=64, al=[0.1, 0.1], be=[0.5, 0.95], warm=2000, nb=5, seed=204),
+    dict(N=200, E=2400, F=4, bs=80, k=80, al=[0.2], be=[0.5], warm=1600, nb=5, seed=205),
 ])
 def test_protocol_vs_oracle(oracle, cfg):
     """Larger seeded runs: T-PPR state bit-exact, embeddings / memory within 1e-4
@@ -505,6 +509,37 @@ def test_output_layer_kernels_agree(F, k, n):
         _capi.set_kernel_choice(_capi.CHOICE_EMBED_OUT, 0)
     for mode in ("latency", "persist", "auto"):
         assert np.array_equal(outs["tiled"], outs[mode]), mode
+
+
+def test_pipeline_with_wide_k_matches_sequential():
+    """k = 64 through the native step: the wide streaming path takes one batch per T-PPR launch (a requested group of 4 is
+    clamped), runs ahead on its stream like any other, and the step's results equal the sequential protocol's bit for bit."""
+    N, E, D, F, T, k, al, be, seed, bs = 200, 1200, 100, 1, 100, 64, [0.1, 0.1], [0.5, 0.95], 77, 100
+    src, dst, neg, ts, eidx = I.make_stream("general", N, E, seed)
+    w = I.model_weights(D, F, T, len(al), seed)
+    _, efeat = I.random_tables(N, E + 1, D, F, seed)
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (src, dst, neg, ts, eidx)]
+    batches = [tuple(x[a:a + bs] for x in t) for a in range(0, E, bs)]
+    outs = {}
+    for mode in ("seq", "pipe"):
+        tgn = build_tgn(N, E + 1, D, F, T, k, al, be, w, efeat).eval()
+        if mode == "pipe":
+            tgn.enable_pipeline(tppr_cus=0, max_batch=128, group=4)
+        main = getattr(tgn, "main_stream", None) or torch.cuda.current_stream()
+        with torch.cuda.stream(main):
+            embs = [tgn.step_device(*cur, ahead=batches[b + 1: b + 6] if mode == "pipe" else None).clone()
+                    for b, cur in enumerate(batches)]
+        torch.cuda.synchronize()
+        tgn.embedding_module.tppr_finder.check_status()
+        outs[mode] = (torch.stack(embs).cpu().numpy(), tgn.memory.memory.cpu().numpy(),
+                      [tgn.embedding_module.tppr_finder.export_state(m) for m in range(2)])
+        tgn.enable_pipeline(False)
+    assert np.array_equal(outs["seq"][0], outs["pipe"][0])
+    assert np.array_equal(outs["seq"][1], outs["pipe"][1])
+    for a, b in zip(outs["seq"][2], outs["pipe"][2]):
+        for kk in a:
+            assert np.array_equal(a[kk], b[kk]), kk
 
 
 def test_group_members_are_released_when_the_launch_is_rejected():
@@ -1250,7 +1285,7 @@ def test_projected_table_follows_memory_and_weights(oracle, F):
     step(2000, 2250)
 
 
-@pytest.mark.parametrize("F,k", [(1, 20), (172, 20), (4, 40)])
+@pytest.mark.parametrize("F,k", [(1, 20), (172, 20), (4, 40), (1, 64)])       # (k = 64: the wide streaming path under training)
 def test_fused_training_backward_full_dims(F, k):
     """The fused HIP training path (overlay forward + k_fc1_agg_bwd) at the real layer sizes (D = T = 100,
     two T-PPR models) against the torch composition of the same step, which fixture g8_train_grads pins to the
