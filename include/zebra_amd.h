@@ -41,8 +41,10 @@ extern "C" {
                                  * hub chains, pruning query) */
 #define ZT_MAX_K_WIDE 255       /* streaming T-PPR accepts k up to here (the reference's --topk is unbounded, train.py:46): beyond
                                  * ZT_MAX_K a correct-first path takes over -- one wavefront per model applies the edges in order
-                                 * (csrc/tppr_wide.hpp), same state layout, same results as the oracle bit for bit, not tuned.  The
-                                 * aggregation takes k <= 80 (one query row per workgroup tile); the pruning strategy k <= ZT_MAX_K */
+                                 * (csrc/tppr_wide.hpp), same state layout, same results as the oracle bit for bit, not tuned.  zt_embed
+                                 * takes such rows through the generic kernel's 16-tile instantiation (k <= 80 in any case; up to 255
+                                 * over the projected table, where a query row's tile fits LDS); the training kernels k <= 80; the
+                                 * pruning strategy k <= ZT_MAX_K */
 
 /* Human-readable description of the last failure on this thread. */
 const char *zt_last_error(void);

@@ -94,6 +94,9 @@ def test_embeddings_golden_all_batches():
     # generic aggregation kernel, whose workgroup tile holds one query row of up to 80 neighbours
     dict(N=300, E=3000, F=1, bs=100, k=64, al=[0.1, 0.1], be=[0.5, 0.95], warm=2000, nb=5, seed=204),
     dict(N=200, E=2400, F=4, bs=80, k=80, al=[0.2], be=[0.5], warm=1600, nb=5, seed=205),
+    # ... and beyond 80: the generic kernel's 16-tile instantiation over the projected table (one query row of up to 255)
+    dict(N=150, E=3000, F=1, bs=100, k=128, al=[0.1, 0.1], be=[0.5, 0.95], warm=2400, nb=4, seed=206),
+    dict(N=90, E=2700, F=4, bs=60, k=255, al=[0.2], be=[0.8], warm=2400, nb=4, seed=207),
 ])
 def test_protocol_vs_oracle(oracle, cfg):
     """Larger seeded runs: T-PPR state bit-exact, embeddings / memory within 1e-4

@@ -26,6 +26,7 @@ using namespace zt;
 namespace {
 
 constexpr int MAX_MT = 5;          // M-tiles (16 gathered rows each) per workgroup
+constexpr int MAX_MT_BIG = 16;     // ... of the instantiation for 80 < k <= 255 (k_fc1_agg<TAB, MAX_MT_BIG>)
 constexpr int LDS_BUDGET = 150 * 1024;
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -61,7 +62,10 @@ __global__ void k_pad_matrix(const float *__restrict__ W, int ld, int c0, int ro
 // changes: at most 2B rows per batch instead of 3B*k*M gathered rows).  The accumulators START from the
 // gathered P rows, the tile holds only [ef | cos] and the contraction runs over F + T columns: for F = 1
 // half the matrix work and none of the memory-row staging.  `memory` then points at P and D is the row stride Dp.
-template <bool TAB>
+// MMT: M-tiles a workgroup can hold.  MAX_MT (5: 80 gathered rows) for every k <= 80; MAX_MT_BIG (16) is instantiated for
+// 80 < k <= 255 -- a query row of that many neighbours must still fit ONE workgroup's tile (dictionaries wider than a
+// wavefront: tppr_wide.hpp; correct first, not tuned).
+template <bool TAB, int MMT = MAX_MT>
 __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     const float *__restrict__ memory, const float *__restrict__ efeat, const float *__restrict__ time_w,
     long long num_nodes, long long num_edges, int D, int F, int T, long long N, int k, int rq, int mt_count, int lda,
@@ -137,9 +141,9 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
     AGG_STAMP(0);
     // accumulators: zero, or (TAB) the projected rows P[nbr[row]][col] -- issued before the staging below so that the
     // memory round trip is hidden behind it; the MFMAs then accumulate on top of them
-    f32x4 acc[MAX_MT][NTW];
+    f32x4 acc[MMT][NTW];
 #pragma unroll
-    for (int a = 0; a < MAX_MT; ++a)
+    for (int a = 0; a < MMT; ++a)
 #pragma unroll
         for (int b = 0; b < NTW; ++b) {
             acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -351,16 +355,16 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
 #pragma unroll
                 for (int b = 0; b < NTW; ++b) bnext[b] = *reinterpret_cast<const f32x4 *>(bp[b] + 16 * (kc + 1));
             }
-            f32x4 av[MAX_MT];
+            f32x4 av[MMT];
 #pragma unroll
-            for (int a = 0; a < MAX_MT; ++a)
+            for (int a = 0; a < MMT; ++a)
                 av[a] = a < mt_count
                             ? *reinterpret_cast<const f32x4 *>(A + (size_t)(a * 16 + r16) * lda + 16 * kc + 4 * g4)
                             : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int a = 0; a < MAX_MT; ++a)
+                for (int a = 0; a < MMT; ++a)
 #pragma unroll
                     for (int b = 0; b < NTW; ++b)
                         if (a < mt_count && live[b])
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(AGG_THREADS) void k_fc1_agg(
         const int col = (wave + b * AGG_WAVES) * 16 + r16;
         const float bias = col < Dout ? b1[col] : 0.f;
 #pragma unroll
-        for (int a = 0; a < MAX_MT; ++a) {
+        for (int a = 0; a < MMT; ++a) {
             if (a >= mt_count) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1250,20 +1254,21 @@ struct EmbedPlan {
     size_t lds2;
     size_t off_w1p, off_H, off_S, off_fc2t, off_fc1st, off_fc2st, off_w1t, off_wm, off_wl, off_wfrag, total;
     int hg;                                     // partial-sum groups per query row in H (k_fc1_agg_wide: k / 4; else 1)
+    bool big;                                   // k > 80: the MAX_MT_BIG instantiation of the generic kernel (mt = 0: that path's tile does not fit)
 };
 
 // tile shape for a contraction over Kp columns: as many whole query rows as fit MAX_MT tiles / the LDS budget
-bool tile_shape(int Kp, int Dp, int k, int T, int *lda_out, int *mt_out, int *rq_out, size_t *lds_out)
+bool tile_shape(int Kp, int Dp, int k, int T, int *lda_out, int *mt_out, int *rq_out, size_t *lds_out, int max_mt = MAX_MT)
 {
     const int lda = Kp + 4;
-    int mt = MAX_MT;
+    int mt = max_mt;
     while (mt > 1 && ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) --mt;
     int rq = (mt * 16) / k;
     if (rq < 1) {
         // one query row must fit: grow to ceil(k/16) tiles if the budget allows
         mt = (k + 15) / 16;
         rq = 1;
-        if (mt > MAX_MT || ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) return false;
+        if (mt > max_mt || ((size_t)mt * 16 * lda * 4 + (size_t)mt * 16 * 16) > (size_t)LDS_BUDGET) return false;
     }
     mt = (rq * k + 15) / 16;
     // the hidden staging [rows_p][Dp+1] reuses the A region: it must fit
@@ -1278,10 +1283,17 @@ bool make_plan(int64_t N, int D, int F, int T, int M, int k, EmbedPlan &p)
     const int K1 = D + F + T;
     p.Dp = round_up(D, 16);
     p.K1p = round_up(K1, 16);
-    if (!tile_shape(p.K1p, p.Dp, k, T, &p.lda, &p.mt, &p.rq, &p.lds)) return false;
+    p.big = k > MAX_MT * 16;
+    const int max_mt = p.big ? MAX_MT_BIG : MAX_MT;
+    const bool full_ok = tile_shape(p.K1p, p.Dp, k, T, &p.lda, &p.mt, &p.rq, &p.lds, max_mt);
+    if (!full_ok) {
+        if (!p.big) return false;
+        p.mt = 0; p.rq = 1; p.lda = p.K1p + 4; p.lds = 0;       // (wide k: only the table path's narrower tile may fit)
+    }
     p.K2p = round_up(F + T, 16);
     p.mt2 = 0;                                  // table path unavailable (e.g. F + T < D: the staging would not fit)
-    if (!tile_shape(p.K2p, p.Dp, k, T, &p.lda2, &p.mt2, &p.rq2, &p.lds2)) p.mt2 = 0;
+    if (!tile_shape(p.K2p, p.Dp, k, T, &p.lda2, &p.mt2, &p.rq2, &p.lds2, max_mt)) p.mt2 = 0;
+    if (p.mt == 0 && p.mt2 == 0) return false;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
     // padded weights first: their offsets depend on (D, F, T) only, so a workspace prepared once serves every N
@@ -1429,10 +1441,20 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
     const bool tab = proj_table_dev != nullptr && p.mt2 > 0;
     const size_t lds = tab ? p.lds2 : p.lds;
     static size_t attr_lds[2] = {0, 0};
+    if (!tab && p.mt == 0) {
+        set_error("zt_embed: k=%d needs the projected table (a query row's [memory | ef | time] tile does not fit %d KB of LDS)", k, LDS_BUDGET / 1024);
+        return ZT_ERR_UNSUPPORTED;
+    }
     if (lds > 48 * 1024 && lds > attr_lds[tab ? 1 : 0]) {
         const void *fn = tab ? reinterpret_cast<const void *>(k_fc1_agg<true>) : reinterpret_cast<const void *>(k_fc1_agg<false>);
         ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds[tab ? 1 : 0] = lds;
+    }
+    static size_t attr_big[2] = {0, 0};
+    if (p.big && lds > 48 * 1024 && lds > attr_big[tab ? 1 : 0]) {
+        const void *fn = tab ? reinterpret_cast<const void *>(k_fc1_agg<true, MAX_MT_BIG>) : reinterpret_cast<const void *>(k_fc1_agg<false, MAX_MT_BIG>);
+        ZT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_big[tab ? 1 : 0] = lds;
     }
     // the reference's default widths take the specialised kernels (zt_set_kernel_choice(ZT_CHOICE_AGGREGATE, ZT_AGG_GENERIC): the generic one)
     const bool generic = zt::kernel_choice(ZT_CHOICE_AGGREGATE) == ZT_AGG_GENERIC;
@@ -1500,14 +1522,24 @@ static int embed_impl(const float *memory_dev, const float *efeat_dev, int64_t n
 #undef ZT_D100
     } else if (tab) {
         dim3 grid((unsigned)((N + p.rq2 - 1) / p.rq2), (unsigned)M);
-        k_fc1_agg<true><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
-                                                       T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,
-                                                       p.K2p, wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
+        if (p.big)
+            k_fc1_agg<true, MAX_MT_BIG><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
+                                                                   T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,
+                                                                   p.K2p, wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
+        else
+            k_fc1_agg<true><<<grid, AGG_THREADS, lds, s>>>(proj_table_dev, efeat_dev, wt->time_w, num_nodes, num_edges, p.Dp, F,
+                                                           T, N, k, p.rq2, p.mt2, p.lda2, nbr_dev, eix_dev, dt_dev, w_dev, W1t,
+                                                           p.K2p, wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
     } else {
         dim3 grid((unsigned)((N + p.rq - 1) / p.rq), (unsigned)M);
-        k_fc1_agg<false><<<grid, AGG_THREADS, lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N,
-                                                        k, p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
-                                                        wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
+        if (p.big)
+            k_fc1_agg<false, MAX_MT_BIG><<<grid, AGG_THREADS, lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N,
+                                                                    k, p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
+                                                                    wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
+        else
+            k_fc1_agg<false><<<grid, AGG_THREADS, lds, s>>>(memory_dev, efeat_dev, wt->time_w, num_nodes, num_edges, D, F, T, N,
+                                                            k, p.rq, p.mt, p.lda, nbr_dev, eix_dev, dt_dev, w_dev, W1p, p.K1p,
+                                                            wt->fc1_b, H, S, status_dev, D, nullptr, nullptr);
     }
     ZT_PROF_END(s, P_FC1_AGG);
     if (mid_wait != nullptr) ZT_HIP(hipStreamWaitEvent(s, mid_wait, 0));
@@ -1683,6 +1715,10 @@ extern "C" int zt_agg_train_forward(const float *memory_dev, const float *overla
     EmbedPlan p;
     if (D > 128 || !make_plan(N, D, F, T, M, k, p)) {
         set_error("zt_agg_train_forward: unsupported shape");
+        return ZT_ERR_UNSUPPORTED;
+    }
+    if (p.big) {
+        set_error("zt_agg_train_forward: k=%d: the training kernels hold a query row of at most %d neighbours", k, MAX_MT * 16);
         return ZT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
