@@ -44,7 +44,8 @@ extern "C" {
                                  * (csrc/tppr_wide.hpp), same state layout, same results as the oracle bit for bit, not tuned.  zt_embed
                                  * takes such rows through the generic kernel's 16-tile instantiation (k <= 80 in any case; up to 255
                                  * over the projected table, where a query row's tile fits LDS); the training kernels k <= 80; the
-                                 * pruning strategy k <= ZT_MAX_K */
+                                 * pruning query any k up to here (its kept set strides over the lanes; the selection beyond
+                                 * ZT_MAX_K is the generic replay of numba_sort.hpp) */
 
 /* Human-readable description of the last failure on this thread. */
 const char *zt_last_error(void);

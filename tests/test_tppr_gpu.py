@@ -385,6 +385,27 @@ def test_pruning_vs_oracle_superuser_shape(zt, oracle):
                                                                  (np.int32, np.int32, np.float32, np.float32)])
 
 
+@pytest.mark.parametrize("k,width,depth,beta", [(64, 12, 2, 0.5), (100, 20, 2, 0.5), (255, 30, 2, 0.8), (80, 6, 3, 0.95)])
+def test_pruning_wide_k_vs_oracle(zt, oracle, k, width, depth, beta):
+    """get_pruned_topk with k beyond a wavefront (the reference puts no bound on --topk, train.py:46): the kept set strides
+    over the lanes and the selection is the generic replay; beta = 0.5 makes exact ties at the cut.  Bit-identical to the
+    oracle, rows with fewer than k candidates included."""
+    N, E = 400, 24000
+    src, dst, neg, ts, eidx = I.make_stream("hub", N, E, 305)
+    nf = zt.get_neighbor_finder(types.SimpleNamespace(sources=src, destinations=dst, edge_idxs=eidx, timestamps=ts))
+    csr = oracle.CsrOracle(src, dst, eidx, ts, nf.num_nodes)
+    s = E - 300
+    q = np.concatenate([src[s:], dst[s:], neg[s:]])
+    qt = np.concatenate([ts[s:]] * 3)
+    outs_a = [np.zeros((900, k), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+    outs_b = [np.zeros((900, k), dt) for dt in (np.int32, np.int32, np.float32, np.float32)]
+    nf.get_pruned_topk(q, qt, width, depth, 0.1, beta, k, *outs_a)
+    csr.get_pruned_topk(q, qt, width, depth, 0.1, beta, k, *outs_b)
+    for x, y, nm in zip(outs_a, outs_b, ("nodes", "eidx", "dt", "w")):
+        assert np.array_equal(x, y), nm
+    assert (outs_b[3][:, 0] != 0).any() and (np.count_nonzero(outs_b[3], axis=1) == k).any()     # some rows are full
+
+
 @pytest.mark.parametrize("n,k", [(16, 5), (17, 5), (31, 20), (41, 20), (41, 40), (63, 31), (64, 20), (65, 31), (81, 40),
                                  (100, 50), (127, 63), (128, 20), (11, 5), (21, 10)])
 def test_exact_topk_selection_paths(zt, oracle, n, k):

@@ -820,4 +820,44 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
     return 2;
 }
 
+// np.argsort(values)[-k:] in numba's order for ANY k (kept sets wider than a wavefront: tppr_wide.hpp, the pruning query with
+// k > ZT_MAX_K) and any n: ranks by counting where no tie reaches the kept ranks, the wave-parallel replay up to 128
+// candidates, one lane's literal replay beyond (and for NaN).  a, sel (>= k), S, seq_perm (>= n), seq_stk (>= 96): LDS of
+// this wave.  Correct first: the rank pass is n reads per candidate.
+__device__ inline void topk_select_any(const double *a, int n, int k, int *sel, SortLds &S, int *seq_perm, int *seq_stk)
+{
+    const int lane = lane_id();
+    const int drop = n - k;
+    bool slow = false, has_nan = false;
+    for (int c = lane; c < ((n + WAVE - 1) / WAVE) * WAVE; c += WAVE) {
+        int lt = 0, eq = 0;
+        const bool live = c < n;
+        const double v = live ? a[c] : 0.0;
+        const bool nan = live && (v != v);
+        for (int q = 0; q < n; ++q) {
+            const double x = a[q];
+            lt += (x < v) ? 1 : 0;
+            eq += (x == v) ? 1 : 0;
+        }
+        eq -= 1;                                     // itself
+        const bool bad = live && (nan || (eq > 0 && lt + eq >= drop));
+        if (__ballot(bad) != 0ull) slow = true;
+        if (__ballot(nan) != 0ull) has_nan = true;
+        if (!slow && live && !nan && lt >= drop) sel[lt - drop] = c;
+    }
+    wave_sync();
+    if (!slow) return;
+    if (n <= 128 && !has_nan) {
+        numba_argsort_wave(a, n, S);
+        for (int q = lane; q < k; q += WAVE) sel[q] = S.r2[drop + q];
+        wave_sync();
+        return;
+    }
+    if (lane == 0) {
+        numba_argsort_seq(a, n, seq_perm, seq_stk);
+        for (int q = 0; q < k; ++q) sel[q] = seq_perm[drop + q];
+    }
+    wave_sync();
+}
+
 }  // namespace zt

@@ -46,7 +46,7 @@ struct PruneLds {
     double *ts;             // [cap_c]
     double *w;              // [M][cap_c] weight of every occurrence, per model
     int *perm;              // [cap_c] owner frontier entry of a new state (walk) / first occurrence (merge) / sort scratch
-    int *sel;               // 64
+    int *sel;               // 64 (k <= ZT_MAX_K) or 256
     int *stk;               // 96
     int *f_cnt;             // [cap_f] per frontier entry: number of states it emits
     int *f_off;             // [cap_f] exclusive scan of f_cnt
@@ -58,13 +58,15 @@ struct PruneLds {
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-__host__ __device__ inline size_t prune_lds_bytes(int cap_c, int cap_f, int M)
+// (sel: 64 entries for k <= ZT_MAX_K -- the tuned configurations keep their LDS footprint --, 256 for the wider k)
+__host__ __device__ inline size_t prune_sel_words(int k) { return k <= 64 ? 64 : 256; }
+__host__ __device__ inline size_t prune_lds_bytes(int cap_c, int cap_f, int M, int k)
 {
-    return (2 + (size_t)M) * align16((size_t)cap_c * 8) + align16((size_t)cap_c * 4) + align16(64 * 4) + align16(96 * 4) +
+    return (2 + (size_t)M) * align16((size_t)cap_c * 8) + align16((size_t)cap_c * 4) + align16(prune_sel_words(k) * 4) + align16(96 * 4) +
            3 * align16((size_t)cap_f * 4) + (1 + (size_t)M) * align16((size_t)cap_f * 8) + align16(sizeof(SortLds));
 }
 
-__device__ inline PruneLds carve(char *base, int cap_c, int cap_f, int M)
+__device__ inline PruneLds carve(char *base, int cap_c, int cap_f, int M, int k)
 {
     PruneLds L;
     char *p = base;
@@ -72,7 +74,7 @@ __device__ inline PruneLds carve(char *base, int cap_c, int cap_f, int M)
     L.ts = reinterpret_cast<double *>(p); p += align16((size_t)cap_c * 8);
     L.w = reinterpret_cast<double *>(p); p += (size_t)M * align16((size_t)cap_c * 8);
     L.perm = reinterpret_cast<int *>(p); p += align16((size_t)cap_c * 4);
-    L.sel = reinterpret_cast<int *>(p); p += align16(64 * 4);
+    L.sel = reinterpret_cast<int *>(p); p += align16(prune_sel_words(k) * 4);
     L.stk = reinterpret_cast<int *>(p); p += align16(96 * 4);
     L.f_cnt = reinterpret_cast<int *>(p); p += align16((size_t)cap_f * 4);
     L.f_off = reinterpret_cast<int *>(p); p += align16((size_t)cap_f * 4);
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = pm.M;
-    const PruneLds L = carve(smem + (threadIdx.x / WAVE) * prune_lds_bytes(cap_c, cap_f, M), cap_c, cap_f, M);
+    const PruneLds L = carve(smem + (threadIdx.x / WAVE) * prune_lds_bytes(cap_c, cap_f, M, k), cap_c, cap_f, M, k);
     const size_t wst = align16((size_t)cap_c * 8) / 8, bst = align16((size_t)cap_f * 8) / 8;   // model strides (doubles)
     const int lane = lane_id();
     const long long qi = (long long)blockIdx.x * PR_WAVES + threadIdx.x / WAVE;
@@ -127,10 +129,10 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
         if (lane == 0) atomicExch(status, ZT_ERR_RANGE);
         // (zero_empty: nobody cleared the slot -- the row would keep the previous group's neighbours and the aggregation of
         //  this step, whose caller may never look at the status word, would consume them: an empty row instead)
-        if (zero_empty && lane < k)
+        if (zero_empty)
             for (int m = 0; m < M; ++m) {
                 const long long ob = (long long)m * out_stride + qi * k;
-                out_nodes[ob + lane] = 0; out_eidx[ob + lane] = 0; out_w[ob + lane] = 0.f; out_dt[ob + lane] = 0.f;
+                for (int j = lane; j < k; j += WAVE) { out_nodes[ob + j] = 0; out_eidx[ob + j] = 0; out_w[ob + j] = 0.f; out_dt[ob + j] = 0.f; }
             }
         return;
     }
@@ -231,10 +233,10 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
     if (n_cand == 0) {                                              // :241-242, row untouched
         // (zero_empty: the caller's output arrays are not cleared beforehand -- pipeline.hip: a memset in front of every
         //  query is a packet on the T-PPR stream, ~6 us of every C4 step -- so an empty row is written here, as zeros)
-        if (zero_empty && lane < k)
+        if (zero_empty)
             for (int m = 0; m < M; ++m) {
                 const long long ob = (long long)m * out_stride + qi * k;
-                out_nodes[ob + lane] = 0; out_eidx[ob + lane] = 0; out_w[ob + lane] = 0.f; out_dt[ob + lane] = 0.f;
+                for (int j = lane; j < k; j += WAVE) { out_nodes[ob + j] = 0; out_eidx[ob + j] = 0; out_w[ob + j] = 0.f; out_dt[ob + j] = 0.f; }
             }
         return;
     }
@@ -314,25 +316,27 @@ __global__ __launch_bounds__(WAVE * PR_WAVES) void k_pruned_topk(
     for (int m = 0; m < M; ++m) {
         const long long ob = (long long)m * out_stride + qi * k;
         const double *wm = L.w + m * wst;
+        // (k <= ZT_MAX_K: one pass, lane j = entry j; wider k -- the reference puts no bound on --topk, train.py:46 -- strides)
         if (nd <= k) {
-            if (lane < k) {
-                const bool a = lane < nd;
-                out_nodes[ob + lane] = a ? (int)(unsigned)(L.key[lane] & 0xffffffffull) : 0;
-                out_eidx[ob + lane] = a ? (int)(unsigned)(L.key[lane] >> 32) : 0;
-                out_w[ob + lane] = a ? (float)wm[lane] : 0.f;
-                const float tsf = a ? (float)L.ts[lane] : 0.f;
-                out_dt[ob + lane] = (float)(qt - (double)tsf);
+            for (int j = lane; j < k; j += WAVE) {
+                const bool a = j < nd;
+                out_nodes[ob + j] = a ? (int)(unsigned)(L.key[j] & 0xffffffffull) : 0;
+                out_eidx[ob + j] = a ? (int)(unsigned)(L.key[j] >> 32) : 0;
+                out_w[ob + j] = a ? (float)wm[j] : 0.f;
+                const float tsf = a ? (float)L.ts[j] : 0.f;
+                out_dt[ob + j] = (float)(qt - (double)tsf);
             }
             continue;
         }
         if (dbg_stop == 4 || (dbg_stop == 3 && nd > WAVE)) { if (lane < k) L.sel[lane] = lane; wave_sync(); }   // (diagnostic)
-        else topk_select_wave(wm, nd, k, L.sel, *L.sort, L.perm, L.stk);
-        if (lane < k) {
-            const int c = L.sel[lane];
-            out_nodes[ob + lane] = (int)(unsigned)(L.key[c] & 0xffffffffull);
-            out_eidx[ob + lane] = (int)(unsigned)(L.key[c] >> 32);
-            out_w[ob + lane] = (float)wm[c];
-            out_dt[ob + lane] = (float)(qt - (double)(float)L.ts[c]);
+        else if (k <= ZT_MAX_K) topk_select_wave(wm, nd, k, L.sel, *L.sort, L.perm, L.stk);
+        else topk_select_any(wm, nd, k, L.sel, *L.sort, L.perm, L.stk);      // kept sets wider than a wavefront: correct first
+        for (int j = lane; j < k; j += WAVE) {
+            const int c = L.sel[j];
+            out_nodes[ob + j] = (int)(unsigned)(L.key[c] & 0xffffffffull);
+            out_eidx[ob + j] = (int)(unsigned)(L.key[c] >> 32);
+            out_w[ob + j] = (float)wm[c];
+            out_dt[ob + j] = (float)(qt - (double)(float)L.ts[c]);
         }
         wave_sync();
     }
@@ -473,9 +477,9 @@ static int pruned_launch(const zt_csr *c, const int32_t *q_nodes_dev, const doub
 {
     long long cap = 0, lvl = 1, front = 1;
     for (int d = 0; d < depth; ++d) { front = lvl; lvl *= width; cap += lvl; if (cap > MAX_CAND) break; }
-    if (k > ZT_MAX_K || cap > MAX_CAND || front > MAX_FRONT) {
+    if (k > ZT_MAX_K_WIDE || cap > MAX_CAND || front > MAX_FRONT) {
         set_error("zt_pruned_topk: k=%d width=%d depth=%d exceeds the LDS-resident limits "
-                  "(k<=%d, sum width^d<=%d)", k, width, depth, ZT_MAX_K, MAX_CAND);
+                  "(k<=%d, sum width^d<=%d)", k, width, depth, ZT_MAX_K_WIDE, MAX_CAND);
         return ZT_ERR_UNSUPPORTED;
     }
     const int cap_c = (int)cap, cap_f = (int)front;
@@ -487,11 +491,11 @@ static int pruned_launch(const zt_csr *c, const int32_t *q_nodes_dev, const doub
     for (int m0 = 0; m0 < M;) {
         // as many models per launch as the workgroup's LDS allows (at least one)
         int mm = M - m0 < PR_MAX_MODELS ? M - m0 : PR_MAX_MODELS;
-        while (mm > 1 && prune_lds_bytes(cap_c, cap_f, mm) * PR_WAVES > 64 * 1024) --mm;
+        while (mm > 1 && prune_lds_bytes(cap_c, cap_f, mm, k) * PR_WAVES > 64 * 1024) --mm;
         PruneModels pm;
         pm.M = mm;
         for (int q = 0; q < mm; ++q) { pm.alpha[q] = alpha[m0 + q]; pm.beta[q] = beta[m0 + q]; }
-        const size_t lds = prune_lds_bytes(cap_c, cap_f, mm) * PR_WAVES;
+        const size_t lds = prune_lds_bytes(cap_c, cap_f, mm, k) * PR_WAVES;
         static size_t attr_lds = 0;
         if (lds > 48 * 1024 && lds > attr_lds) {
             ZT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_pruned_topk),

@@ -86,44 +86,6 @@ __device__ inline void wide_load(const u64 *base, int k, int lane, WideLds &L, i
     if (lane == 0) { L.len[side] = len; L.norm[side] = __longlong_as_double((long long)(((u64)h2 << 32) | h1)); }
 }
 
-// np.argsort(values)[-k:] in numba's order (numba_sort.hpp), for any n <= WIDE_CAND and any k: ranks by counting where no
-// tie reaches the kept ranks, the wave-parallel replay up to 128 candidates, one lane's literal replay beyond (and for NaN)
-__device__ inline void wide_topk(const double *a, int n, int k, WideLds &L)
-{
-    const int lane = lane_id();
-    const int drop = n - k;
-    bool slow = false, has_nan = false;
-    for (int c = lane; c < ((n + WAVE - 1) / WAVE) * WAVE; c += WAVE) {
-        int lt = 0, eq = 0;
-        const bool live = c < n;
-        const double v = live ? a[c] : 0.0;
-        const bool nan = live && (v != v);
-        for (int q = 0; q < n; ++q) {
-            const double x = a[q];
-            lt += (x < v) ? 1 : 0;
-            eq += (x == v) ? 1 : 0;
-        }
-        eq -= 1;                                     // itself
-        const bool bad = live && (nan || (eq > 0 && lt + eq >= drop));
-        if (__ballot(bad) != 0ull) slow = true;
-        if (__ballot(nan) != 0ull) has_nan = true;
-        if (!slow && live && !nan && lt >= drop) L.sel[lt - drop] = c;
-    }
-    wave_sync();
-    if (!slow) return;
-    if (n <= 128 && !has_nan) {
-        numba_argsort_wave(a, n, L.sort);
-        for (int q = lane; q < k; q += WAVE) L.sel[q] = L.sort.r2[drop + q];
-        wave_sync();
-        return;
-    }
-    if (lane == 0) {
-        numba_argsort_seq(a, n, L.perm, L.stk);
-        for (int q = 0; q < k; ++q) L.sel[q] = L.perm[drop + q];
-    }
-    wave_sync();
-}
-
 // One wavefront per emitted model; edges in order.
 __global__ __launch_bounds__(WAVE) void k_stream_wide(zt_tppr h, StreamArgs A)
 {
@@ -216,7 +178,7 @@ __global__ __launch_bounds__(WAVE) void k_stream_wide(zt_tppr h, StreamArgs A)
             }
             // ---- keep the top k (:549-564) and store the row; the norm moves by norm * beta + beta (:567-574) ----
             const int n_new = n <= k ? n : k;
-            if (n > k) wide_topk(L.cw, n, k, L);
+            if (n > k) topk_select_any(L.cw, n, k, L.sel, L.sort, L.perm, L.stk);
             u64 *dst = p == 0 ? bu : bv;
             for (int j = lane; j < n_new; j += WAVE) {
                 const int c = n > k ? L.sel[j] : j;
