@@ -25,6 +25,8 @@ def one(seed, tppr, pyoracle, torch):
     if cap > 1000:
         depth = 2
     k = int(rng.choice([1, 5, 10, 20, 40, 63]))
+    if os.environ.get("ZT_SOAK_K"):                      # (round 6: kept sets wider than a wavefront, e.g. ZT_SOAK_K=100)
+        k = int(os.environ["ZT_SOAK_K"])
     M = int(rng.choice([1, 2, 3]))
     al = [float(rng.choice([0.0, 0.1, 0.3])) for _ in range(M)]
     be = [float(rng.choice([0.5, 0.25, 0.8, 0.95])) for _ in range(M)]

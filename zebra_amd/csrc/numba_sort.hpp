@@ -820,11 +820,145 @@ __device__ inline int topk_select_wave(const double *a, int n, int k, int *sel, 
     return 2;
 }
 
+// ---------------------------------------------------------------------------
+// The wave-parallel replay for MORE than 128 candidates (round 6: kept sets wider than a wavefront, tppr_wide.hpp -- up to
+// 2 x 255 + 1 candidates).  partition_wave / numba_argsort_wave above hold two positions per lane; here SLOTS of them (the
+// same partition: stop lists from ballots, the m-th i-stop swapped with the m-th j-stop while it lies to its left), over an
+// LDS block of its own size.  Kept apart from the 128-candidate form, which sits on k_stream's and k_pruned_topk's hot
+// paths with its LDS footprint.
+// ---------------------------------------------------------------------------
+template <int SLOTS>
+struct SortLdsN {
+    static constexpr int CAP = WAVE * SLOTS;
+    int r[CAP], r2[CAP];
+    int ilist[CAP + 2], jlist[CAP + 2];
+    double v[CAP];
+    short seg_lo[CAP], seg_hi[CAP];
+    int stk[96];
+};
+
+template <int SLOTS>
+__device__ inline int partition_wave_n(const double *a, SortLdsN<SLOTS> &S, int low, int high)
+{
+    const int lane = lane_id();
+    const int mid = (low + high) >> 1;
+    int rl = S.r[low], rm = S.r[mid], rh = S.r[high];
+    double al = a[rl], am = a[rm], ah = a[rh];
+    if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+    if (lt_f(ah, am)) { int t = rh; rh = rm; rm = t; double x = ah; ah = am; am = x; }
+    if (lt_f(am, al)) { int t = rl; rl = rm; rm = t; double x = al; al = am; am = x; }
+    const double pivot = am;
+    wave_sync();
+    if (lane == 0) { S.r[low] = rl; S.r[mid] = rh; S.r[high] = rm; }   // pivot stashed at `high`
+    wave_sync();
+    const u64 below = lanemask_lt();
+    const u64 above = ~below & ~(1ull << lane);
+    u64 GE[SLOTS], LE[SLOTS];
+    bool ge[SLOTS], le[SLOTS];
+    const int nslot = (high - low + WAVE - 1) / WAVE;     // slots this segment reaches into (wave-uniform): the others are skipped
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        GE[q] = 0ull; LE[q] = 0ull; ge[q] = false; le[q] = false;
+        if (q >= nslot) continue;
+        const int p = low + lane + q * WAVE;
+        const bool in = p <= high - 1;
+        const double v = in ? a[S.r[p]] : 0.0;
+        ge[q] = in && !lt_f(v, pivot);
+        le[q] = in && !lt_f(pivot, v);
+        GE[q] = __ballot(ge[q]);
+        LE[q] = __ballot(le[q]);
+    }
+    int nI = 0, nJ = 0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {                     // i-stops ascending: slot by slot, lanes upwards
+        if (q >= nslot) continue;
+        if (ge[q]) S.ilist[nI + __popcll(GE[q] & below)] = low + lane + q * WAVE;
+        nI += __popcll(GE[q]);
+    }
+#pragma unroll
+    for (int q = SLOTS - 1; q >= 0; --q) {                // j-stops descending: the last slot first, lanes downwards
+        if (q >= nslot) continue;
+        if (le[q]) S.jlist[nJ + __popcll(LE[q] & above)] = low + lane + q * WAVE;
+        nJ += __popcll(LE[q]);
+    }
+    if (lane == 0) { S.ilist[nI] = high; S.jlist[nJ] = low - 1; }
+    wave_sync();
+    const int npair = (nI < nJ ? nI : nJ);                // sentinels never swap
+    int M = 0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        if (q * WAVE >= npair) continue;                  // (wave-uniform)
+        const int m = lane + q * WAVE;
+        bool sw = false;
+        int pi = 0, pj = 0;
+        if (m < npair) { pi = S.ilist[m]; pj = S.jlist[m]; sw = pi < pj; }
+        if (sw) { const int x = S.r[pi], y = S.r[pj]; S.r[pi] = y; S.r[pj] = x; }
+        M += __popcll(__ballot(sw));
+    }
+    int ifin = S.ilist[M];
+    if (M > 0) { const int jl = S.jlist[M - 1]; ifin = jl < ifin ? jl : ifin; }
+    ifin = __builtin_amdgcn_readfirstlane(ifin);
+    wave_sync();
+    if (lane == 0) { const int t = S.r[ifin]; S.r[ifin] = S.r[high]; S.r[high] = t; }
+    wave_sync();
+    return ifin;
+}
+
+// Full argsort for 2 <= n <= 64 SLOTS, no NaN.  Result in S.r2[0..n).  (numba_argsort_wave's body over the wider block.)
+template <int SLOTS>
+__device__ inline void numba_argsort_wave_n(const double *a, int n, SortLdsN<SLOTS> &S)
+{
+    const int lane = lane_id();
+    for (int p = lane; p < n; p += WAVE) S.r[p] = p;
+    if (lane == 0) { S.stk[0] = 0; S.stk[1] = n - 1; }
+    wave_sync();
+    int sp = 1;
+    while (sp > 0) {
+        --sp;
+        int low = __builtin_amdgcn_readfirstlane(S.stk[2 * sp]);
+        int high = __builtin_amdgcn_readfirstlane(S.stk[2 * sp + 1]);
+        wave_sync();
+        while (high - low >= 15) {
+            const int i = partition_wave_n<SLOTS>(a, S, low, high);
+            if (lane == 0) { S.seg_lo[i] = (short)i; S.seg_hi[i] = (short)i; }   // the pivot is in its final place
+            if (high - i > i - low) {
+                if (high > i) { if (lane == 0) { S.stk[2 * sp] = i + 1; S.stk[2 * sp + 1] = high; } ++sp; }
+                high = i - 1;
+            } else {
+                if (i > low) { if (lane == 0) { S.stk[2 * sp] = low; S.stk[2 * sp + 1] = i - 1; } ++sp; }
+                low = i + 1;
+            }
+        }
+        for (int p = low + lane; p <= high; p += WAVE) { S.seg_lo[p] = (short)low; S.seg_hi[p] = (short)high; }   // (<= 15 entries)
+        wave_sync();
+    }
+    // stable rank inside every segment (= insertion sort with strict <)
+    for (int p = lane; p < n; p += WAVE) S.v[p] = a[S.r[p]];
+    wave_sync();
+    for (int p = lane; p < n; p += WAVE) {
+        const int lo = S.seg_lo[p], hi = S.seg_hi[p];
+        const double v = S.v[p];
+        int rank = 0;
+        for (int q = lo; q <= hi; ++q) {
+            const double x = S.v[q];
+            rank += (x < v || (x == v && q < p)) ? 1 : 0;
+        }
+        S.r2[lo + rank] = S.r[p];
+    }
+    wave_sync();
+}
+
 // np.argsort(values)[-k:] in numba's order for ANY k (kept sets wider than a wavefront: tppr_wide.hpp, the pruning query with
-// k > ZT_MAX_K) and any n: ranks by counting where no tie reaches the kept ranks, the wave-parallel replay up to 128
-// candidates, one lane's literal replay beyond (and for NaN).  a, sel (>= k), S, seq_perm (>= n), seq_stk (>= 96): LDS of
-// this wave.  Correct first: the rank pass is n reads per candidate.
-__device__ inline void topk_select_any(const double *a, int n, int k, int *sel, SortLds &S, int *seq_perm, int *seq_stk)
+// k > ZT_MAX_K) and any n: ranks by counting where no tie reaches the kept ranks, else the wave-parallel replay while the
+// candidates fit the sort block (128 for SortLds, 64 SLOTS for SortLdsN), one lane's literal replay beyond (and for NaN).
+// a, sel (>= k), S, seq_perm (>= n), seq_stk (>= 96): LDS of this wave.
+__device__ __forceinline__ int sort_cap(const SortLds &) { return 128; }
+template <int SLOTS> __device__ __forceinline__ int sort_cap(const SortLdsN<SLOTS> &) { return WAVE * SLOTS; }
+__device__ __forceinline__ void sort_wave(const double *a, int n, SortLds &S) { numba_argsort_wave(a, n, S); }
+template <int SLOTS> __device__ __forceinline__ void sort_wave(const double *a, int n, SortLdsN<SLOTS> &S) { numba_argsort_wave_n<SLOTS>(a, n, S); }
+
+template <class SL>
+__device__ inline void topk_select_any(const double *a, int n, int k, int *sel, SL &S, int *seq_perm, int *seq_stk)
 {
     const int lane = lane_id();
     const int drop = n - k;
@@ -834,10 +968,16 @@ __device__ inline void topk_select_any(const double *a, int n, int k, int *sel, 
         const bool live = c < n;
         const double v = live ? a[c] : 0.0;
         const bool nan = live && (v != v);
-        for (int q = 0; q < n; ++q) {
-            const double x = a[q];
-            lt += (x < v) ? 1 : 0;
-            eq += (x == v) ? 1 : 0;
+        for (int q0 = 0; q0 < n; q0 += 8) {          // 8 broadcast reads in flight per step
+            double x[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = a[(q0 + t) < n ? (q0 + t) : (n - 1)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool in = (q0 + t) < n;
+                lt += (in && x[t] < v) ? 1 : 0;
+                eq += (in && x[t] == v) ? 1 : 0;
+            }
         }
         eq -= 1;                                     // itself
         const bool bad = live && (nan || (eq > 0 && lt + eq >= drop));
@@ -847,8 +987,8 @@ __device__ inline void topk_select_any(const double *a, int n, int k, int *sel, 
     }
     wave_sync();
     if (!slow) return;
-    if (n <= 128 && !has_nan) {
-        numba_argsort_wave(a, n, S);
+    if (n <= sort_cap(S) && !has_nan) {
+        sort_wave(a, n, S);
         for (int q = lane; q < k; q += WAVE) sel[q] = S.r2[drop + q];
         wave_sync();
         return;

@@ -5,11 +5,15 @@
 // as the reference's loop does (utils/util.py:473-576): no prepass, no tags to poll, no chains -- a wave that works alone
 // needs none of them.  The state is the SAME row of granules (tppr_state.hpp: header + six entry-major arrays of k), so
 // reset, copy, export / import, checkpoints and snapshots are the code every other k uses; tags are written as 0.
-//   per edge (u, v, fake), per model:  emit the three rows as they are (:504-506), load the old rows of u and v into LDS,
+//   per edge (u, v, fake), per model:  the rows of u, v and the negative sample into LDS (all requested together: one memory
+//   round trip up to k = 128, two beyond), emit the three rows as they are (:504-506),
 //   build t_s1_PPR for (u <- v) and (v <- u) from the OLD rows (:509-547: scale, merge by key in dictionary order, the new
 //   key last), keep the top k in numba's argsort order when there are more (:555-564; numba_sort.hpp), store, move the norms.
-// Cost: ~20-60 us per edge and model.  A wide k is a quality knob of the reference, not the configuration its throughput
-// is quoted on (BASELINE.json: k = 20 / 40).
+// Cost with full rows and both models of C5's (alpha, beta) side by side (tools/exp/wide_k_cost.py, profiles/r6/experiments/
+// wide_k_cost.log): 80 / 154 / 591 us per edge at k = 64 / 100 / 255 -- the numba-order selection over 2k + 1 candidates is
+// most of it (a rank pass of n reads per candidate, then, where ties reach the kept set, the wave-parallel quicksort replay
+// over up to 512 positions: numba_sort.hpp, SortLdsN) -- against 5 us at k = 63 on the same stream.  A wide k is a quality knob
+// of the reference, not the configuration its throughput is quoted on (BASELINE.json: k = 20 / 40).
 #pragma once
 
 #include "tppr_hop.hpp"
@@ -21,16 +25,16 @@ constexpr int WIDE_ROW = 256;                    // entries of one old row in LD
 constexpr int WIDE_CAND = 2 * WIDE_ROW;          // candidates of one update: k + k + 1 <= 511
 
 struct WideLds {
-    u64 rk[2][WIDE_ROW];                         // the old rows of u (side 0) and v (side 1)
-    double rt[2][WIDE_ROW], rw[2][WIDE_ROW];
+    u64 rk[3][WIDE_ROW];                         // the old rows of u (side 0), v (side 1) and the negative sample (side 2)
+    double rt[3][WIDE_ROW], rw[3][WIDE_ROW];
     u64 ck[WIDE_CAND];                           // t_s1_PPR in dictionary order
     double ct[WIDE_CAND], cw[WIDE_CAND];
     int sel[WIDE_ROW];                           // the kept candidates in output order
     int perm[WIDE_CAND];                         // scratch of the sequential argsort replay
     int stk[96];
-    SortLds sort;
-    int len[2];
-    double norm[2];
+    SortLdsN<WIDE_CAND / WAVE> sort;             // the wave-parallel argsort replay over all 512 candidate positions
+    int len[3];
+    double norm[3];
 };
 
 // ids of a launch: the conditions of the prepass's k_count (tppr_prepass.hip: d_count) -- every node id in [0, N), every
@@ -51,39 +55,57 @@ __global__ void k_wide_begin(int *ctl) { if (threadIdx.x == 0) { ctl[2] = 0; ctl
 
 __device__ __forceinline__ u64 wide_lo(u64 g) { return (u64)(unsigned)g; }
 
-// extract_streaming_tppr (utils/util.py:447-469) for one row, straight from its granules
-__device__ inline void wide_emit(const u64 *base, int k, int lane, double tnow, int *on, int *oe, float *od, float *ow)
+// The rows of an edge's nodes into LDS in as few memory round trips as the wave's load queue allows: the headers and the
+// entries of ALL sides are requested together, 128 entries per side and trip, whatever the rows' lengths (entries beyond a
+// row's length are never looked at).  n_sides = 2: u and v; 3: the negative sample as well.
+__device__ inline void wide_load(u64 *const *base, int n_sides, int k, int lane, WideLds &L)
 {
-    const int len = (int)(unsigned)ld_agent(base);
-    for (int j = lane; j < k; j += WAVE) {
-        const bool a = j < len;
-        const u64 *e = base + HDR + j;
-        u64 g0 = 0, g1 = 0, g2 = 0, g3 = 0, g4 = 0, g5 = 0;
-        if (a) { g0 = ld_agent(e); g1 = ld_agent(e + k); g2 = ld_agent(e + 2 * k); g3 = ld_agent(e + 3 * k); g4 = ld_agent(e + 4 * k); g5 = ld_agent(e + 5 * k); }
-        const double ts = __longlong_as_double((long long)((wide_lo(g3) << 32) | wide_lo(g2)));
-        const double w = __longlong_as_double((long long)((wide_lo(g5) << 32) | wide_lo(g4)));
-        on[j] = a ? (int)(unsigned)g0 : 0;
-        oe[j] = a ? (int)(unsigned)g1 : 0;
-        ow[j] = a ? (float)w : 0.f;
-        const float tsf = a ? (float)ts : 0.f;                 // tmp_timestamps is float32
-        od[j] = len == 0 ? 0.f : (float)(tnow - (double)tsf);  // (an empty dictionary leaves the zero row: :450)
+    u64 h[3] = {0ull, 0ull, 0ull};
+#pragma unroll
+    for (int sd = 0; sd < 3; ++sd)
+        if (sd < n_sides && lane < 3) h[sd] = ld_agent(base[sd] + lane);
+    for (int j0 = lane; j0 < k; j0 += 2 * WAVE) {
+        u64 g[3][2][6];
+#pragma unroll
+        for (int sd = 0; sd < 3; ++sd)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = j0 + t * WAVE;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) g[sd][t][c] = (sd < n_sides && j < k) ? ld_agent(base[sd] + HDR + j + c * k) : 0ull;
+            }
+#pragma unroll
+        for (int sd = 0; sd < 3; ++sd)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = j0 + t * WAVE;
+                if (sd < n_sides && j < k) {
+                    L.rk[sd][j] = (wide_lo(g[sd][t][1]) << 32) | wide_lo(g[sd][t][0]);
+                    L.rt[sd][j] = __longlong_as_double((long long)((wide_lo(g[sd][t][3]) << 32) | wide_lo(g[sd][t][2])));
+                    L.rw[sd][j] = __longlong_as_double((long long)((wide_lo(g[sd][t][5]) << 32) | wide_lo(g[sd][t][4])));
+                }
+            }
+    }
+#pragma unroll
+    for (int sd = 0; sd < 3; ++sd) {
+        const unsigned h0 = (unsigned)__shfl((unsigned)h[sd], 0), h1 = (unsigned)__shfl((unsigned)h[sd], 1), h2 = (unsigned)__shfl((unsigned)h[sd], 2);
+        if (sd < n_sides && lane == 0) { L.len[sd] = (int)h0; L.norm[sd] = __longlong_as_double((long long)(((u64)h2 << 32) | h1)); }
     }
 }
 
-__device__ inline void wide_load(const u64 *base, int k, int lane, WideLds &L, int side)
+// extract_streaming_tppr (utils/util.py:447-469) for one row, from its copy in LDS
+__device__ inline void wide_emit(const WideLds &L, int side, int k, int lane, double tnow, int *on, int *oe, float *od, float *ow)
 {
-    const u64 h = lane < 3 ? ld_agent(base + lane) : 0ull;
-    const unsigned h0 = (unsigned)__shfl((unsigned)h, 0), h1 = (unsigned)__shfl((unsigned)h, 1), h2 = (unsigned)__shfl((unsigned)h, 2);
-    const int len = (int)h0;
-    for (int j = lane; j < len; j += WAVE) {
-        const u64 *e = base + HDR + j;
-        const u64 g0 = ld_agent(e), g1 = ld_agent(e + k), g2 = ld_agent(e + 2 * k), g3 = ld_agent(e + 3 * k), g4 = ld_agent(e + 4 * k),
-                  g5 = ld_agent(e + 5 * k);
-        L.rk[side][j] = (wide_lo(g1) << 32) | wide_lo(g0);
-        L.rt[side][j] = __longlong_as_double((long long)((wide_lo(g3) << 32) | wide_lo(g2)));
-        L.rw[side][j] = __longlong_as_double((long long)((wide_lo(g5) << 32) | wide_lo(g4)));
+    const int len = L.len[side];
+    for (int j = lane; j < k; j += WAVE) {
+        const bool a = j < len;
+        const u64 key = a ? L.rk[side][j] : 0ull;
+        on[j] = (int)(unsigned)(key & 0xffffffffull);
+        oe[j] = (int)(unsigned)(key >> 32);
+        ow[j] = a ? (float)L.rw[side][j] : 0.f;
+        const float tsf = a ? (float)L.rt[side][j] : 0.f;      // tmp_timestamps is float32
+        od[j] = len == 0 ? 0.f : (float)(tnow - (double)tsf);  // (an empty dictionary leaves the zero row: :450)
     }
-    if (lane == 0) { L.len[side] = len; L.norm[side] = __longlong_as_double((long long)(((u64)h2 << 32) | h1)); }
 }
 
 // One wavefront per emitted model; edges in order.
@@ -109,20 +131,19 @@ __global__ __launch_bounds__(WAVE) void k_stream_wide(zt_tppr h, StreamArgs A)
         const double tnow = A.tsv[i];
         const u64 eid = (u64)A.eidx[i];
         u64 *bu = rows + u * rg, *bv = rows + v * rg;
-        // ---- the three output rows, as the dictionaries are BEFORE this edge (:504-506) ----
-        if (A.emit) {
-            const long long ou = ob + (long long)i * k, ov = ob + (A.role_stride + i) * k;
-            wide_emit(bu, k, lane, tnow, A.out_nodes + ou, A.out_eidx + ou, A.out_dt + ou, A.out_w + ou);
-            wide_emit(bv, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
-            if (A.n_roles == 3) {
-                const long long g = A.nodes[2 * A.role_stride + i], og = ob + (2 * A.role_stride + i) * k;
-                wide_emit(rows + g * rg, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
-            }
-        }
-        // ---- the old rows: both updates read them (PPR_list is replaced only after both, :566-574) ----
-        wide_load(bu, k, lane, L, 0);
-        if (u != v) wide_load(bv, k, lane, L, 1);
+        // ---- the rows of u, v (and the negative sample) as they are BEFORE this edge: one or two memory round trips ----
+        const bool fake = A.emit && A.n_roles == 3;
+        u64 *bases[3] = {bu, bv, fake ? rows + (long long)A.nodes[2 * A.role_stride + i] * rg : bu};
+        wide_load(bases, fake ? 3 : 2, k, lane, L);
         wave_sync();
+        // ---- the three output rows (:504-506) ----
+        if (A.emit) {
+            const long long ou = ob + (long long)i * k, ov = ob + (A.role_stride + i) * k, og = ob + (2 * A.role_stride + i) * k;
+            wide_emit(L, 0, k, lane, tnow, A.out_nodes + ou, A.out_eidx + ou, A.out_dt + ou, A.out_w + ou);
+            wide_emit(L, 1, k, lane, tnow, A.out_nodes + ov, A.out_eidx + ov, A.out_dt + ov, A.out_w + ov);
+            if (fake) wide_emit(L, 2, k, lane, tnow, A.out_nodes + og, A.out_eidx + og, A.out_dt + og, A.out_w + og);
+        }
+        // ---- both updates read the OLD rows (PPR_list is replaced only after both, :566-574): side 0 = u, side 1 = v ----
         const int n_pairs = u != v ? 2 : 1;
         for (int p = 0; p < n_pairs; ++p) {
             const int s1 = p, s2 = u != v ? 1 - p : 0;
