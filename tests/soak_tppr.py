@@ -45,6 +45,21 @@ def one(seed, tppr, pyoracle):
     eidx = np.arange(1, E + 1, dtype=np.int64)
     if os.environ.get("ZT_SOAK_K"):
         k = int(os.environ["ZT_SOAK_K"])
+    if os.environ.get("ZT_SOAK_MAX_N"):                  # (round 6, with a wide ZT_SOAK_K: dense rows, ties over 2k + 1 candidates,
+        cap = int(os.environ["ZT_SOAK_MAX_N"])           #  in a few hundred edges -- the wide path is ~100 us per edge)
+        if N > cap or bs * nb > 40 * cap:
+            N = min(N, cap)
+            bs = min(bs, 10 * cap)
+            nb = min(nb, 3)
+            E = bs * nb
+            p = 1.0 / np.arange(1, N) ** expo
+            p /= p.sum()
+            perm = rng.permutation(N - 1) + 1
+            src = perm[rng.choice(N - 1, E, p=p)].astype(np.int32)
+            dst = perm[rng.choice(N - 1, E, p=p)].astype(np.int32)
+            neg = perm[rng.choice(N - 1, E, p=p)].astype(np.int32)
+            ts = np.cumsum(rng.randint(0, 3, E)).astype(np.float64)
+            eidx = np.arange(1, E + 1, dtype=np.int64)
     if os.environ.get("ZT_SOAK_VERBOSE"):
         print("seed %d: N=%d k=%d bs=%d nb=%d M=%d alpha=%s beta=%s expo=%.1f" % (seed, N, k, bs, nb, M, al, be, expo), flush=True)
     f = tppr.tppr_finder(N, k, M, al, be)

@@ -211,6 +211,8 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v)
 // (s_ff1 / v_readlane / v_writelane / s_andn2 ...: 9 instructions x 64 = ~580 per claim, on a chain workgroup whose instruction
 // issue is what bounds a hub chain); `atomicAdd(p, 1)` by every lane with a pointer the compiler cannot prove uniform is 64
 // atomics to one address (~10 ns each at the memory side).  Here: exec = lane 0 for the one instruction.
+// PRECONDITION: called in wave-uniform control flow with every lane active (the top of k_stream's two queue loops) -- lane 0
+// issues the add with ITS copy of the operands, and the result is read from lane 0.
 // Returns the value before the add, wave-uniform.  p: LDS.
 __device__ __forceinline__ int wave_claim_lds(int *p, int v)
 {
