@@ -4,7 +4,7 @@
 #   (run it with tools/exp/bench_lib.py tools/out/libzebra_NAME.so <bench.py args>)
 # The alternatives that were measured slower than the library's pick are variant builds too (their sources: tools/exp/variants/):
 #   tools/build_variant.sh chainvariants "-DZT_CHAIN_VARIANTS"                            (paired / spine / duo hub chains)
-#   tools/build_variant.sh prepasscoop "-DZT_PREPASS_COOP_VARIANT" tppr_prepass.hip       (the prepass as one cooperative kernel)
+#   tools/build_variant.sh prepasscoop "-DZT_PREPASS_COOP_VARIANT -mllvm -amdgpu-atomic-optimizer-strategy=DPP" tppr_prepass.hip   (the prepass as one cooperative kernel; the second flag is what zebra_amd/build.py compiles that file with)
 #   ZT_TEST_LIB=tools/out/chainvariants/libzebra_amd.so python -m pytest tests/test_tppr_gpu.py -m gpu -k "paired or spine or duo"
 set -e
 NAME=${1:?name}; FLAGS=$2; SRC=${3:-tppr_stream.hip}
