@@ -509,6 +509,14 @@ extern "C" int zt_pipeline_step_ahead(zt_pipeline *p, const zt_batch *cur, const
     // group -- on a stream without a CU mask -- are left with the T-PPR stream's compute units, beside the hub chains.
     zt::member_gate gate = {nullptr, 0, p->latch_dev};
     if (s->by_member) {
+        // The counters are zeroed by the group's staging kernel, on another stream: the gate must not look at them before that
+        // kernel has run -- what is left there from the slot's previous group IS a full count.  In practice the staging is two
+        // launch groups ahead of this step; by construction it is this wait, once per group (`filled` is recorded behind the
+        // staging and the plan; the T-PPR launch that counts waits for it too).
+        if (!s->waited) {
+            if (hipEventQuery(s->filled) != hipSuccess) { (void)hipGetLastError(); ZT_HIP(hipStreamWaitEvent(p->main_s, s->filled, 0)); }
+            s->waited = true;
+        }
         gate.word = s->mdone + j; gate.target = (int32_t)(s->B[j] * d.M);
         // (inside the kernel only where the T-PPR stream has compute units of its own: a persistent aggregation kernel that
         //  waits on EVERY compute unit of an unmasked device, registers full, would keep out the very launch it waits for)
